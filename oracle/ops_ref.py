@@ -1,0 +1,427 @@
+"""TEST INFRASTRUCTURE ONLY — CPU semantics of every s2k stage, and a program emulator.
+
+Each function below states, with plain torch CPU ops, what one stage record
+(`sentinel2-landcover-classification_amd/plan/opdefs.py`) must compute.  Two uses:
+  * tests/test_plan_cpu.py runs whole planned programs through `run_program` and compares with
+    oracle autograd — this validates the planner (the hand-derived backward) without a GPU;
+  * tests/test_ops_gpu.py runs single-stage programs through the HIP C-ABI and compares with
+    the same functions.
+The arithmetic mirrors the reference's torch calls (F.conv2d / F.batch_norm / ... as used in
+/root/reference/src/modules/efficientnet_unet.py and losses.py); nothing here is product code.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32}
+
+
+class Mem:
+    """Byte-addressed bases (one flat uint8 CPU tensor each).
+
+    wide=True: every f32 tensor is held as float64 at twice its byte offset (the bases must be
+    allocated twice as large).  Running a planned program this way against a float64 oracle
+    checks the planner's algebra to ~1e-12, free of the fp32 noise that small-batch BatchNorm
+    and ReLU masks amplify to ~1e-2 in the gradients."""
+
+    def __init__(self, bases: dict[int, torch.Tensor], wide: bool = False, narrow_bases=()):
+        self.bases = bases
+        self.wide = wide
+        self.narrow = set(narrow_bases)
+        self.fdtype = torch.float64 if wide else torch.float32
+
+    def addr(self, ref: int, elem_off: int = 0) -> int:
+        """ref advanced by elem_off f32 elements."""
+        return ref + elem_off * 4
+
+    def view(self, ref: int, shape, dtype="f32", strides=None) -> torch.Tensor | None:
+        if ref < 0:
+            return None
+        base, off = ref >> 56, ref & ((1 << 56) - 1)
+        if self.wide and base not in self.narrow:
+            off *= 2
+            if dtype == "f32":
+                dtype = "f64"
+        dt = _DT[dtype]
+        isz = torch.empty((), dtype=dt).element_size()
+        buf = self.bases[base]
+        assert off % isz == 0
+        flat = buf.view(torch.uint8)[off:].view(dt) if off else buf.view(torch.uint8).view(dt)
+        n = int(np.prod(shape)) if strides is None else None
+        if strides is None:
+            return flat[:n].view(*shape)
+        return torch.as_strided(flat, tuple(shape), tuple(strides))
+
+
+def _pro(x, bnv, gate, pro, C):
+    """prologue: act(scale*x+shift) * gate[b][c]; bnv rows = scale, shift, mean, invstd."""
+    if pro != 0:
+        x = x * bnv[0].view(1, C, 1, 1) + bnv[1].view(1, C, 1, 1)
+        if pro == 2:
+            x = F.silu(x)
+        elif pro == 3:
+            x = F.relu(x)
+    if gate is not None:
+        x = x * gate.view(gate.shape[0], C, 1, 1)
+    return x
+
+
+def _act_grad(u, act):
+    if act == 2:
+        s = torch.sigmoid(u)
+        return s * (1 + u * (1 - s))
+    if act == 3:
+        return (u > 0).to(u.dtype)
+    return torch.ones_like(u)
+
+
+def _unshuffle2(x):  # [B,C,2H,2W] -> [B,C*4,H,W] with k = (c,dy,dx)
+    B, C, H2, W2 = x.shape
+    return x.view(B, C, H2 // 2, 2, W2 // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(B, C * 4, H2 // 2, W2 // 2)
+
+
+def _shuffle2(z, Cout):  # [B,4*Cout,H,W] rows (co,dy,dx) -> [B,Cout,2H,2W]
+    B, _, H, W = z.shape
+    return z.view(B, Cout, 2, 2, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, Cout, 2 * H, 2 * W)
+
+
+def _pad_to(x, pt, pl, k_h, k_w, s, Ho, Wo):
+    H, W = x.shape[-2:]
+    pb = (Ho - 1) * s + k_h - H - pt
+    pr = (Wo - 1) * s + k_w - W - pl
+    return F.pad(x, [pl, pr, pt, pb])
+
+
+def op_memset(m: Mem, o):
+    base, off = o["DST"] >> 56, o["DST"] & ((1 << 56) - 1)
+    k = 2 if (m.wide and base not in m.narrow) else 1
+    m.bases[base].view(torch.uint8)[off * k:(off + o["BYTES"]) * k].zero_()
+
+
+def op_axpy(m: Mem, o):
+    m.view(o["Y"], (o["COUNT"],)).add_(m.view(o["X"], (o["COUNT"],)))
+
+
+def op_conv(m: Mem, o):
+    B, C1, C2, H, W, M = o["B"], o["C1"], o["C2"], o["H"], o["W"], o["M"]
+    KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
+    T = KH * KW
+    Ct = C1 + C2
+    if mode == 2:
+        co = C1 // 4
+        x1 = _unshuffle2(m.view(o["X1"], (B, co, 2 * H, 2 * W)))
+    else:
+        x1 = m.view(o["X1"], (B, C1, H, W))
+    x = _pro(x1, m.view(o["BNV1"], (4, C1)), m.view(o["GATE1"], (B, C1)), o["PRO1"], C1)
+    if C2:
+        x2 = _pro(m.view(o["X2"], (B, C2, H, W)), m.view(o["BNV2"], (4, C2)), None, o["PRO2"], C2)
+        x = torch.cat([x, x2], 1)
+    wv = m.view(o["WT"], (M, Ct, T), strides=(o["W_SM"], o["W_SK"], o["W_ST"]))
+    if o["FLIP"]:
+        wv = wv.flip(2)
+    wv = wv.reshape(M, Ct, KH, KW)
+    y = F.conv2d(_pad_to(x, o["PAD_T"], o["PAD_L"], KH, KW, S, Ho, Wo), wv, None, S)
+    bias = m.view(o["BIAS"], (M // 4 if mode == 1 else M,))
+    YC = o["YC"]
+    if mode == 1:
+        y = _shuffle2(y, M // 4)
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        dst = m.view(o["Y"], (B, M // 4, 2 * Ho, 2 * Wo), strides=(YC * 4 * Ho * Wo, 4 * Ho * Wo, 2 * Wo, 1))
+    else:
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        dst = m.view(o["Y"], (B, M, Ho, Wo), strides=(YC * Ho * Wo, Ho * Wo, Wo, 1))
+    if o["STATS"] >= 0:
+        st = m.view(o["STATS"], (2, M), "f64")
+        st[0] += y.double().sum((0, 2, 3))
+        st[1] += (y.double() ** 2).sum((0, 2, 3))
+    if o["BETA"]:
+        dst.add_(y)
+    else:
+        dst.copy_(y)
+
+
+def op_wgrad(m: Mem, o):
+    B, M, C, CT, H, W = o["B"], o["M"], o["C"], o["CTOT"], o["H"], o["W"]
+    KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
+    T = KH * KW
+    P = _pro(m.view(o["P"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
+    Q = _pro(m.view(o["Q"], (B, C, H, W)), m.view(o["BNVQ"], (4, C)), m.view(o["GATEQ"], (B, C)), o["PROQ"], C)
+    if mode == 2:
+        Qg = _unshuffle2(Q).view(B, C, 4, Ho * Wo)
+        dW = torch.einsum("bmp,bctp->tmc", P.reshape(B, M, Ho * Wo).double(), Qg.double())
+    else:
+        Qp = _pad_to(Q, o["PAD_T"], o["PAD_L"], KH, KW, S, Ho, Wo)
+        cols = F.unfold(Qp, (KH, KW), stride=S).view(B, C, T, Ho * Wo)
+        dW = torch.einsum("bmp,bctp->tmc", P.reshape(B, M, Ho * Wo).double(), cols.double())
+    m.view(o["WGS"], (T, M, C), strides=(M * CT, CT, 1)).add_(dW.to(m.fdtype))
+
+
+def op_wgrad_finalize(m: Mem, o):
+    tab = m.view(o["TABLE"], (o["N_ENTRIES"], 5), "i32")
+    for off, M, C, T, _ in tab.tolist():
+        src = m.view(m.addr(o["WGS"], off), (T, M, C))
+        dst = m.view(m.addr(o["GRADS"], off), (M, C, T))
+        dst.add_(src.permute(1, 2, 0))
+
+
+def _dw_geo(o):
+    return (o["B"], o["C"], o["H"], o["W"], o["K"], o["STRIDE"], o["PAD_T"], o["PAD_L"], o["HO"], o["WO"])
+
+
+def op_dwconv_fwd(m: Mem, o):
+    B, C, H, W, K, S, pt, pl, Ho, Wo = _dw_geo(o)
+    x = _pro(m.view(o["X"], (B, C, H, W)), m.view(o["BNV"], (4, C)), None, o["PRO"], C)
+    w = m.view(o["WT"], (C, 1, K, K))
+    y = F.conv2d(_pad_to(x, pt, pl, K, K, S, Ho, Wo), w, None, S, 0, 1, C)
+    m.view(o["Y"], (B, C, Ho, Wo)).copy_(y)
+    if o["STATS"] >= 0:
+        st = m.view(o["STATS"], (2, C), "f64")
+        st[0] += y.double().sum((0, 2, 3))
+        st[1] += (y.double() ** 2).sum((0, 2, 3))
+
+
+def op_dwconv_dgrad(m: Mem, o):
+    B, C, H, W, K, S, pt, pl, Ho, Wo = _dw_geo(o)
+    dy = m.view(o["DY"], (B, C, Ho, Wo))
+    w = m.view(o["WT"], (C, 1, K, K))
+    xd = torch.zeros(B, C, H, W, requires_grad=True, dtype=dy.dtype)
+    y = F.conv2d(_pad_to(xd, pt, pl, K, K, S, Ho, Wo), w, None, S, 0, 1, C)
+    (gx,) = torch.autograd.grad(y, xd, dy)
+    if o["PRO"] != 0:
+        bnv = m.view(o["BNV"], (4, C))
+        xr = m.view(o["XRAW"], (B, C, H, W))
+        u = xr * bnv[0].view(1, C, 1, 1) + bnv[1].view(1, C, 1, 1)
+        gx = gx * _act_grad(u, o["PRO"])
+        if o["STATS2"] >= 0:
+            xhat = (xr - bnv[2].view(1, C, 1, 1)) * bnv[3].view(1, C, 1, 1)
+            st = m.view(o["STATS2"], (2, C), "f64")
+            st[0] += gx.double().sum((0, 2, 3))
+            st[1] += (gx.double() * xhat.double()).sum((0, 2, 3))
+    g = m.view(o["G"], (B, C, H, W))
+    if o["BETA"]:
+        g.add_(gx)
+    else:
+        g.copy_(gx)
+
+
+def op_dwconv_wgrad(m: Mem, o):
+    B, C, H, W, K, S, pt, pl, Ho, Wo = _dw_geo(o)
+    dy = m.view(o["DY"], (B, C, Ho, Wo))
+    x = _pro(m.view(o["X"], (B, C, H, W)), m.view(o["BNV"], (4, C)), None, o["PRO"], C)
+    wd = torch.zeros(C, 1, K, K, requires_grad=True, dtype=dy.dtype)
+    y = F.conv2d(_pad_to(x, pt, pl, K, K, S, Ho, Wo), wd, None, S, 0, 1, C)
+    (gw,) = torch.autograd.grad(y, wd, dy)
+    m.view(o["DW"], (C, 1, K, K)).add_(gw)
+
+
+def op_bn_finalize(m: Mem, o):
+    C = o["C"]
+    gamma, beta = m.view(o["GAMMA"], (C,)), m.view(o["BETA"], (C,))
+    rm, rv = m.view(o["RM"], (C,)), m.view(o["RV"], (C,))
+    bnv = m.view(o["BNV"], (4, C))
+    if o["TRAIN"]:
+        n = float(o["COUNT"])
+        st = m.view(o["STATS"], (2, C), "f64")
+        mean = st[0] / n
+        var = (st[1] / n - mean * mean).clamp_min(0.0)
+        invstd = 1.0 / torch.sqrt(var + float(np.float32(o["EPS"])))
+        mom = float(np.float32(o["MOM"]))
+        rm.mul_(1 - mom).add_((mom * mean).to(m.fdtype))
+        rv.mul_(1 - mom).add_((mom * var * (n / max(n - 1.0, 1.0))).to(m.fdtype))
+        mean, invstd = mean.to(m.fdtype), invstd.to(m.fdtype)
+    else:
+        mean = rm.clone()
+        invstd = 1.0 / torch.sqrt(rv + o["EPS"])
+    scale = gamma * invstd
+    bnv[0] = scale
+    bnv[1] = beta - mean * scale
+    bnv[2] = mean
+    bnv[3] = invstd
+
+
+def op_se_pool(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    a = _pro(m.view(o["Y"], (B, C, HW, 1)), m.view(o["BNV"], (4, C)), None, o["PRO"], C)
+    m.view(o["POOL"], (B, C)).copy_(a.view(B, C, HW).mean(2))
+
+
+def op_se_fc(m: Mem, o):
+    B, C, Q = o["B"], o["C"], o["CSQ"]
+    pool = m.view(o["POOL"], (B, C))
+    hpre = pool @ m.view(o["W1"], (Q, C)).t() + m.view(o["B1"], (Q,))
+    g = F.silu(hpre) @ m.view(o["W2"], (C, Q)).t() + m.view(o["B2"], (C,))
+    m.view(o["HPRE"], (B, Q)).copy_(hpre)
+    m.view(o["GATE"], (B, C)).copy_(torch.sigmoid(g))
+
+
+def op_se_fc_bwd(m: Mem, o):
+    B, C, Q = o["B"], o["C"], o["CSQ"]
+    dgate, gate = m.view(o["DGATE"], (B, C)), m.view(o["GATE"], (B, C))
+    hpre, pool = m.view(o["HPRE"], (B, Q)), m.view(o["POOL"], (B, C))
+    W1, W2 = m.view(o["W1"], (Q, C)), m.view(o["W2"], (C, Q))
+    dgp = dgate * gate * (1 - gate)
+    h = F.silu(hpre)
+    m.view(o["DW2"], (C, Q)).add_(dgp.t() @ h)
+    m.view(o["DB2"], (C,)).add_(dgp.sum(0))
+    dhp = (dgp @ W2) * _act_grad(hpre, 2)
+    m.view(o["DW1"], (Q, C)).add_(dhp.t() @ pool)
+    m.view(o["DB1"], (Q,)).add_(dhp.sum(0))
+    m.view(o["DPOOL"], (B, C)).copy_(dhp @ W1)
+
+
+def op_se_bwd_reduce(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    a = _pro(m.view(o["Y"], (B, C, HW, 1)), m.view(o["BNV"], (4, C)), None, o["PRO"], C).view(B, C, HW)
+    m.view(o["DGATE"], (B, C)).copy_((m.view(o["G"], (B, C, HW)) * a).sum(2))
+
+
+def _dcs(m, o, B):
+    noise = m.view(o["NOISE"], (B,))
+    if noise is None:
+        return None
+    keep = np.float32(o["KEEP"])
+    return torch.floor(float(keep) + noise) / float(keep)
+
+
+def op_bn_bwd_reduce(m: Mem, o):
+    B, C, HW, act = o["B"], o["C"], o["HW"], o["ACT"]
+    g = m.view(o["G"], (B, C, HW)).clone()
+    y = m.view(o["Y"], (B, C, HW))
+    bnv = m.view(o["BNV"], (4, C))
+    mul, add = m.view(o["MULBC"], (B, C)), m.view(o["ADDBC"], (B, C))
+    if mul is not None:
+        g = g * mul.view(B, C, 1)
+    dcs = _dcs(m, o, B)
+    if dcs is not None:
+        g = g * dcs.view(B, 1, 1)
+    if add is not None:
+        g = g + add.view(B, C, 1) * float(np.float32(o["ADDSCALE"]))
+    u = y * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)
+    g = g * _act_grad(u, act)
+    xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
+    st = m.view(o["STATS2"], (2, C), "f64")
+    st[0] += g.double().sum((0, 2))
+    st[1] += (g.double() * xhat.double()).sum((0, 2))
+    m.view(o["GOUT"], (B, C, HW)).copy_(g)
+
+
+def op_bn_bwd_finalize(m: Mem, o):
+    C, n = o["C"], float(o["COUNT"])
+    st = m.view(o["STATS2"], (2, C), "f64")
+    gamma, bnv = m.view(o["GAMMA"], (C,)), m.view(o["BNV"], (4, C))
+    m.view(o["DGAMMA"], (C,)).add_(st[1].to(m.fdtype))
+    m.view(o["DBETA"], (C,)).add_(st[0].to(m.fdtype))
+    coef = m.view(o["COEF"], (3, C))
+    a = (gamma * bnv[3]).double()
+    coef[0] = a.to(m.fdtype)
+    coef[1] = (-a * st[1] / n).to(m.fdtype)
+    coef[2] = (-a * st[0] / n).to(m.fdtype)
+
+
+def op_bn_bwd_apply(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    gp, y = m.view(o["GP"], (B, C, HW)), m.view(o["Y"], (B, C, HW))
+    bnv, coef = m.view(o["BNV"], (4, C)), m.view(o["COEF"], (3, C))
+    xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
+    dy = coef[0].view(1, C, 1) * gp + coef[1].view(1, C, 1) * xhat + coef[2].view(1, C, 1)
+    m.view(o["DY"], (B, C, HW)).copy_(dy)
+
+
+def op_bn_residual(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    bnv = m.view(o["BNV"], (4, C))
+    v = m.view(o["Y"], (B, C, HW)) * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)
+    dcs = _dcs(m, o, B)
+    if dcs is not None:
+        v = v * dcs.view(B, 1, 1)
+    ident = m.view(o["IDENT"], (B, C, HW))
+    if ident is not None:
+        v = v + ident
+    m.view(o["XOUT"], (B, C, HW)).copy_(v)
+
+
+def op_channel_sum(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    m.view(o["OUT"], (C,)).add_(m.view(o["G"], (B, C, HW)).double().sum((0, 2)).to(m.fdtype))
+
+
+def _loss_value(lg, y, alpha, o):
+    from . import losses_ref
+
+    ign = o["IGNORE"]
+    if o["MODE"] == 0:
+        return losses_ref.cross_entropy(lg, y, alpha, float(np.float32(o["SMOOTH"])), ign)
+    return losses_ref.focal(lg, y, alpha, float(np.float32(o["GAMMA"])), float(np.float32(o["SMOOTH"])), ign,
+                            "sum" if o["REDUCE_SUM"] else "mean")
+
+
+def op_loss_fwd(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    lg = m.view(o["LOGITS"], (B, C, HW, 1))
+    y = m.view(o["LABELS"], (B, HW, 1), "i64")
+    alpha = m.view(o["ALPHA"], (C,))
+    m.view(o["LOSS"], (1,)).copy_(_loss_value(lg, y, alpha, o).reshape(1))
+
+
+def op_loss_bwd(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    lg = m.view(o["LOGITS"], (B, C, HW, 1)).clone().requires_grad_(True)
+    y = m.view(o["LABELS"], (B, HW, 1), "i64")
+    alpha = m.view(o["ALPHA"], (C,))
+    v = _loss_value(lg, y, alpha, o)
+    (g,) = torch.autograd.grad(v, lg)
+    m.view(o["DLOGITS"], (B, C, HW, 1)).copy_(g * m.view(o["GOUT"], (1,)))
+
+
+def op_argmax(m: Mem, o):
+    from . import losses_ref
+
+    B, C, HW = o["B"], o["C"], o["HW"]
+    m.view(o["MASK"], (B, HW, 1), "i64").copy_(losses_ref.class_mask(m.view(o["LOGITS"], (B, C, HW, 1))))
+
+
+DISPATCH = {
+    "MEMSET": op_memset, "AXPY": op_axpy, "CONV": op_conv, "WGRAD": op_wgrad, "WGRAD_FINALIZE": op_wgrad_finalize,
+    "DWCONV_FWD": op_dwconv_fwd, "DWCONV_DGRAD": op_dwconv_dgrad, "DWCONV_WGRAD": op_dwconv_wgrad,
+    "BN_FINALIZE": op_bn_finalize, "SE_POOL": op_se_pool, "SE_FC": op_se_fc, "SE_FC_BWD": op_se_fc_bwd,
+    "SE_BWD_REDUCE": op_se_bwd_reduce, "BN_BWD_REDUCE": op_bn_bwd_reduce, "BN_BWD_FINALIZE": op_bn_bwd_finalize,
+    "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
+    "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
+}
+
+
+def unpack(packed: np.ndarray, opdefs) -> list[tuple[str, dict]]:
+    """Decode packed S2kOp records back to (kind, fields) — the emulator consumes exactly what
+    the native executor would."""
+    names = {v: k for k, v in opdefs.KIND.items()}
+    out = []
+    for rec in packed:
+        kind = names[int(rec["kind"])]
+        t, n, d, f = opdefs.OPS[kind]
+        o = {}
+        for j, k in enumerate(t):
+            o[k] = int(rec["t"][j])
+        for j, k in enumerate(n):
+            o[k] = int(rec["n"][j])
+        for j, k in enumerate(d):
+            o[k] = int(rec["d"][j])
+        for j, k in enumerate(f):
+            o[k] = float(rec["f"][j])
+        out.append((kind, o))
+    return out
+
+
+def run_program(packed: np.ndarray, bases: dict[int, torch.Tensor], opdefs, wide: bool = False,
+                narrow_bases=()) -> None:
+    m = Mem(bases, wide, narrow_bases)
+    with torch.no_grad():
+        for kind, o in unpack(packed, opdefs):
+            if kind in ("DWCONV_DGRAD", "DWCONV_WGRAD", "LOSS_BWD"):
+                with torch.enable_grad():
+                    DISPATCH[kind](m, o)
+            else:
+                DISPATCH[kind](m, o)

@@ -1,0 +1,569 @@
+"""Planner for the EfficientNet-UNet hot path: emits the forward and backward stage programs.
+
+Mirrors the data flow of /root/reference/src/modules/efficientnet_unet.py (EfficientnetUnet.forward
+:125-138, EfficientNet.encode :251-263, MBConvBlock.forward :377-387) but as a static list of
+fused stages over a preplanned HBM arena:
+
+  * every conv writes its *raw* output once; BatchNorm batch statistics are accumulated in the
+    conv epilogue (f64), folded to {scale, shift, mean, invstd} by BN_FINALIZE, and the
+    normalise + activation (+ SE gate) is applied in the *consumer's* load prologue, so
+    activations are never materialised (except the MBConv block output, which has two consumers);
+  * channel concat in the decoder is two source pointers, never a copy;
+  * backward is emitted explicitly (no autograd graph): per BN a reduce / finalize / apply trio,
+    per conv a wgrad + dgrad pair on MFMA.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+from . import opdefs as D
+from .program import Arena, Program, TRef
+
+CAT_SIZES = {  # efficientnet_unet.py:154-165 (size[0:4]); size[4] generalised to 32 + in_channels
+    "b0": [592, 296, 152, 80], "b1": [592, 296, 152, 80], "b2": [600, 304, 152, 80],
+    "b3": [608, 304, 160, 88], "b4": [624, 312, 160, 88], "b5": [640, 320, 168, 88],
+    "b6": [656, 328, 168, 96], "b7": [672, 336, 176, 96],
+}
+
+
+@dataclass
+class BlockSpec:
+    kernel: int
+    stride: int
+    cin: int
+    cout: int
+    expand: int
+    se: int
+    residual: bool
+
+    @property
+    def cexp(self) -> int:
+        return self.cin * self.expand
+
+
+@dataclass
+class UnetSpec:
+    version: str
+    in_channels: int
+    num_classes: int
+    stem_out: int
+    head_out: int
+    blocks: list[BlockSpec]
+    bn_momentum: float          # already flipped (1 - config value), efficientnet_unet.py:53
+    bn_eps: float
+    drop_connect_rate: float | None
+
+
+def same_pads(size: int, k: int, s: int) -> tuple[int, int]:
+    """TF 'SAME' (efficientnet_unet.py:288-297): returns (out, pad_before)."""
+    out = math.ceil(size / s)
+    pad = max((out - 1) * s + (k - 1) + 1 - size, 0)
+    return out, pad // 2
+
+
+@dataclass
+class Act:
+    """A tensor as its consumers see it: raw NCHW data + the prologue that turns it into values."""
+    raw: TRef
+    C: int
+    H: int
+    W: int
+    bnv: TRef | None = None
+    pro: int = D.PRO_NONE
+    gate: TRef | None = None
+    needs_grad: bool = True
+    grad: TRef | None = None      # grad w.r.t. the prologue-applied value, [B,C,H,W]
+    grad_init: bool = False
+    # SE coupling (set by the SE record's backward, consumed by the producer's BN backward)
+    mulbc: TRef | None = None
+    addbc: TRef | None = None
+    addscale: float = 0.0
+    # set when a consumer's dgrad already applied act' and accumulated the BN-backward sums
+    fused_stats2: TRef | None = None
+
+
+@dataclass
+class ParamLayout:
+    params: dict = field(default_factory=dict)   # name -> (float offset, shape)
+    bufs: dict = field(default_factory=dict)     # running_mean / running_var -> (float offset, shape)
+    nbt: list = field(default_factory=list)      # names of num_batches_tracked, in order
+    n_params: int = 0
+    n_bufs: int = 0
+
+    def add_param(self, name, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        self.params[name] = (self.n_params, tuple(shape))
+        self.n_params += n
+
+    def add_buf(self, name, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        self.bufs[name] = (self.n_bufs, tuple(shape))
+        self.n_bufs += n
+
+
+@dataclass
+class UnetPlan:
+    spec: UnetSpec
+    B: int
+    H: int
+    W: int
+    training: bool
+    fwd: Program
+    bwd: Program | None
+    ws_bytes: int
+    aux_bytes: int
+    const_table: list           # int32 rows for WGRAD_FINALIZE
+    layout: ParamLayout
+    n_noise_rows: int
+    bwd_param_marks: list       # (op index in bwd, lowest float offset whose grads are final after it)
+    logits_shape: tuple
+    tensors: dict               # debug: name -> TRef
+
+
+class _P:
+    """Planner state."""
+
+    def __init__(self, spec: UnetSpec, layout: ParamLayout, B: int, H: int, W: int, training: bool):
+        self.spec, self.layout, self.B, self.H, self.W, self.training = spec, layout, B, H, W, training
+        self.ws = Arena(D.BASE["WS"])
+        self.aux = Arena(D.BASE["AUX"])
+        self.fwd = Program("unet_fwd")
+        self.bwd = Program("unet_bwd")
+        self.tape: list = []
+        self.table: list = []
+        self.table_total = 0
+        self.tensors: dict = {}
+        self.marks: list = []
+
+    # -- references into the flat parameter / grad / buffer bases --------------------------
+    def param(self, name) -> TRef:
+        off, shape = self.layout.params[name]
+        return TRef(D.BASE["PARAMS"], off * 4, shape, "f32", name)
+
+    def pgrad(self, name) -> TRef:
+        off, shape = self.layout.params[name]
+        return TRef(D.BASE["GRADS"], off * 4, shape, "f32", "d:" + name)
+
+    def wgs(self, name) -> TRef:
+        off, shape = self.layout.params[name]
+        return TRef(D.BASE["WGS"], off * 4, shape, "f32", "wgs:" + name)
+
+    def buf(self, name) -> TRef:
+        off, shape = self.layout.bufs[name]
+        return TRef(D.BASE["BUFS"], off * 4, shape, "f32", name)
+
+    def alloc(self, name, shape, dtype="f32") -> TRef:
+        t = self.ws.alloc(name, shape, dtype)
+        self.tensors[name] = t
+        return t
+
+    def grad_of(self, a: Act, name: str) -> TRef:
+        if a.grad is None:
+            a.grad = self.alloc("g:" + name, (self.B, a.C, a.H, a.W))
+        return a.grad
+
+    def table_entry(self, wname: str, M: int, C: int, T: int):
+        off, _ = self.layout.params[wname]
+        self.table.append((off, M, C, T, self.table_total))
+        self.table_total += M * C * T
+
+
+# ------------------------------------------------------------------------------------------
+# forward emission helpers (each also pushes a backward closure on the tape)
+# ------------------------------------------------------------------------------------------
+
+def _bn_forward(p: _P, prefix: str, y: TRef, C: int, count: int, stats: TRef | None, eps: float, mom: float) -> TRef:
+    bnv = p.alloc("bnv:" + prefix, (4, C))
+    p.fwd.add("BN_FINALIZE", STATS=stats, GAMMA=p.param(prefix + ".weight"), BETA=p.param(prefix + ".bias"),
+              RM=p.buf(prefix + ".running_mean"), RV=p.buf(prefix + ".running_var"), BNV=bnv,
+              COUNT=count, C=C, TRAIN=int(p.training), EPS=eps, MOM=mom)
+    return bnv
+
+
+def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: int, act: int,
+                 mulbc=None, addbc=None, addscale=0.0, noise=None, keep=1.0, inplace=True,
+                 pre_stats: TRef | None = None) -> TRef:
+    """REDUCE -> FINALIZE -> APPLY; returns dY (grad w.r.t. the raw conv output).
+    `pre_stats`: G already is g' and its sums were accumulated by the producer of G (fused dgrad)."""
+    B = p.B
+    if pre_stats is not None:
+        st2, gp = pre_stats, G
+    else:
+        st2 = p.aux.alloc("stats2:" + prefix, (2, C), "f64")
+        gp = G if inplace else p.alloc("gp:" + prefix, (B, C, HW))
+        p.bwd.add("BN_BWD_REDUCE", G=G, Y=y, BNV=bnv, MULBC=mulbc, ADDBC=addbc, NOISE=noise, GOUT=gp, STATS2=st2,
+                  B=B, C=C, HW=HW, ACT=act, KEEP=keep, ADDSCALE=addscale)
+    coef = p.alloc("coef:" + prefix, (3, C))
+    p.bwd.add("BN_BWD_FINALIZE", STATS2=st2, GAMMA=p.param(prefix + ".weight"), BNV=bnv,
+              DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COEF=coef,
+              COUNT=B * HW, C=C)
+    p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=coef, DY=gp, B=B, C=C, HW=HW)
+    return gp
+
+
+def _conv_geometry(src: Act, k: int, stride: int, same: bool):
+    if same:
+        Ho, pt = same_pads(src.H, k, stride)
+        Wo, pl = same_pads(src.W, k, stride)
+    else:  # nn.Conv2d(k, stride 1, padding k//2)
+        Ho, Wo, pt, pl = src.H, src.W, k // 2, k // 2
+    return Ho, Wo, pt, pl
+
+
+def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: int, stride: int,
+                      pt: int, pl: int, Ho: int, Wo: int, bias_grad_from: str | None):
+    """Backward of a dense conv given dY [B,M,Ho,Wo]."""
+    B = p.B
+    T = k * k
+    Ctot = sum(s.C for s in srcs)
+    p.table_entry(wname, M, Ctot, T)
+    c_off = 0
+    for s in srcs:
+        p.bwd.add("WGRAD", P=dY, BNVP=None, GATEP=None, Q=s.raw, BNVQ=s.bnv, GATEQ=s.gate,
+                  WGS=p.wgs(wname).at(c_off), B=B, M=M, C=s.C, CTOT=Ctot, H=s.H, W=s.W, KH=k, KW=k,
+                  STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=D.PRO_NONE, PROQ=s.pro,
+                  MODE=D.MODE_CONV)
+        c_off += s.C
+    if bias_grad_from is not None:
+        p.bwd.add("CHANNEL_SUM", G=dY, OUT=p.pgrad(bias_grad_from), B=B, C=M, HW=Ho * Wo)
+    c_off = 0
+    for i, s in enumerate(srcs):
+        if s.needs_grad:
+            assert stride == 1, "dgrad of strided dense conv is never needed on this path"
+            g = p.grad_of(s, f"{wname}.src{i}")
+            # dX[b][c][y][x] = sum_{m,tap} W[m][c_off+c][flip(tap)] * dY[b][m][y+ky-(k-1-pt)][...]
+            p.bwd.add("CONV", X1=dY, BNV1=None, GATE1=None, X2=None, BNV2=None,
+                      WT=p.param(wname).at(c_off * T), BIAS=None, Y=g, STATS=None,
+                      B=B, C1=M, C2=0, H=Ho, W=Wo, M=s.C, KH=k, KW=k, STRIDE=1,
+                      PAD_T=k - 1 - pt, PAD_L=k - 1 - pl, HO=s.H, WO=s.W, PRO1=D.PRO_NONE, PRO2=D.PRO_NONE,
+                      MODE=D.MODE_CONV, W_SM=T, W_SK=Ctot * T, W_ST=1, FLIP=1, BETA=int(s.grad_init), YC=s.C)
+            s.grad_init = True
+        c_off += s.C
+
+
+def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, stride: int, same: bool,
+            act: int, eps: float, mom: float, bias: str | None = None) -> Act:
+    """Dense conv (+bias) -> train/eval BatchNorm -> activation, output left virtual."""
+    B = p.B
+    Ho, Wo, pt, pl = _conv_geometry(srcs[0], k, stride, same)
+    y = p.alloc("y:" + wname, (B, M, Ho, Wo))
+    stats = p.aux.alloc("stats:" + bnprefix, (2, M), "f64") if p.training else None
+    s1 = srcs[0]
+    s2 = srcs[1] if len(srcs) > 1 else None
+    Ctot = sum(s.C for s in srcs)
+    T = k * k
+    p.fwd.add("CONV", X1=s1.raw, BNV1=s1.bnv, GATE1=s1.gate, X2=s2.raw if s2 else None,
+              BNV2=s2.bnv if s2 else None, WT=p.param(wname), BIAS=p.param(bias) if bias else None, Y=y,
+              STATS=stats, B=B, C1=s1.C, C2=s2.C if s2 else 0, H=s1.H, W=s1.W, M=M, KH=k, KW=k, STRIDE=stride,
+              PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO1=s1.pro, PRO2=s2.pro if s2 else 0, MODE=D.MODE_CONV,
+              W_SM=Ctot * T, W_SK=T, W_ST=1, FLIP=0, BETA=0, YC=M)
+    if s2 is not None:
+        assert s2.gate is None
+    bnv = _bn_forward(p, bnprefix, y, M, B * Ho * Wo, stats, eps, mom)
+    out = Act(y, M, Ho, Wo, bnv, act)
+
+    def backward():
+        if not out.grad_init:
+            raise RuntimeError(f"no gradient reached {wname}")
+        dY = _bn_backward(p, bnprefix, out.grad, y, bnv, M, Ho * Wo, act,
+                          out.mulbc, out.addbc, out.addscale, pre_stats=out.fused_stats2)
+        if bias:
+            pass  # a bias in front of BatchNorm has exactly zero gradient (sum of dY is 0); grads stay 0
+        _conv_dgrad_wgrad(p, wname, dY, srcs, M, k, stride, pt, pl, Ho, Wo, None)
+
+    p.tape.append(backward)
+    return out
+
+
+def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Act, M: int, ident: Act | None,
+                             dc_rate: float | None, eps: float, mom: float) -> Act:
+    """MBConv tail: 1x1 project -> BN -> [drop-connect] + identity, materialised (it has two consumers)."""
+    B = p.B
+    H, W = src.H, src.W
+    y = p.alloc("y:" + wname, (B, M, H, W))
+    stats = p.aux.alloc("stats:" + bnprefix, (2, M), "f64") if p.training else None
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=p.param(wname), BIAS=None,
+              Y=y, STATS=stats, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
+              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1, FLIP=0, BETA=0, YC=M)
+    bnv = _bn_forward(p, bnprefix, y, M, B * H * W, stats, eps, mom)
+    xout = p.alloc(f"x:block{idx}", (B, M, H, W))
+    use_dc = bool(ident is not None and dc_rate and p.training)
+    keep = 1.0 - dc_rate if use_dc else 1.0
+    noise = TRef(D.BASE["NOISE"], idx * B * 4, (B,), "f32", f"noise{idx}") if use_dc else None
+    p.fwd.add("BN_RESIDUAL", Y=y, BNV=bnv, IDENT=ident.raw if ident is not None else None, NOISE=noise,
+              XOUT=xout, B=B, C=M, HW=H * W, KEEP=keep)
+    if ident is not None:
+        assert ident.pro == D.PRO_NONE and ident.C == M
+    out = Act(xout, M, H, W)
+
+    def backward():
+        if not out.grad_init:
+            raise RuntimeError(f"no gradient reached block {idx}")
+        G = out.grad
+        if ident is not None and ident.needs_grad:
+            if not ident.grad_init:
+                ident.grad, ident.grad_init = G, True      # alias: later dgrads accumulate in place
+            else:
+                p.bwd.add("AXPY", X=G, Y=ident.grad, COUNT=B * M * H * W)
+        dY = _bn_backward(p, bnprefix, G, y, bnv, M, H * W, D.ACT_NONE, noise=noise, keep=keep, inplace=False)
+        _conv_dgrad_wgrad(p, wname, dY, [src], M, 1, 1, 0, 0, H, W, None)
+
+    p.tape.append(backward)
+    return out
+
+
+def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, eps: float, mom: float) -> Act:
+    B, C = p.B, src.C
+    Ho, pt = same_pads(src.H, k, stride)
+    Wo, pl = same_pads(src.W, k, stride)
+    y = p.alloc("y:" + wname, (B, C, Ho, Wo))
+    stats = p.aux.alloc("stats:" + bnprefix, (2, C), "f64") if p.training else None
+    assert src.gate is None
+    geo = dict(B=B, C=C, H=src.H, W=src.W, K=k, STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO=src.pro)
+    p.fwd.add("DWCONV_FWD", X=src.raw, BNV=src.bnv, WT=p.param(wname), Y=y, STATS=stats, **geo)
+    bnv = _bn_forward(p, bnprefix, y, C, B * Ho * Wo, stats, eps, mom)
+    out = Act(y, C, Ho, Wo, bnv, D.PRO_SILU)
+
+    def backward():
+        dY = _bn_backward(p, bnprefix, out.grad, y, bnv, C, Ho * Wo, D.ACT_SILU, out.mulbc, out.addbc, out.addscale)
+        p.bwd.add("DWCONV_WGRAD", DY=dY, X=src.raw, BNV=src.bnv, DW=p.pgrad(wname), **geo)
+        if not src.needs_grad:
+            return
+        if src.pro == D.PRO_NONE:
+            g = p.grad_of(src, wname + ".src")
+            p.bwd.add("DWCONV_DGRAD", DY=dY, WT=p.param(wname), XRAW=None, BNV=None, G=g, STATS2=None,
+                      BETA=int(src.grad_init), **geo)
+            src.grad_init = True
+        else:
+            # fused: dgrad * act'(u) and the BN-backward statistics of the producer; the producer's
+            # backward then only runs FINALIZE + APPLY on this buffer.
+            g = p.grad_of(src, wname + ".src")
+            assert not src.grad_init
+            st2 = p.aux.alloc("stats2f:" + bnprefix, (2, C), "f64")
+            p.bwd.add("DWCONV_DGRAD", DY=dY, WT=p.param(wname), XRAW=src.raw, BNV=src.bnv, G=g, STATS2=st2,
+                      BETA=0, **geo)
+            src.grad_init = True
+            src.fused_stats2 = st2
+
+    p.tape.append(backward)
+    return out
+
+
+def squeeze_excite(p: _P, prefix: str, a: Act, se: int) -> Act:
+    """x * sigmoid(SE(x)) (efficientnet_unet.py:381): attaches the gate to the virtual activation."""
+    B, C, HW = p.B, a.C, a.H * a.W
+    pool = p.alloc("pool:" + prefix, (B, C))
+    hpre = p.alloc("hpre:" + prefix, (B, se))
+    gate = p.alloc("gate:" + prefix, (B, C))
+    p.fwd.add("SE_POOL", Y=a.raw, BNV=a.bnv, POOL=pool, B=B, C=C, HW=HW, PRO=a.pro)
+    w1, b1 = prefix + ".1.weight", prefix + ".1.bias"
+    w2, b2 = prefix + ".3.weight", prefix + ".3.bias"
+    p.fwd.add("SE_FC", POOL=pool, W1=p.param(w1), B1=p.param(b1), W2=p.param(w2), B2=p.param(b2),
+              HPRE=hpre, GATE=gate, B=B, C=C, CSQ=se)
+    a.gate = gate
+
+    def backward():
+        dgate = p.alloc("dgate:" + prefix, (B, C))
+        dpool = p.alloc("dpool:" + prefix, (B, C))
+        p.bwd.add("SE_BWD_REDUCE", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, B=B, C=C, HW=HW, PRO=a.pro)
+        p.bwd.add("SE_FC_BWD", DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=p.param(w1), W2=p.param(w2),
+                  DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2), DB2=p.pgrad(b2), DPOOL=dpool,
+                  B=B, C=C, CSQ=se)
+        a.mulbc, a.addbc, a.addscale = gate, dpool, 1.0 / HW
+
+    p.tape.append(backward)
+    return a
+
+
+def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
+    """nn.ConvTranspose2d(k=2, s=2, bias) as one GEMM with M = (co,dy,dx) and an interleaved store."""
+    B, Cin, H, W = p.B, src.C, src.H, src.W
+    u = p.alloc("u:" + wname, (B, Cout, 2 * H, 2 * W))
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=p.param(wname),
+              BIAS=p.param(bname), Y=u, STATS=None, B=B, C1=Cin, C2=0, H=H, W=W, M=4 * Cout, KH=1, KW=1, STRIDE=1,
+              PAD_T=0, PAD_L=0, HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONVT_SCATTER,
+              W_SM=1, W_SK=4 * Cout, W_ST=1, FLIP=0, BETA=0, YC=Cout)
+    out = Act(u, Cout, 2 * H, 2 * W)
+
+    def backward():
+        G = out.grad
+        p.table_entry(wname, Cin, Cout, 4)
+        p.bwd.add("WGRAD", P=src.raw, BNVP=src.bnv, GATEP=src.gate, Q=G, BNVQ=None, GATEQ=None, WGS=p.wgs(wname),
+                  B=B, M=Cin, C=Cout, CTOT=Cout, H=2 * H, W=2 * W, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0,
+                  HO=H, WO=W, PROP=src.pro, PROQ=D.PRO_NONE, MODE=D.MODE_GATHER2X2)
+        p.bwd.add("CHANNEL_SUM", G=G, OUT=p.pgrad(bname), B=B, C=Cout, HW=4 * H * W)
+        if src.needs_grad:
+            g = p.grad_of(src, wname + ".src")
+            # dX[b][ci][y][x] = sum_{k=(co,dy,dx)} W[ci][k] * G[b][co][2y+dy][2x+dx]
+            p.bwd.add("CONV", X1=G, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=p.param(wname), BIAS=None, Y=g,
+                      STATS=None, B=B, C1=4 * Cout, C2=0, H=H, W=W, M=Cin, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
+                      HO=H, WO=W, PRO1=D.PRO_NONE, PRO2=0, MODE=D.MODE_GATHER2X2, W_SM=4 * Cout, W_SK=1, W_ST=1,
+                      FLIP=0, BETA=int(src.grad_init), YC=Cin)
+            src.grad_init = True
+
+    p.tape.append(backward)
+    return out
+
+
+def out_conv(p: _P, wname: str, bname: str, src: Act, M: int) -> TRef:
+    B, H, W = p.B, src.H, src.W
+    logits = TRef(D.BASE["OUT"], 0, (B, M, H, W), "f32", "logits")
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=None, X2=None, BNV2=None, WT=p.param(wname),
+              BIAS=p.param(bname), Y=logits, STATS=None, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1,
+              PAD_T=0, PAD_L=0, HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1,
+              FLIP=0, BETA=0, YC=M)
+
+    def backward():
+        dY = TRef(D.BASE["DOUT"], 0, (B, M, H, W), "f32", "dlogits")
+        _conv_dgrad_wgrad(p, wname, dY, [src], M, 1, 1, 0, 0, H, W, bname)
+
+    p.tape.append(backward)
+    return logits
+
+
+# ------------------------------------------------------------------------------------------
+
+def build_layout(spec: UnetSpec) -> ParamLayout:
+    """Flat parameter / buffer layout in the reference's registration order."""
+    L = ParamLayout()
+
+    def bn(prefix, c):
+        L.add_param(prefix + ".weight", (c,))
+        L.add_param(prefix + ".bias", (c,))
+        L.add_buf(prefix + ".running_mean", (c,))
+        L.add_buf(prefix + ".running_var", (c,))
+        L.nbt.append(prefix + ".num_batches_tracked")
+
+    L.add_param("encoder.stem.0.weight", (spec.stem_out, spec.in_channels, 3, 3))
+    bn("encoder.stem.1", spec.stem_out)
+    for i, b in enumerate(spec.blocks):
+        pre = f"encoder.blocks.{i}."
+        j = 0
+        if b.expand != 1:
+            L.add_param(pre + "stem.0.weight", (b.cexp, b.cin, 1, 1))
+            bn(pre + "stem.1", b.cexp)
+            j = 3
+        L.add_param(pre + f"stem.{j}.weight", (b.cexp, 1, b.kernel, b.kernel))
+        bn(pre + f"stem.{j + 1}", b.cexp)
+        L.add_param(pre + "squeeze_excitation.1.weight", (b.se, b.cexp, 1, 1))
+        L.add_param(pre + "squeeze_excitation.1.bias", (b.se,))
+        L.add_param(pre + "squeeze_excitation.3.weight", (b.cexp, b.se, 1, 1))
+        L.add_param(pre + "squeeze_excitation.3.bias", (b.cexp,))
+        L.add_param(pre + "final_layer.0.weight", (b.cout, b.cexp, 1, 1))
+        bn(pre + "final_layer.1", b.cout)
+    L.add_param("encoder.conv_head.0.weight", (spec.head_out, spec.blocks[-1].cout, 1, 1))
+    bn("encoder.conv_head.1", spec.head_out)
+    L.add_param("encoder.fc.3.weight", (spec.num_classes, spec.head_out))
+    L.add_param("encoder.fc.3.bias", (spec.num_classes,))
+    ups_in, ups_out = [spec.head_out, 512, 256, 128], [512, 256, 128, 64]
+    cat = CAT_SIZES[spec.version]
+    for i in range(4):
+        L.add_param(f"up_convs.{i}.weight", (ups_in[i], ups_out[i], 2, 2))
+        L.add_param(f"up_convs.{i}.bias", (ups_out[i],))
+    for i in range(4):
+        pre = f"double_convs.{i}"
+        L.add_param(pre + ".0.weight", (ups_out[i], cat[i], 3, 3))
+        L.add_param(pre + ".0.bias", (ups_out[i],))
+        bn(pre + ".1", ups_out[i])
+        L.add_param(pre + ".3.weight", (ups_out[i], ups_out[i], 3, 3))
+        L.add_param(pre + ".3.bias", (ups_out[i],))
+        bn(pre + ".4", ups_out[i])
+    L.add_param("input_up_conv.weight", (64, 32, 2, 2))
+    L.add_param("input_up_conv.bias", (32,))
+    pre = "input_double_conv"
+    L.add_param(pre + ".0.weight", (32, 32 + spec.in_channels, 3, 3))
+    L.add_param(pre + ".0.bias", (32,))
+    bn(pre + ".1", 32)
+    L.add_param(pre + ".3.weight", (32, 32, 3, 3))
+    L.add_param(pre + ".3.bias", (32,))
+    bn(pre + ".4", 32)
+    L.add_param("out_conv1x1.weight", (spec.num_classes, 32, 1, 1))
+    L.add_param("out_conv1x1.bias", (spec.num_classes,))
+    return L
+
+
+def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None) -> UnetPlan:
+    if H % 32 or W % 32:
+        raise ValueError(f"EfficientnetUnet needs H, W multiples of 32, got {H}x{W}")
+    layout = layout or build_layout(spec)
+    p = _P(spec, layout, B, H, W, training)
+    eps, mom = spec.bn_eps, spec.bn_momentum
+    x_in = Act(TRef(D.BASE["X"], 0, (B, spec.in_channels, H, W), "f32", "x"), spec.in_channels, H, W,
+               needs_grad=False)
+
+    # encoder --------------------------------------------------------------------------
+    cur = conv_bn(p, "encoder.stem.0.weight", "encoder.stem.1", [x_in], spec.stem_out, 3, 2, True,
+                  D.PRO_SILU, eps, mom)
+    block_outs: list[Act] = []
+    n = len(spec.blocks)
+    for i, b in enumerate(spec.blocks):
+        pre = f"encoder.blocks.{i}."
+        xin = cur
+        j = 0
+        a = xin
+        if b.expand != 1:
+            a = conv_bn(p, pre + "stem.0.weight", pre + "stem.1", [xin], b.cexp, 1, 1, True, D.PRO_SILU, eps, mom)
+            j = 3
+        a = dwconv_bn(p, pre + f"stem.{j}.weight", pre + f"stem.{j + 1}", a, b.kernel, b.stride, eps, mom)
+        a = squeeze_excite(p, pre + "squeeze_excitation", a, b.se)
+        rate = spec.drop_connect_rate * (i / n) if spec.drop_connect_rate is not None else None
+        cur = project_conv_bn_residual(p, i, pre + "final_layer.0.weight", pre + "final_layer.1", a, b.cout,
+                                       xin if b.residual else None, rate, eps, mom)
+        block_outs.append(cur)
+    head_hw = (cur.H, cur.W)
+    fmaps: list[Act] = []
+    for a in block_outs:  # first block output at each new spatial size, deepest first (encode :259)
+        if (a.H, a.W) not in [(f.H, f.W) for f in fmaps] and (a.H, a.W) != head_hw:
+            fmaps.insert(0, a)
+    if len(fmaps) != 4:
+        raise ValueError(f"expected 4 skip feature maps, got {len(fmaps)} for input {H}x{W}")
+    cur = conv_bn(p, "encoder.conv_head.0.weight", "encoder.conv_head.1", [cur], spec.head_out, 1, 1, True,
+                  D.PRO_SILU, eps, mom)
+
+    # decoder --------------------------------------------------------------------------
+    ups_out = [512, 256, 128, 64]
+    cat = CAT_SIZES[spec.version]
+    for i, fm in enumerate(fmaps):
+        u = conv_transpose(p, f"up_convs.{i}.weight", f"up_convs.{i}.bias", cur, ups_out[i])
+        if u.C + fm.C != cat[i] or (u.H, u.W) != (fm.H, fm.W):
+            raise ValueError(f"decoder level {i}: cat {u.C}+{fm.C} != {cat[i]} or size mismatch")
+        pre = f"double_convs.{i}"
+        a = conv_bn(p, pre + ".0.weight", pre + ".1", [u, fm], ups_out[i], 3, 1, False, D.PRO_RELU, 1e-5, 0.1,
+                    bias=pre + ".0.bias")
+        cur = conv_bn(p, pre + ".3.weight", pre + ".4", [a], ups_out[i], 3, 1, False, D.PRO_RELU, 1e-5, 0.1,
+                      bias=pre + ".3.bias")
+    u = conv_transpose(p, "input_up_conv.weight", "input_up_conv.bias", cur, 32)
+    pre = "input_double_conv"
+    a = conv_bn(p, pre + ".0.weight", pre + ".1", [u, x_in], 32, 3, 1, False, D.PRO_RELU, 1e-5, 0.1,
+                bias=pre + ".0.bias")
+    cur = conv_bn(p, pre + ".3.weight", pre + ".4", [a], 32, 3, 1, False, D.PRO_RELU, 1e-5, 0.1,
+                  bias=pre + ".3.bias")
+    logits = out_conv(p, "out_conv1x1.weight", "out_conv1x1.bias", cur, spec.num_classes)
+
+    fwd_aux_end = p.aux.mark()
+    if training and fwd_aux_end:
+        p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
+
+    bwd = None
+    if training:
+        for back in reversed(p.tape):
+            back()
+            p.marks.append(len(p.bwd.ops))
+        bwd_aux_end = p.aux.mark()
+        pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
+        if bwd_aux_end > fwd_aux_end:
+            pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
+                                           BYTES=bwd_aux_end - fwd_aux_end)))
+        p.bwd.ops[0:0] = pre_ops
+        p.bwd.add("WGRAD_FINALIZE", TABLE=TRef(D.BASE["CONST"], 0, (len(p.table), 5), "i32"),
+                  WGS=TRef(D.BASE["WGS"], 0, (layout.n_params,)), GRADS=TRef(D.BASE["GRADS"], 0, (layout.n_params,)),
+                  TOTAL=p.table_total, N_ENTRIES=len(p.table))
+        bwd = p.bwd
+
+    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.table, layout, n,
+                    [], (B, spec.num_classes, H, W), p.tensors)

@@ -1,0 +1,46 @@
+"""Run planned s2k programs through the CPU emulator (oracle/ops_ref.py) — test infrastructure."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import s2lc_amd  # noqa: F401
+from s2lc_amd.plan import opdefs as D
+from oracle import ops_ref
+
+NARROW = (D.BASE["CONST"],)
+
+
+def _bytes(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous().reshape(-1).view(torch.uint8)
+
+
+def make_bases(plan, flat_params, flat_bufs, x, noise, n_out, wide: bool = False):
+    """wide: hold every f32 tensor as float64 (see ops_ref.Mem)."""
+    fd = torch.float64 if wide else torch.float32
+    k = 2 if wide else 1
+    pad8 = lambda n: (n + 7) // 8 * 8  # noqa: E731
+    bases = {
+        D.BASE["WS"]: torch.zeros(k * pad8(plan.ws_bytes) + 64, dtype=torch.uint8),
+        D.BASE["AUX"]: torch.zeros(k * pad8(plan.aux_bytes) + 64, dtype=torch.uint8),
+        D.BASE["PARAMS"]: _bytes(flat_params.detach().to(fd).clone()),
+        D.BASE["GRADS"]: _bytes(torch.zeros_like(flat_params, dtype=fd)),
+        D.BASE["WGS"]: _bytes(torch.zeros_like(flat_params, dtype=fd)),
+        D.BASE["BUFS"]: _bytes(flat_bufs.detach().to(fd).clone()),
+        D.BASE["X"]: _bytes(x.to(fd).clone()),
+        D.BASE["OUT"]: _bytes(torch.zeros(n_out, dtype=fd)),
+        D.BASE["DOUT"]: _bytes(torch.zeros(n_out, dtype=fd)),
+        D.BASE["NOISE"]: _bytes(noise.clone().to(fd)),
+        D.BASE["CONST"]: _bytes(torch.tensor(plan.const_table if plan.const_table else [[0] * 5], dtype=torch.int32)),
+    }
+    # poison the workspace so that reads of never-written memory show up as NaN
+    bases[D.BASE["WS"]][: k * pad8(plan.ws_bytes)].view(fd).fill_(float("nan"))
+    return bases
+
+
+def fview(bases, name: str, wide: bool = False) -> torch.Tensor:
+    return bases[D.BASE[name]].view(torch.float64 if wide else torch.float32)
+
+
+def emulate(packed: np.ndarray, bases, wide: bool = False) -> None:
+    ops_ref.run_program(packed, bases, D, wide=wide, narrow_bases=NARROW)

@@ -1,0 +1,135 @@
+"""CPU: the planner's forward AND hand-derived backward programs, run through the op emulator,
+reproduce oracle autograd (logits, gradient w.r.t. every parameter, running statistics).
+
+Two modes.  `wide` holds everything in float64 and must agree with a float64 oracle to ~1e-9:
+that checks the planner's algebra exactly.  The fp32 mode is compared with the *same float64
+truth* and must not be worse than a small multiple of the fp32 oracle's own distance from it:
+with train-mode BatchNorm on small maps and ReLU masks, fp32 gradients of this network carry
+~1e-2 relative noise in ANY implementation (the reference's included), so a fixed 1e-3 bar on
+gradients would be meaningless; the 1e-3 bar of BASELINE.json applies to logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import detgen, losses_ref
+from oracle import efficientnet_unet_ref as R
+from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+from tests.helpers import rel_err
+from tests.plan_harness import emulate, fview, make_bases
+
+
+def _setup(version, C, H, B, ncls, seed, dcr=0.2):
+    cfg = EfficientNetConfig(version, C, ncls, class_distribution=[1.0 / ncls] * ncls, drop_connect_rate=dcr)
+    model = EfficientnetUnet(cfg)
+    net = R.build(version, C, ncls, drop_connect_rate=dcr)
+    sd = detgen.fill_state(R.state_shapes(net), seed=seed)
+    model.load_state_dict(sd)
+    x = detgen.normal("plan.x", (B, C, H, H), seed=seed)
+    y = detgen.labels("plan.y", (B, H, H), ncls, seed=seed)
+    noise = detgen.uniform("plan.dc", (len(net.blocks), B), 0.0, 1.0, seed=seed)
+    return model, net, sd, x, y, noise
+
+
+def oracle_grads(net, sd, x, y, noise, ncls, dtype):
+    sdd = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            v = v.detach().to(dtype)
+            if not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        sdd[k] = v
+    newbuf = {}
+    logits = R.unet_forward(sdd, net, x.to(dtype), training=True, dc_noise=noise.to(dtype), new_buffers=newbuf)
+    loss = losses_ref.focal(logits, y, torch.ones(ncls, dtype=dtype), 2.0, 0.0, ignore_index=0)
+    (dlogits,) = torch.autograd.grad(loss, logits, retain_graph=True)
+    loss.backward()
+    return sdd, logits.detach(), dlogits, newbuf
+
+
+# wide cases use drop-connect rates whose keep probabilities are exact in fp32 (the stage record
+# carries KEEP as a float), so the float64 comparison is not limited by that 1e-8 rounding
+@pytest.mark.parametrize("version,C,H,B,wide,dcr", [("b0", 6, 64, 2, True, 0.25), ("b5", 13, 64, 2, True, None),
+                                                     ("b0", 4, 128, 2, False, 0.2)])
+def test_train_programs_match_oracle_autograd(version, C, H, B, wide, dcr):
+    ncls = 4
+    model, net, sd, x, y, noise = _setup(version, C, H, B, ncls, seed=21, dcr=dcr)
+    plan = model._make_plan(B, H, H, True)
+    bases = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H, wide)
+    emulate(plan.fwd.pack(), bases, wide)
+    logits = fview(bases, "OUT", wide).view(B, ncls, H, H).clone()
+
+    sd64, logits64, dlogits64, newbuf64 = oracle_grads(net, sd, x, y, noise, ncls, torch.float64)
+    if wide:
+        assert rel_err(logits.numpy(), logits64.numpy()) < 1e-6
+        fview(bases, "DOUT", wide).copy_(dlogits64.reshape(-1))
+    else:
+        sd32, logits32, dlogits32, _ = oracle_grads(net, sd, x, y, noise, ncls, torch.float32)
+        assert rel_err(logits.numpy(), logits64.numpy()) < 1e-4  # logits: well inside the 1e-3 bar
+        fview(bases, "DOUT", wide).copy_(dlogits32.reshape(-1))
+    emulate(plan.bwd.pack(), bases, wide)
+    grads = fview(bases, "GRADS", wide)
+    scale = max(v.grad.abs().max().item() for v in sd64.values() if v.requires_grad and v.grad is not None)
+    errs_em, errs_or = [], []
+    for name, (off, shape) in plan.layout.params.items():
+        g = grads[off:off + int(np.prod(shape))].view(shape)
+        ref = sd64[name].grad
+        if ref is None:
+            assert name.startswith("encoder.fc.") and g.abs().max() == 0
+            continue
+        if ref.abs().max().item() < 1e-9 * scale:
+            # analytically zero (a per-channel constant in front of train-mode BN): we emit exact 0
+            assert g.abs().max().item() <= 1e-6 * scale, name
+            continue
+        e = rel_err(g.numpy(), ref.numpy())
+        if wide:
+            assert e < 1e-5, (name, e)
+        else:
+            errs_em.append(e)
+            errs_or.append(rel_err(sd32[name].grad.numpy(), ref.numpy()))
+    if not wide:
+        errs_em, errs_or = np.array(errs_em), np.array(errs_or)
+        assert np.median(errs_em) < 3 * np.median(errs_or) + 1e-4
+        assert errs_em.max() < 5 * errs_or.max() + 1e-3
+    bufs = fview(bases, "BUFS", wide)
+    for name, (off, shape) in plan.layout.bufs.items():
+        got = bufs[off:off + shape[0]]
+        assert rel_err(got.numpy(), newbuf64[name].numpy()) < (1e-6 if wide else 1e-5), name
+
+
+def test_eval_program_matches_oracle():
+    model, net, sd, x, y, noise = _setup("b0", 4, 64, 1, 4, seed=22)
+    model.eval()
+    plan = model._make_plan(1, 64, 64, False)
+    assert plan.bwd is None
+    bases = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, 4 * 64 * 64)
+    from s2lc_amd.plan import opdefs as D
+
+    before = bases[D.BASE["BUFS"]].clone()
+    emulate(plan.fwd.pack(), bases)
+    logits = fview(bases, "OUT").view(1, 4, 64, 64)
+    with torch.no_grad():
+        ref = R.unet_forward(sd, net, x, training=False)
+    assert rel_err(logits.numpy(), ref.numpy()) < 1e-5
+    assert torch.equal(before, bases[D.BASE["BUFS"]])  # eval never touches running stats
+
+
+def test_state_dict_surface_matches_reference_names():
+    for version, C in (("b0", 6), ("b3", 4), ("b5", 13)):
+        model = EfficientnetUnet(EfficientNetConfig(version, C, 4, class_distribution=[.25] * 4))
+        shapes = R.state_shapes(R.build(version, C, 4))
+        sd = model.state_dict()
+        assert list(sd) == list(shapes)
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
+    # classifier bias = log prior (utils.py:174-188)
+    m = EfficientnetUnet(EfficientNetConfig("b0", 6, 4, class_distribution=[.1, .2, .3, .4]))
+    assert torch.allclose(m.out_conv1x1.bias, (torch.tensor([.1, .2, .3, .4]) + 1e-6).log())
+    with pytest.raises(ValueError):
+        EfficientNetConfig("b9", 6, 4)
+
+
+def test_forward_without_gpu_fails_loudly():
+    m = EfficientnetUnet(EfficientNetConfig("b0", 6, 4, class_distribution=[.25] * 4))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 6, 64, 64))
