@@ -1,0 +1,82 @@
+/* s2k — C ABI of the MI355X-native segmentation hot path (libs2k.so, gfx950 only).
+ *
+ * Drop-in boundary.  The reference's hot path is pure Python calling ATen:
+ *   EfficientnetUnet.forward            /root/reference/src/modules/efficientnet_unet.py:125-138
+ *   EfficientNet.encode / MBConvBlock   efficientnet_unet.py:251-263, :377-387
+ *   FocalLoss.__call__ / CrossEntropy   /root/reference/src/losses.py:24-89
+ *   logits.argmax(dim=1)                /root/reference/src/train_segmentation.py:145
+ *   loss.backward() (torch autograd)    train_segmentation.py:87-93 via Lightning
+ * There is no FFI in the reference for this path, so the entry points below are what a binding
+ * for it would call: a whole forward (or backward) of the network is ONE `s2k_program_run` over
+ * an array of fused-stage records planned on the host; every stage kind is also launchable on
+ * its own (`s2k_op_launch`) for parity tests.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Rules of the boundary
+ *   - plain C: pointers, sizes, POD structs; no torch / HIP types in signatures except the
+ *     stream, passed as an opaque `void*` (a hipStream_t);
+ *   - every device pointer is BORROWED: the library never allocates, frees or synchronises;
+ *     all work is enqueued on the caller's stream (graph-capturable);
+ *   - return 0 on success, a negative S2K_E* code on failure, never throw; the message for the
+ *     last failure on the calling thread is `s2k_last_error()`;
+ *   - re-entrant, no mutable global state.
+ */
+#ifndef S2K_H
+#define S2K_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "s2k_ops.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2K_ABI_VERSION 1
+
+#define S2K_OK 0
+#define S2K_EINVAL (-22)   /* malformed stage record / unsupported geometry */
+#define S2K_ENOSYS (-38)   /* unknown stage kind */
+#define S2K_EFAULT (-14)   /* null base for a referenced tensor */
+#define S2K_EHIP (-5)      /* a HIP launch failed; see s2k_last_error() */
+
+/* One fused stage.  Field meaning per kind: include/s2k_ops.h (generated from plan/opdefs.py).
+ * t[]: tensor refs = (base_id << 56) | byte_offset, -1 = null.  256 bytes. */
+typedef struct S2kOp {
+    int32_t kind;
+    int32_t flags;
+    int64_t t[S2K_N_T];
+    int64_t n[S2K_N_N];
+    int32_t d[S2K_N_D];
+    float f[S2K_N_F];
+} S2kOp;
+
+int s2k_abi_version(void);
+size_t s2k_op_size(void);                 /* sizeof(S2kOp), for binding self-checks */
+const char* s2k_last_error(void);         /* thread-local, never NULL */
+const char* s2k_kind_name(int kind);      /* "CONV", ... or NULL */
+
+/* Enqueue ops[begin, end) on `stream`.  bases[i] is the device pointer of base i
+ * (S2K_BASE_*), NULL if that base is not used by the range. */
+int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream);
+
+/* Single stage (parity tests, loss, argmax). */
+int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream);
+
+/* Device-side timing of a program range with HIP events on `stream` (bench.py roofline leg):
+ * per-kind accumulated milliseconds into ms_by_kind[S2K_N_KINDS + 1]; synchronises the stream. */
+int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
+                        float* ms_by_kind, int* launches_by_kind);
+
+/* fused Adam step (L2-coupled decay, train_segmentation.py:109-127): p, g, m, v flat fp32 [n]. */
+int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream);
+
+/* Diagnostics for tests: run a 32x32x2 f32 MFMA on A[32x2], B[2x32] and return D[32x32]
+ * (checks the lane maps the kernels rely on with exact integer data). */
+int s2k_selftest_mfma(const float* a, const float* b, float* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2K_H */

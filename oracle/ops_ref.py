@@ -353,6 +353,8 @@ def _loss_value(lg, y, alpha, o):
     from . import losses_ref
 
     ign = o["IGNORE"]
+    if alpha is None and o["MODE"] != 0:
+        alpha = torch.ones(lg.shape[1], dtype=lg.dtype)
     if o["MODE"] == 0:
         return losses_ref.cross_entropy(lg, y, alpha, float(np.float32(o["SMOOTH"])), ign)
     return losses_ref.focal(lg, y, alpha, float(np.float32(o["GAMMA"])), float(np.float32(o["SMOOTH"])), ign,

@@ -1,0 +1,597 @@
+// HBM-bound stages around the convolutions: BatchNorm finalize / backward (reduce, finalize, apply),
+// squeeze-excitation (pool, FCs, backward), residual + drop-connect, channel sums, grad layout fold.
+//
+// Reference arithmetic being replaced: nn.BatchNorm2d train/eval (efficientnet_unet.py:170-175,
+// 194,329,345,367), SE branch + x*sigmoid(SE(x)) (:346-381), _drop_connect + residual (:383-398).
+// Work decomposition: one wave per (plane, chunk) task, float4 accesses when the plane size allows,
+// wave shuffle reductions, one f64 atomic per task for per-channel sums.
+#include "common.h"
+
+namespace s2k {
+
+constexpr int CHUNK = 4096;   // elements of one (b,c) plane handled by one wave
+
+template <typename T>
+static T* ref_ptr(const Ctx& c, int64_t ref) {
+    if (ref < 0) return nullptr;
+    const int base = (int)(ref >> 56);
+    const int64_t off = ref & ((1ll << 56) - 1);
+    if (base >= c.n_bases || c.bases[base] == nullptr) return reinterpret_cast<T*>(1);
+    return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
+}
+static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
+#define CHECK_PTRS(name, ...)                                                                         \
+    do {                                                                                              \
+        const void* _ps[] = {__VA_ARGS__};                                                            \
+        for (const void* _q : _ps)                                                                    \
+            if (bad(_q)) { set_error(name ": tensor references a null base"); return S2K_EFAULT; }    \
+    } while (0)
+
+struct Task {
+    int64_t plane;
+    int start, count;
+};
+
+__device__ __forceinline__ bool get_task(int HW, int64_t nplanes, Task& t) {
+    const int chunks = (HW + CHUNK - 1) / CHUNK;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= nplanes * chunks) return false;
+    t.plane = task / chunks;
+    const int ck = (int)(task - t.plane * chunks);
+    t.start = ck * CHUNK;
+    t.count = min(CHUNK, HW - t.start);
+    return true;
+}
+
+static unsigned task_blocks(int HW, int64_t nplanes) {
+    const int chunks = (HW + CHUNK - 1) / CHUNK;
+    return (unsigned)cdiv64(nplanes * chunks, 4);
+}
+
+// ---------------- AXPY ---------------------------------------------------------------------------
+__global__ void axpy_kernel(const float* x, float* y, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4*>(x)[i];
+        float4 b = reinterpret_cast<float4*>(y)[i];
+        b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+        reinterpret_cast<float4*>(y)[i] = b;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += x[i];
+}
+
+int launch_axpy(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_AXPY_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_AXPY_T_Y]);
+    CHECK_PTRS("axpy", x, y);
+    const int64_t n = op.n[S2K_AXPY_N_COUNT];
+    if (!x || !y || n <= 0) { set_error("axpy: bad args"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64(n, 4 * 256), 2048);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, c.stream, x, y, n);
+    return S2K_OK;
+}
+
+// ---------------- WGRAD_FINALIZE -------------------------------------------------------------------
+// table rows: {float offset, M, C, T, start}; thread e handles output element e of the concatenated
+// conv-weight index space: GRADS[off + (m*C + c)*T + t] += WGS[off + (t*M + m)*C + c]
+__global__ void wgrad_finalize_kernel(const int* table, int n_entries, const float* wgs, float* grads, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int lo = 0, hi = n_entries - 1;
+        while (lo < hi) {  // last entry with start <= e
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)table[mid * 5 + 4] <= e) lo = mid; else hi = mid - 1;
+        }
+        const int* r = table + lo * 5;
+        const int64_t off = r[0];
+        const int M = r[1], C = r[2], T = r[3];
+        const int local = (int)(e - r[4]);
+        const int t = local % T;
+        const int mc = local / T;
+        const int cc = mc % C, m = mc / C;
+        grads[off + local] += wgs[off + ((int64_t)t * M + m) * C + cc];
+    }
+}
+
+int launch_wgrad_finalize(const S2kOp& op, const Ctx& c) {
+    const int* table = ref_ptr<const int>(c, op.t[S2K_WGRAD_FINALIZE_T_TABLE]);
+    const float* wgs = ref_ptr<const float>(c, op.t[S2K_WGRAD_FINALIZE_T_WGS]);
+    float* grads = ref_ptr<float>(c, op.t[S2K_WGRAD_FINALIZE_T_GRADS]);
+    CHECK_PTRS("wgrad_finalize", table, wgs, grads);
+    const int64_t total = op.n[S2K_WGRAD_FINALIZE_N_TOTAL];
+    const int n = op.d[S2K_WGRAD_FINALIZE_D_N_ENTRIES];
+    if (!table || !wgs || !grads || n <= 0 || total <= 0 || total > 0x7fffffff) { set_error("wgrad_finalize: bad args"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, c.stream, table, n, wgs, grads, total);
+    return S2K_OK;
+}
+
+// ---------------- BN_FINALIZE ----------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, const float* gamma, const float* beta, float* rm, float* rv,
+                                   float* bnv, int C, int train, double count, float eps, float mom) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, invstd;
+    if (train) {
+        const double m = stats[c] / count;
+        double var = stats[C + c] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        mean = (float)m;
+        const double unbiased = var * (count / fmax(count - 1.0, 1.0));
+        rm[c] = (1.0f - mom) * rm[c] + mom * mean;
+        rv[c] = (1.0f - mom) * rv[c] + mom * (float)unbiased;
+    } else {
+        mean = rm[c];
+        invstd = 1.0f / sqrtf(rv[c] + eps);
+    }
+    const float scale = gamma[c] * invstd;
+    bnv[c] = scale;
+    bnv[C + c] = beta[c] - mean * scale;
+    bnv[2 * C + c] = mean;
+    bnv[3 * C + c] = invstd;
+}
+
+int launch_bn_finalize(const S2kOp& op, const Ctx& c) {
+    const double* stats = ref_ptr<const double>(c, op.t[S2K_BN_FINALIZE_T_STATS]);
+    const float* gamma = ref_ptr<const float>(c, op.t[S2K_BN_FINALIZE_T_GAMMA]);
+    const float* beta = ref_ptr<const float>(c, op.t[S2K_BN_FINALIZE_T_BETA]);
+    float* rm = ref_ptr<float>(c, op.t[S2K_BN_FINALIZE_T_RM]);
+    float* rv = ref_ptr<float>(c, op.t[S2K_BN_FINALIZE_T_RV]);
+    float* bnv = ref_ptr<float>(c, op.t[S2K_BN_FINALIZE_T_BNV]);
+    CHECK_PTRS("bn_finalize", stats, gamma, beta, rm, rv, bnv);
+    const int C = op.d[S2K_BN_FINALIZE_D_C], train = op.d[S2K_BN_FINALIZE_D_TRAIN];
+    if (!gamma || !beta || !rm || !rv || !bnv || C <= 0 || (train && !stats)) { set_error("bn_finalize: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, stats, gamma, beta, rm, rv, bnv, C,
+                       train, (double)op.n[S2K_BN_FINALIZE_N_COUNT], op.f[S2K_BN_FINALIZE_F_EPS], op.f[S2K_BN_FINALIZE_F_MOM]);
+    return S2K_OK;
+}
+
+// ---------------- plane reductions: SE_POOL, SE_BWD_REDUCE, CHANNEL_SUM ----------------------------------
+// MODE 0: out[plane] = sum act(affine(y)) / HW      (SE_POOL; whole plane per wave, CHUNK ignored)
+// MODE 1: out[plane] = sum g * act(affine(y))       (SE_BWD_REDUCE)
+// MODE 2: out[c]    += sum g                        (CHANNEL_SUM, float atomics)
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, const float* y, const float* bnv,
+                                                                float* out, int C, int HW, int64_t nplanes, int pro) {
+    const int lane = threadIdx.x & 63;
+    int64_t plane;
+    int start, count;
+    if (MODE == 2) {
+        Task t;
+        if (!get_task(HW, nplanes, t)) return;
+        plane = t.plane; start = t.start; count = t.count;
+    } else {
+        plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (plane >= nplanes) return;
+        start = 0; count = HW;
+    }
+    const int c = (int)(plane % C);
+    float scale = 1.0f, shift = 0.0f;
+    if (MODE != 2 && pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
+    const int64_t base = plane * HW + start;
+    float s = 0.0f;
+    if (VEC) {
+        const int n4 = count >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            float4 a = make_float4(0, 0, 0, 0), b = make_float4(1, 1, 1, 1);
+            if (MODE != 0) a = reinterpret_cast<const float4*>(g + base)[i];
+            if (MODE != 2) {
+                b = reinterpret_cast<const float4*>(y + base)[i];
+                b.x = apply_pro(b.x, pro, scale, shift); b.y = apply_pro(b.y, pro, scale, shift);
+                b.z = apply_pro(b.z, pro, scale, shift); b.w = apply_pro(b.w, pro, scale, shift);
+            }
+            if (MODE == 0) s += (b.x + b.y) + (b.z + b.w);
+            else s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+    } else {
+        for (int i = lane; i < count; i += 64) {
+            float a = (MODE != 0) ? g[base + i] : 0.0f;
+            float b = (MODE != 2) ? apply_pro(y[base + i], pro, scale, shift) : 1.0f;
+            s += (MODE == 0) ? b : a * b;
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (MODE == 0) out[plane] = s / (float)HW;
+        else if (MODE == 1) out[plane] = s;
+        else atomicAdd(out + c, s);
+    }
+}
+
+template <int MODE>
+static int launch_plane_reduce(const float* g, const float* y, const float* bnv, float* out, int B, int C, int HW, int pro,
+                               hipStream_t st) {
+    const int64_t nplanes = (int64_t)B * C;
+    const unsigned blocks = (MODE == 2) ? task_blocks(HW, nplanes) : (unsigned)cdiv64(nplanes, 4);
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((plane_reduce_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro);
+    else
+        hipLaunchKernelGGL((plane_reduce_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro);
+    return S2K_OK;
+}
+
+int launch_se_pool(const S2kOp& op, const Ctx& c) {
+    const float* y = ref_ptr<const float>(c, op.t[S2K_SE_POOL_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_SE_POOL_T_BNV]);
+    float* pool = ref_ptr<float>(c, op.t[S2K_SE_POOL_T_POOL]);
+    CHECK_PTRS("se_pool", y, bnv, pool);
+    const int pro = op.d[S2K_SE_POOL_D_PRO];
+    if (!y || !pool || (pro && !bnv)) { set_error("se_pool: bad args"); return S2K_EINVAL; }
+    return launch_plane_reduce<0>(nullptr, y, bnv, pool, op.d[S2K_SE_POOL_D_B], op.d[S2K_SE_POOL_D_C], op.d[S2K_SE_POOL_D_HW], pro, c.stream);
+}
+
+int launch_se_bwd_reduce(const S2kOp& op, const Ctx& c) {
+    const float* g = ref_ptr<const float>(c, op.t[S2K_SE_BWD_REDUCE_T_G]);
+    const float* y = ref_ptr<const float>(c, op.t[S2K_SE_BWD_REDUCE_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_SE_BWD_REDUCE_T_BNV]);
+    float* out = ref_ptr<float>(c, op.t[S2K_SE_BWD_REDUCE_T_DGATE]);
+    CHECK_PTRS("se_bwd_reduce", g, y, bnv, out);
+    const int pro = op.d[S2K_SE_BWD_REDUCE_D_PRO];
+    if (!g || !y || !out || (pro && !bnv)) { set_error("se_bwd_reduce: bad args"); return S2K_EINVAL; }
+    return launch_plane_reduce<1>(g, y, bnv, out, op.d[S2K_SE_BWD_REDUCE_D_B], op.d[S2K_SE_BWD_REDUCE_D_C],
+                                  op.d[S2K_SE_BWD_REDUCE_D_HW], pro, c.stream);
+}
+
+int launch_channel_sum(const S2kOp& op, const Ctx& c) {
+    const float* g = ref_ptr<const float>(c, op.t[S2K_CHANNEL_SUM_T_G]);
+    float* out = ref_ptr<float>(c, op.t[S2K_CHANNEL_SUM_T_OUT]);
+    CHECK_PTRS("channel_sum", g, out);
+    if (!g || !out) { set_error("channel_sum: bad args"); return S2K_EINVAL; }
+    return launch_plane_reduce<2>(g, nullptr, nullptr, out, op.d[S2K_CHANNEL_SUM_D_B], op.d[S2K_CHANNEL_SUM_D_C],
+                                  op.d[S2K_CHANNEL_SUM_D_HW], 0, c.stream);
+}
+
+// ---------------- SE FCs ---------------------------------------------------------------------------------
+// one workgroup (1024 threads = 16 waves) per sample
+__global__ void __launch_bounds__(1024) se_fc_kernel(const float* pool, const float* w1, const float* b1, const float* w2,
+                                                     const float* b2, float* hpre, float* gate, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sp = smem;       // [C]
+    float* sh = smem + C;   // [Q]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < C; i += 1024) sp[i] = pool[(int64_t)b * C + i];
+    __syncthreads();
+    for (int j = wave; j < Q; j += 16) {
+        float s = 0.0f;
+        for (int i = lane; i < C; i += 64) s = fmaf(w1[(int64_t)j * C + i], sp[i], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            s += b1[j];
+            hpre[(int64_t)b * Q + j] = s;
+            sh[j] = silu_f(s);
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < C; i += 16) {
+        float s = 0.0f;
+        for (int j = lane; j < Q; j += 64) s = fmaf(w2[(int64_t)i * Q + j], sh[j], s);
+        s = wave_sum(s);
+        if (lane == 0) gate[(int64_t)b * C + i] = 1.0f / (1.0f + __expf(-(s + b2[i])));
+    }
+}
+
+int launch_se_fc(const S2kOp& op, const Ctx& c) {
+    const float* pool = ref_ptr<const float>(c, op.t[S2K_SE_FC_T_POOL]);
+    const float* w1 = ref_ptr<const float>(c, op.t[S2K_SE_FC_T_W1]);
+    const float* b1 = ref_ptr<const float>(c, op.t[S2K_SE_FC_T_B1]);
+    const float* w2 = ref_ptr<const float>(c, op.t[S2K_SE_FC_T_W2]);
+    const float* b2 = ref_ptr<const float>(c, op.t[S2K_SE_FC_T_B2]);
+    float* hpre = ref_ptr<float>(c, op.t[S2K_SE_FC_T_HPRE]);
+    float* gate = ref_ptr<float>(c, op.t[S2K_SE_FC_T_GATE]);
+    CHECK_PTRS("se_fc", pool, w1, b1, w2, b2, hpre, gate);
+    const int B = op.d[S2K_SE_FC_D_B], C = op.d[S2K_SE_FC_D_C], Q = op.d[S2K_SE_FC_D_CSQ];
+    if (!pool || !w1 || !b1 || !w2 || !b2 || !hpre || !gate || B <= 0 || C <= 0 || Q <= 0 || (size_t)(C + Q) * 4 > 60000) {
+        set_error("se_fc: bad args"); return S2K_EINVAL;
+    }
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(1024), (C + Q) * sizeof(float), c.stream, pool, w1, b1, w2, b2, hpre, gate, C, Q);
+    return S2K_OK;
+}
+
+// backward, phase A: per sample.  dgate -> dgp (in place), hs = silu(hpre), dhp (overwrites hpre), dpool
+__global__ void __launch_bounds__(1024) se_fc_bwd_a_kernel(float* dgate, const float* gate, float* hpre, const float* w1,
+                                                           const float* w2, float* hs, float* dpool, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sg = smem;            // [C] dgp
+    float* sd = smem + C;        // [Q] dhp
+    float* part = smem + C + Q;  // [16][Q] per-wave partial dh
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < C; i += 1024) {
+        const float gt = gate[(int64_t)b * C + i];
+        const float v = dgate[(int64_t)b * C + i] * gt * (1.0f - gt);
+        sg[i] = v;
+        dgate[(int64_t)b * C + i] = v;
+    }
+    __syncthreads();
+    // dh[j] = sum_c w2[c][j] * dgp[c]: wave w takes channels c = w, w+16, ...; lanes run over j (coalesced rows)
+    for (int j0 = 0; j0 < Q; j0 += 64) {
+        const int j = j0 + lane;
+        float s = 0.0f;
+        if (j < Q)
+            for (int i = wave; i < C; i += 16) s = fmaf(w2[(int64_t)i * Q + j], sg[i], s);
+        if (j < Q) part[wave * Q + j] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < Q; j += 1024) {
+        float s = 0.0f;
+        for (int w = 0; w < 16; ++w) s += part[w * Q + j];
+        const float hp = hpre[(int64_t)b * Q + j];
+        hs[(int64_t)b * Q + j] = silu_f(hp);
+        const float v = s * act_grad(hp, S2K_PRO_SILU);
+        sd[j] = v;
+        hpre[(int64_t)b * Q + j] = v;  // hpre now holds dhp
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += 1024) {
+        float s = 0.0f;
+        for (int j = 0; j < Q; ++j) s = fmaf(w1[(int64_t)j * C + i], sd[j], s);
+        dpool[(int64_t)b * C + i] = s;
+    }
+}
+
+// backward, phase B: parameter gradients, summed over the batch inside the thread (no atomics)
+__global__ void __launch_bounds__(NTHREADS) se_fc_bwd_b_kernel(const float* dgp, const float* hs, const float* dhp,
+                                                               const float* pool, float* dw1, float* db1, float* dw2,
+                                                               float* db2, int B, int C, int Q) {
+    const int64_t total = (int64_t)C * Q;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t e = t0; e < total; e += stride) {  // dw2[c][j], j fastest
+        const int cc = (int)(e / Q), j = (int)(e - (int64_t)cc * Q);
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s = fmaf(dgp[(int64_t)b * C + cc], hs[(int64_t)b * Q + j], s);
+        dw2[e] += s;
+    }
+    for (int64_t e = t0; e < total; e += stride) {  // dw1[j][c], c fastest
+        const int j = (int)(e / C), cc = (int)(e - (int64_t)j * C);
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s = fmaf(dhp[(int64_t)b * Q + j], pool[(int64_t)b * C + cc], s);
+        dw1[e] += s;
+    }
+    for (int64_t e = t0; e < C; e += stride) {
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s += dgp[(int64_t)b * C + e];
+        db2[e] += s;
+    }
+    for (int64_t e = t0; e < Q; e += stride) {
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) s += dhp[(int64_t)b * Q + e];
+        db1[e] += s;
+    }
+}
+
+int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
+    float* dgate = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DGATE]);
+    const float* gate = ref_ptr<const float>(c, op.t[S2K_SE_FC_BWD_T_GATE]);
+    float* hpre = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_HPRE]);
+    const float* pool = ref_ptr<const float>(c, op.t[S2K_SE_FC_BWD_T_POOL]);
+    const float* w1 = ref_ptr<const float>(c, op.t[S2K_SE_FC_BWD_T_W1]);
+    const float* w2 = ref_ptr<const float>(c, op.t[S2K_SE_FC_BWD_T_W2]);
+    float* dw1 = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DW1]);
+    float* db1 = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DB1]);
+    float* dw2 = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DW2]);
+    float* db2 = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DB2]);
+    float* dpool = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DPOOL]);
+    float* hs = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_HS]);
+    CHECK_PTRS("se_fc_bwd", dgate, gate, hpre, pool, w1, w2, dw1, db1, dw2, db2, dpool, hs);
+    const int B = op.d[S2K_SE_FC_BWD_D_B], C = op.d[S2K_SE_FC_BWD_D_C], Q = op.d[S2K_SE_FC_BWD_D_CSQ];
+    if (!dgate || !gate || !hpre || !pool || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpool || !hs || B <= 0) {
+        set_error("se_fc_bwd: bad args"); return S2K_EINVAL;
+    }
+    const size_t lds = ((size_t)C + Q + 16 * (size_t)Q) * sizeof(float);
+    if (lds > 60000) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(se_fc_bwd_a_kernel, dim3(B), dim3(1024), lds, c.stream, dgate, gate, hpre, w1, w2, hs, dpool, C, Q);
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
+    hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);
+    return S2K_OK;
+}
+
+// ---------------- BN backward ------------------------------------------------------------------------------
+// g' = (g * mulbc[b][c] * dcs[b] + addbc[b][c] * addscale) * act'(scale*y + shift); sums of g' and g'*xhat
+template <bool VEC>
+__global__ void __launch_bounds__(NTHREADS) bn_bwd_reduce_kernel(const float* g, const float* y, const float* bnv,
+                                                                 const float* mulbc, const float* addbc, const float* noise,
+                                                                 float* gout, double* stats2, int C, int HW, int64_t nplanes,
+                                                                 int act, float keep, float addscale) {
+    Task t;
+    if (!get_task(HW, nplanes, t)) return;
+    const int lane = threadIdx.x & 63;
+    const int c = (int)(t.plane % C);
+    const int b = (int)(t.plane / C);
+    const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+    float mul = mulbc ? mulbc[t.plane] : 1.0f;
+    if (noise) mul *= floorf(keep + noise[b]) / keep;
+    const float add = addbc ? addbc[t.plane] * addscale : 0.0f;
+    const int64_t base = t.plane * HW + t.start;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (VEC) {
+        const int n4 = t.count >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            float4 gv = reinterpret_cast<const float4*>(g + base)[i];
+            const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+            float* gp = &gv.x;
+            const float* yp = &yv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = fmaf(gp[k], mul, add);
+                if (act != S2K_PRO_NONE) v *= act_grad(fmaf(yp[k], scale, shift), act);
+                gp[k] = v;
+                s1 += v;
+                s2 = fmaf(v, (yp[k] - mean) * invstd, s2);
+            }
+            reinterpret_cast<float4*>(gout + base)[i] = gv;
+        }
+    } else {
+        for (int i = lane; i < t.count; i += 64) {
+            const float yy = y[base + i];
+            float v = fmaf(g[base + i], mul, add);
+            if (act != S2K_PRO_NONE) v *= act_grad(fmaf(yy, scale, shift), act);
+            gout[base + i] = v;
+            s1 += v;
+            s2 = fmaf(v, (yy - mean) * invstd, s2);
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        atomic_add_d(stats2 + c, (double)s1);
+        atomic_add_d(stats2 + C + c, (double)s2);
+    }
+}
+
+int launch_bn_bwd_reduce(const S2kOp& op, const Ctx& c) {
+    const float* g = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_G]);
+    const float* y = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_BNV]);
+    const float* mulbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_MULBC]);
+    const float* addbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_ADDBC]);
+    const float* noise = ref_ptr<const float>(c, op.t[S2K_BN_BWD_REDUCE_T_NOISE]);
+    float* gout = ref_ptr<float>(c, op.t[S2K_BN_BWD_REDUCE_T_GOUT]);
+    double* st2 = ref_ptr<double>(c, op.t[S2K_BN_BWD_REDUCE_T_STATS2]);
+    CHECK_PTRS("bn_bwd_reduce", g, y, bnv, mulbc, addbc, noise, gout, st2);
+    const int B = op.d[S2K_BN_BWD_REDUCE_D_B], C = op.d[S2K_BN_BWD_REDUCE_D_C], HW = op.d[S2K_BN_BWD_REDUCE_D_HW];
+    if (!g || !y || !bnv || !gout || !st2 || B <= 0 || C <= 0 || HW <= 0) { set_error("bn_bwd_reduce: bad args"); return S2K_EINVAL; }
+    const int64_t nplanes = (int64_t)B * C;
+    const unsigned blocks = task_blocks(HW, nplanes);
+    const int act = op.d[S2K_BN_BWD_REDUCE_D_ACT];
+    const float keep = op.f[S2K_BN_BWD_REDUCE_F_KEEP], addscale = op.f[S2K_BN_BWD_REDUCE_F_ADDSCALE];
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, mulbc, addbc, noise,
+                           gout, st2, C, HW, nplanes, act, keep, addscale);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, mulbc, addbc, noise,
+                           gout, st2, C, HW, nplanes, act, keep, addscale);
+    return S2K_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* st2, const float* gamma, const float* bnv, float* dgamma, float* dbeta,
+                                       float* coef, int C, double count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = st2[c], s2 = st2[C + c];
+    dgamma[c] += (float)s2;
+    dbeta[c] += (float)s1;
+    const double a = (double)gamma[c] * (double)bnv[3 * C + c];
+    coef[c] = (float)a;
+    coef[C + c] = (float)(-a * s2 / count);
+    coef[2 * C + c] = (float)(-a * s1 / count);
+}
+
+int launch_bn_bwd_finalize(const S2kOp& op, const Ctx& c) {
+    const double* st2 = ref_ptr<const double>(c, op.t[S2K_BN_BWD_FINALIZE_T_STATS2]);
+    const float* gamma = ref_ptr<const float>(c, op.t[S2K_BN_BWD_FINALIZE_T_GAMMA]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_BN_BWD_FINALIZE_T_BNV]);
+    float* dgamma = ref_ptr<float>(c, op.t[S2K_BN_BWD_FINALIZE_T_DGAMMA]);
+    float* dbeta = ref_ptr<float>(c, op.t[S2K_BN_BWD_FINALIZE_T_DBETA]);
+    float* coef = ref_ptr<float>(c, op.t[S2K_BN_BWD_FINALIZE_T_COEF]);
+    CHECK_PTRS("bn_bwd_finalize", st2, gamma, bnv, dgamma, dbeta, coef);
+    const int C = op.d[S2K_BN_BWD_FINALIZE_D_C];
+    if (!st2 || !gamma || !bnv || !dgamma || !dbeta || !coef || C <= 0) { set_error("bn_bwd_finalize: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, st2, gamma, bnv, dgamma, dbeta, coef, C,
+                       (double)op.n[S2K_BN_BWD_FINALIZE_N_COUNT]);
+    return S2K_OK;
+}
+
+// MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY);  MODE 1: xout = (scale*y+shift)*dcs[b] + ident (BN_RESIDUAL)
+template <int MODE, bool VEC>
+__global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, const float* y, const float* bnv, const float* coef,
+                                                             const float* noise, float* out, int C, int HW, int64_t nplanes,
+                                                             float keep) {
+    Task t;
+    if (!get_task(HW, nplanes, t)) return;
+    const int lane = threadIdx.x & 63;
+    const int c = (int)(t.plane % C);
+    float k0, k1, k2;  // out = k0*a + k1*y + k2
+    if (MODE == 0) {
+        const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+        const float A = coef[c], Bq = coef[C + c], Cq = coef[2 * C + c];
+        k0 = A; k1 = Bq * invstd; k2 = Cq - Bq * invstd * mean;
+    } else {
+        float dcs = 1.0f;
+        if (noise) dcs = floorf(keep + noise[(int)(t.plane / C)]) / keep;
+        k0 = a ? 1.0f : 0.0f; k1 = bnv[c] * dcs; k2 = bnv[C + c] * dcs;
+    }
+    const int64_t base = t.plane * HW + t.start;
+    if (VEC) {
+        const int n4 = t.count >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            float4 av = make_float4(0, 0, 0, 0);
+            if (a) av = reinterpret_cast<const float4*>(a + base)[i];
+            const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+            float4 o;
+            o.x = fmaf(k0, av.x, fmaf(k1, yv.x, k2)); o.y = fmaf(k0, av.y, fmaf(k1, yv.y, k2));
+            o.z = fmaf(k0, av.z, fmaf(k1, yv.z, k2)); o.w = fmaf(k0, av.w, fmaf(k1, yv.w, k2));
+            reinterpret_cast<float4*>(out + base)[i] = o;
+        }
+    } else {
+        for (int i = lane; i < t.count; i += 64) {
+            const float av = a ? a[base + i] : 0.0f;
+            out[base + i] = fmaf(k0, av, fmaf(k1, y[base + i], k2));
+        }
+    }
+}
+
+template <int MODE>
+static void launch_plane_map(const float* a, const float* y, const float* bnv, const float* coef, const float* noise, float* out,
+                             int B, int C, int HW, float keep, hipStream_t st) {
+    const int64_t nplanes = (int64_t)B * C;
+    const unsigned blocks = task_blocks(HW, nplanes);
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((plane_map_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep);
+    else
+        hipLaunchKernelGGL((plane_map_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep);
+}
+
+int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
+    const float* gp = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_GP]);
+    const float* y = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_BNV]);
+    const float* coef = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_COEF]);
+    float* dy = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DY]);
+    CHECK_PTRS("bn_bwd_apply", gp, y, bnv, coef, dy);
+    if (!gp || !y || !bnv || !coef || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
+    launch_plane_map<0>(gp, y, bnv, coef, nullptr, dy, op.d[S2K_BN_BWD_APPLY_D_B], op.d[S2K_BN_BWD_APPLY_D_C], op.d[S2K_BN_BWD_APPLY_D_HW], 1.0f, c.stream);
+    return S2K_OK;
+}
+
+int launch_bn_residual(const S2kOp& op, const Ctx& c) {
+    const float* y = ref_ptr<const float>(c, op.t[S2K_BN_RESIDUAL_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_BN_RESIDUAL_T_BNV]);
+    const float* ident = ref_ptr<const float>(c, op.t[S2K_BN_RESIDUAL_T_IDENT]);
+    const float* noise = ref_ptr<const float>(c, op.t[S2K_BN_RESIDUAL_T_NOISE]);
+    float* xout = ref_ptr<float>(c, op.t[S2K_BN_RESIDUAL_T_XOUT]);
+    CHECK_PTRS("bn_residual", y, bnv, ident, noise, xout);
+    if (!y || !bnv || !xout) { set_error("bn_residual: bad args"); return S2K_EINVAL; }
+    launch_plane_map<1>(ident, y, bnv, nullptr, noise, xout, op.d[S2K_BN_RESIDUAL_D_B], op.d[S2K_BN_RESIDUAL_D_C],
+                        op.d[S2K_BN_RESIDUAL_D_HW], op.f[S2K_BN_RESIDUAL_F_KEEP], c.stream);
+    return S2K_OK;
+}
+
+// ---------------- fused Adam (L2-coupled weight decay; torch.optim.Adam semantics) -------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                            float wd, float bc1, float bc2) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.0f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                int step, hipStream_t st) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) { set_error("adam: bad args"); return S2K_EINVAL; }
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+    const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
+    return S2K_OK;
+}
+
+}  // namespace s2k

@@ -1,0 +1,218 @@
+// Per-pixel cross-entropy / focal loss (+ gradient) and the class mask.
+//
+// Replaces /root/reference/src/losses.py:24-89 (get_loss -> nn.CrossEntropyLoss | FocalLoss.__call__:
+// F.cross_entropy(reduction="none", label_smoothing, ignore_index) -> pt = exp(-ce) ->
+// alpha[y] * (1-pt)^gamma * ce -> mean over ALL pixels) and logits.argmax(dim=1)
+// (train_segmentation.py:145,206).  One thread per pixel: the C logits of a pixel are C coalesced
+// plane reads; log-softmax, NLL, smoothing term and focal modulation stay in registers; the sum
+// is a wave shuffle reduction + one f64 atomic per wave.  Pure HBM streaming (read logits once).
+#include "common.h"
+
+namespace s2k {
+
+constexpr int MAXC = 64;
+
+struct LossP {
+    const float* logits;
+    const int64_t* labels;
+    const float* alpha;
+    double* acc;        // [2]: numerator, denominator
+    float* loss;        // [1]
+    const float* gout;  // [1] upstream gradient (backward)
+    float* dlogits;
+    int B, C, HW, mode, ignore, reduce_sum;
+    float gamma, smooth;
+};
+
+template <typename T>
+static T* ref_ptr(const Ctx& c, int64_t ref) {
+    if (ref < 0) return nullptr;
+    const int base = (int)(ref >> 56);
+    const int64_t off = ref & ((1ll << 56) - 1);
+    if (base >= c.n_bases || c.bases[base] == nullptr) return reinterpret_cast<T*>(1);
+    return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
+}
+static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
+
+// log-softmax of one pixel into lp[]; returns nothing else
+__device__ __forceinline__ void pixel_logp(const LossP& p, int b, int hw, float* lp) {
+    const float* src = p.logits + ((int64_t)b * p.C) * p.HW + hw;
+    float mx = -INFINITY;
+    for (int c = 0; c < p.C; ++c) {
+        lp[c] = src[(int64_t)c * p.HW];
+        mx = fmaxf(mx, lp[c]);
+    }
+    float se = 0.0f;
+    for (int c = 0; c < p.C; ++c) se += expf(lp[c] - mx);
+    const float lse = mx + logf(se);
+    for (int c = 0; c < p.C; ++c) lp[c] -= lse;
+}
+
+__global__ void __launch_bounds__(NTHREADS) loss_fwd_kernel(const LossP p) {
+    const int64_t npix = (int64_t)p.B * p.HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double num = 0.0, den = 0.0;
+    float lp[MAXC];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int b = (int)(i / p.HW), hw = (int)(i - (int64_t)b * p.HW);
+        const int64_t y = p.labels[i];
+        if (y == p.ignore || y < 0 || y >= p.C) continue;
+        pixel_logp(p, b, hw, lp);
+        if (p.mode == 0) {
+            const float wy = p.alpha ? p.alpha[y] : 1.0f;
+            float ce = (1.0f - p.smooth) * wy * (-lp[y]);
+            if (p.smooth > 0.0f) {
+                float sm = 0.0f;
+                for (int c = 0; c < p.C; ++c) sm -= (p.alpha ? p.alpha[c] : 1.0f) * lp[c];
+                ce += (p.smooth / p.C) * sm;
+            }
+            num += ce;
+            den += wy;
+        } else {
+            float ce = (1.0f - p.smooth) * (-lp[y]);
+            if (p.smooth > 0.0f) {
+                float sm = 0.0f;
+                for (int c = 0; c < p.C; ++c) sm -= lp[c];
+                ce += (p.smooth / p.C) * sm;
+            }
+            const float pt = expf(-ce);
+            const float a = p.alpha ? p.alpha[y] : 1.0f;
+            num += a * powf(1.0f - pt, p.gamma) * ce;
+        }
+    }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_add_d(p.acc, num);
+        atomic_add_d(p.acc + 1, den);
+    }
+}
+
+__global__ void loss_finish_kernel(const LossP p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double v;
+    if (p.mode == 0) v = p.acc[0] / p.acc[1];  // mean over non-ignored (NaN when none, as torch)
+    else v = p.reduce_sum ? p.acc[0] : p.acc[0] / ((double)p.B * p.HW);
+    p.loss[0] = (float)v;
+}
+
+__global__ void __launch_bounds__(NTHREADS) loss_bwd_kernel(const LossP p) {
+    const int64_t npix = (int64_t)p.B * p.HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float go = p.gout ? p.gout[0] : 1.0f;
+    float norm;
+    if (p.mode == 0) norm = go / (float)p.acc[1];
+    else norm = p.reduce_sum ? go : go / (float)((double)p.B * p.HW);
+    float lp[MAXC];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int b = (int)(i / p.HW), hw = (int)(i - (int64_t)b * p.HW);
+        float* dst = p.dlogits + ((int64_t)b * p.C) * p.HW + hw;
+        const int64_t y = p.labels[i];
+        if (y == p.ignore || y < 0 || y >= p.C) {
+            for (int c = 0; c < p.C; ++c) dst[(int64_t)c * p.HW] = 0.0f;
+            continue;
+        }
+        pixel_logp(p, b, hw, lp);
+        if (p.mode == 0) {
+            const float wy = p.alpha ? p.alpha[y] : 1.0f;
+            float wsum = 0.0f;
+            if (p.smooth > 0.0f)
+                for (int c = 0; c < p.C; ++c) wsum += p.alpha ? p.alpha[c] : 1.0f;
+            for (int c = 0; c < p.C; ++c) {
+                const float pc = expf(lp[c]);
+                float d = (1.0f - p.smooth) * wy * (pc - (c == y ? 1.0f : 0.0f));
+                if (p.smooth > 0.0f) d += (p.smooth / p.C) * (pc * wsum - (p.alpha ? p.alpha[c] : 1.0f));
+                dst[(int64_t)c * p.HW] = d * norm;
+            }
+        } else {
+            float ce = (1.0f - p.smooth) * (-lp[y]);
+            if (p.smooth > 0.0f) {
+                float sm = 0.0f;
+                for (int c = 0; c < p.C; ++c) sm -= lp[c];
+                ce += (p.smooth / p.C) * sm;
+            }
+            const float pt = expf(-ce);
+            const float om = 1.0f - pt;
+            const float a = p.alpha ? p.alpha[y] : 1.0f;
+            float dfl = 0.0f;  // d focal / d ce
+            if (om > 0.0f) dfl = a * (powf(om, p.gamma) + p.gamma * powf(om, p.gamma - 1.0f) * pt * ce);
+            else if (p.gamma == 0.0f) dfl = a;
+            for (int c = 0; c < p.C; ++c) {
+                const float pc = expf(lp[c]);
+                const float dce = (1.0f - p.smooth) * (pc - (c == y ? 1.0f : 0.0f)) + p.smooth * (pc - 1.0f / p.C);
+                dst[(int64_t)c * p.HW] = dfl * dce * norm;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(NTHREADS) argmax_kernel(const float* logits, int64_t* mask, int B, int C, int HW) {
+    const int64_t npix = (int64_t)B * HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        const int b = (int)(i / HW), hw = (int)(i - (int64_t)b * HW);
+        const float* src = logits + ((int64_t)b * C) * HW + hw;
+        float best = src[0];
+        int idx = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = src[(int64_t)c * HW];
+            if (v > best) { best = v; idx = c; }   // strict >: the first maximum wins
+        }
+        mask[i] = idx;
+    }
+}
+
+static int fill(LossP& p, const S2kOp& op, const Ctx& c, bool bwd) {
+    const int32_t* d = op.d;
+    p.B = d[0]; p.C = d[1]; p.HW = d[2]; p.mode = d[3]; p.ignore = d[4]; p.reduce_sum = d[5];
+    p.gamma = op.f[0]; p.smooth = op.f[1];
+    if (p.B <= 0 || p.C <= 1 || p.C > MAXC || p.HW <= 0) { set_error("loss: unsupported shape C=%d", p.C); return S2K_EINVAL; }
+    (void)c; (void)bwd;
+    return S2K_OK;
+}
+
+int launch_loss_fwd(const S2kOp& op, const Ctx& c) {
+    LossP p{};
+    if (int e = fill(p, op, c, false)) return e;
+    p.logits = ref_ptr<const float>(c, op.t[S2K_LOSS_FWD_T_LOGITS]);
+    p.labels = ref_ptr<const int64_t>(c, op.t[S2K_LOSS_FWD_T_LABELS]);
+    p.alpha = ref_ptr<const float>(c, op.t[S2K_LOSS_FWD_T_ALPHA]);
+    p.loss = ref_ptr<float>(c, op.t[S2K_LOSS_FWD_T_LOSS]);
+    p.acc = ref_ptr<double>(c, op.t[S2K_LOSS_FWD_T_ACC]);
+    if (bad(p.logits) || bad(p.labels) || bad(p.alpha) || bad(p.loss) || bad(p.acc)) { set_error("loss_fwd: null base"); return S2K_EFAULT; }
+    if (!p.logits || !p.labels || !p.loss || !p.acc) { set_error("loss_fwd: missing tensor"); return S2K_EINVAL; }
+    if (hipMemsetAsync(p.acc, 0, 2 * sizeof(double), c.stream) != hipSuccess) { set_error("loss_fwd: memset failed"); return S2K_EHIP; }
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)p.B * p.HW, NTHREADS), 2048);
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, p);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c.stream, p);
+    return S2K_OK;
+}
+
+int launch_loss_bwd(const S2kOp& op, const Ctx& c) {
+    LossP p{};
+    if (int e = fill(p, op, c, true)) return e;
+    p.logits = ref_ptr<const float>(c, op.t[S2K_LOSS_BWD_T_LOGITS]);
+    p.labels = ref_ptr<const int64_t>(c, op.t[S2K_LOSS_BWD_T_LABELS]);
+    p.alpha = ref_ptr<const float>(c, op.t[S2K_LOSS_BWD_T_ALPHA]);
+    p.acc = ref_ptr<double>(c, op.t[S2K_LOSS_BWD_T_ACC]);
+    p.gout = ref_ptr<const float>(c, op.t[S2K_LOSS_BWD_T_GOUT]);
+    p.dlogits = ref_ptr<float>(c, op.t[S2K_LOSS_BWD_T_DLOGITS]);
+    if (bad(p.logits) || bad(p.labels) || bad(p.alpha) || bad(p.acc) || bad(p.gout) || bad(p.dlogits)) { set_error("loss_bwd: null base"); return S2K_EFAULT; }
+    if (!p.logits || !p.labels || !p.acc || !p.dlogits) { set_error("loss_bwd: missing tensor"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)p.B * p.HW, NTHREADS), 2048);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, p);
+    return S2K_OK;
+}
+
+int launch_argmax(const S2kOp& op, const Ctx& c) {
+    const float* logits = ref_ptr<const float>(c, op.t[S2K_ARGMAX_T_LOGITS]);
+    int64_t* mask = ref_ptr<int64_t>(c, op.t[S2K_ARGMAX_T_MASK]);
+    if (bad(logits) || bad(mask)) { set_error("argmax: null base"); return S2K_EFAULT; }
+    const int B = op.d[S2K_ARGMAX_D_B], C = op.d[S2K_ARGMAX_D_C], HW = op.d[S2K_ARGMAX_D_HW];
+    if (!logits || !mask || B <= 0 || C <= 0 || HW <= 0) { set_error("argmax: bad args"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)B * HW, NTHREADS), 2048);
+    hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, logits, mask, B, C, HW);
+    return S2K_OK;
+}
+
+}  // namespace s2k

@@ -1,0 +1,184 @@
+// C-ABI entry points (include/s2k.h) and the native stage executor.
+//
+// The executor is the "runtime" of this path: a plain loop over POD stage records that enqueues
+// hand-written kernels on the caller's HIP stream.  No allocation, no synchronisation, no global
+// mutable state — so a whole forward or backward is graph-capturable and costs one FFI call.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace s2k {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_conv(const S2kOp&, const Ctx&);
+int launch_wgrad(const S2kOp&, const Ctx&);
+int launch_dwconv_fwd(const S2kOp&, const Ctx&);
+int launch_dwconv_dgrad(const S2kOp&, const Ctx&);
+int launch_dwconv_wgrad(const S2kOp&, const Ctx&);
+int launch_axpy(const S2kOp&, const Ctx&);
+int launch_wgrad_finalize(const S2kOp&, const Ctx&);
+int launch_bn_finalize(const S2kOp&, const Ctx&);
+int launch_se_pool(const S2kOp&, const Ctx&);
+int launch_se_fc(const S2kOp&, const Ctx&);
+int launch_se_fc_bwd(const S2kOp&, const Ctx&);
+int launch_se_bwd_reduce(const S2kOp&, const Ctx&);
+int launch_bn_bwd_reduce(const S2kOp&, const Ctx&);
+int launch_bn_bwd_finalize(const S2kOp&, const Ctx&);
+int launch_bn_bwd_apply(const S2kOp&, const Ctx&);
+int launch_bn_residual(const S2kOp&, const Ctx&);
+int launch_channel_sum(const S2kOp&, const Ctx&);
+int launch_loss_fwd(const S2kOp&, const Ctx&);
+int launch_loss_bwd(const S2kOp&, const Ctx&);
+int launch_argmax(const S2kOp&, const Ctx&);
+int launch_adam(float*, const float*, float*, float*, int64_t, float, float, float, float, float, int, hipStream_t);
+int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
+
+static int launch_memset(const S2kOp& op, const Ctx& c) {
+    const int64_t ref = op.t[S2K_MEMSET_T_DST];
+    const int64_t bytes = op.n[S2K_MEMSET_N_BYTES];
+    if (ref < 0 || bytes <= 0) { set_error("memset: bad args"); return S2K_EINVAL; }
+    const int base = (int)(ref >> 56);
+    if (base >= c.n_bases || !c.bases[base]) { set_error("memset: null base %d", base); return S2K_EFAULT; }
+    char* dst = static_cast<char*>(c.bases[base]) + (ref & ((1ll << 56) - 1));
+    if (hipMemsetAsync(dst, 0, (size_t)bytes, c.stream) != hipSuccess) { set_error("memset: hipMemsetAsync failed"); return S2K_EHIP; }
+    return S2K_OK;
+}
+
+static const char* const kNames[S2K_N_KINDS + 1] = {
+    nullptr, "MEMSET", "AXPY", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
+    "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
+    "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX"};
+
+static int dispatch(const S2kOp& op, const Ctx& c) {
+    switch (op.kind) {
+        case S2K_OP_MEMSET: return launch_memset(op, c);
+        case S2K_OP_AXPY: return launch_axpy(op, c);
+        case S2K_OP_CONV: return launch_conv(op, c);
+        case S2K_OP_WGRAD: return launch_wgrad(op, c);
+        case S2K_OP_WGRAD_FINALIZE: return launch_wgrad_finalize(op, c);
+        case S2K_OP_DWCONV_FWD: return launch_dwconv_fwd(op, c);
+        case S2K_OP_DWCONV_DGRAD: return launch_dwconv_dgrad(op, c);
+        case S2K_OP_DWCONV_WGRAD: return launch_dwconv_wgrad(op, c);
+        case S2K_OP_BN_FINALIZE: return launch_bn_finalize(op, c);
+        case S2K_OP_SE_POOL: return launch_se_pool(op, c);
+        case S2K_OP_SE_FC: return launch_se_fc(op, c);
+        case S2K_OP_SE_FC_BWD: return launch_se_fc_bwd(op, c);
+        case S2K_OP_SE_BWD_REDUCE: return launch_se_bwd_reduce(op, c);
+        case S2K_OP_BN_BWD_REDUCE: return launch_bn_bwd_reduce(op, c);
+        case S2K_OP_BN_BWD_FINALIZE: return launch_bn_bwd_finalize(op, c);
+        case S2K_OP_BN_BWD_APPLY: return launch_bn_bwd_apply(op, c);
+        case S2K_OP_BN_RESIDUAL: return launch_bn_residual(op, c);
+        case S2K_OP_CHANNEL_SUM: return launch_channel_sum(op, c);
+        case S2K_OP_LOSS_FWD: return launch_loss_fwd(op, c);
+        case S2K_OP_LOSS_BWD: return launch_loss_bwd(op, c);
+        case S2K_OP_ARGMAX: return launch_argmax(op, c);
+        default: set_error("unknown stage kind %d", op.kind); return S2K_ENOSYS;
+    }
+}
+
+static int check_launch(int rc, const S2kOp& op, int index) {
+    if (rc != S2K_OK) {
+        char tmp[400];
+        snprintf(tmp, sizeof(tmp), "%s", g_err);
+        set_error("op %d (%s): %s", index, (op.kind > 0 && op.kind <= S2K_N_KINDS) ? kNames[op.kind] : "?", tmp);
+        return rc;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("op %d (%s): HIP launch error: %s", index, (op.kind > 0 && op.kind <= S2K_N_KINDS) ? kNames[op.kind] : "?",
+                  hipGetErrorString(e));
+        return S2K_EHIP;
+    }
+    return S2K_OK;
+}
+
+}  // namespace s2k
+
+using namespace s2k;
+
+extern "C" {
+
+int s2k_abi_version(void) { return S2K_ABI_VERSION; }
+size_t s2k_op_size(void) { return sizeof(S2kOp); }
+const char* s2k_last_error(void) { return g_err; }
+const char* s2k_kind_name(int kind) { return (kind > 0 && kind <= S2K_N_KINDS) ? kNames[kind] : nullptr; }
+
+int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream) {
+    if (!ops || !bases || begin < 0 || end < begin) { set_error("program_run: bad arguments"); return S2K_EINVAL; }
+    Ctx c{bases, n_bases, static_cast<hipStream_t>(stream)};
+    for (int i = begin; i < end; ++i) {
+        const int rc = check_launch(dispatch(ops[i], c), ops[i], i);
+        if (rc != S2K_OK) return rc;
+    }
+    return S2K_OK;
+}
+
+int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream) {
+    if (!op || !bases) { set_error("op_launch: bad arguments"); return S2K_EINVAL; }
+    Ctx c{bases, n_bases, static_cast<hipStream_t>(stream)};
+    return check_launch(dispatch(*op, c), *op, 0);
+}
+
+int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
+                        int* launches_by_kind) {
+    if (!ops || !bases || !ms_by_kind || !launches_by_kind || begin < 0 || end < begin) {
+        set_error("program_profile: bad arguments");
+        return S2K_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ctx c{bases, n_bases, st};
+    const int n = end - begin;
+    hipEvent_t* ev = new hipEvent_t[n + 1];
+    for (int i = 0; i <= n; ++i) hipEventCreate(&ev[i]);
+    int rc = S2K_OK;
+    hipEventRecord(ev[0], st);
+    int done = 0;
+    for (int i = 0; i < n; ++i) {
+        rc = check_launch(dispatch(ops[begin + i], c), ops[begin + i], begin + i);
+        if (rc != S2K_OK) break;
+        hipEventRecord(ev[i + 1], st);
+        done = i + 1;
+    }
+    hipStreamSynchronize(st);
+    if (rc == S2K_OK) {
+        for (int k = 0; k <= S2K_N_KINDS; ++k) { ms_by_kind[k] = 0.0f; launches_by_kind[k] = 0; }
+        for (int i = 0; i < done; ++i) {
+            float ms = 0.0f;
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            const int k = ops[begin + i].kind;
+            if (k > 0 && k <= S2K_N_KINDS) { ms_by_kind[k] += ms; launches_by_kind[k] += 1; }
+        }
+    }
+    for (int i = 0; i <= n; ++i) hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
+}
+
+int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, void* stream) {
+    const int rc = launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, static_cast<hipStream_t>(stream));
+    if (rc != S2K_OK) return rc;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("adam: %s", hipGetErrorString(e)); return S2K_EHIP; }
+    return S2K_OK;
+}
+
+int s2k_selftest_mfma(const float* a, const float* b, float* d, void* stream) {
+    if (!a || !b || !d) { set_error("selftest: null pointer"); return S2K_EINVAL; }
+    launch_mfma_selftest(a, b, d, static_cast<hipStream_t>(stream));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("selftest: %s", hipGetErrorString(e)); return S2K_EHIP; }
+    return S2K_OK;
+}
+
+}  // extern "C"

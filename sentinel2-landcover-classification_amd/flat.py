@@ -79,6 +79,32 @@ class FlatParamsMixin:
             n = p.numel()
             p.grad = g[off:off + n].view(shape)
 
+    def _grad_scratch(self) -> torch.Tensor:
+        if getattr(self, "_flat_grads2", None) is None or self._flat_grads2.device != self._flat_params.device:
+            self._flat_grads2 = torch.zeros_like(self._flat_params)
+        return self._flat_grads2
+
+    def _grads_live(self) -> bool:
+        """True when the user kept gradients from an earlier backward (accumulation semantics)."""
+        if self._flat_grads is None:
+            return False
+        for p in self.parameters():
+            if p.grad is not None:
+                return p.grad.data_ptr() >= self._flat_grads.data_ptr() and \
+                    p.grad.data_ptr() < self._flat_grads.data_ptr() + self._flat_grads.numel() * 4
+        return False
+
+    def _anchor(self, device) -> torch.Tensor:
+        a = getattr(self, "_anchor_t", None)
+        if a is None or a.device != device:
+            a = torch.zeros((), device=device, requires_grad=True)
+            self._anchor_t = a
+        return a
+
+    @property
+    def _no_grad_params(self) -> set:
+        return getattr(self, "_unused_params", set())
+
     def flat_parameters(self) -> torch.Tensor:
         return self._flat_params
 

@@ -207,6 +207,7 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
         self.apply(init_weights)
         initialize_classification_layer_bias(self.out_conv1x1, class_distribution=config.class_distribution)
         self.drop_connect_noise: torch.Tensor | None = None  # inject [n_blocks, B] uniforms for parity tests
+        self._unused_params = {"encoder.fc.3.weight", "encoder.fc.3.bias"}  # never on the U-Net path (as in the reference)
         self._init_flat(build_layout(self.spec))
 
     @property

@@ -66,7 +66,8 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "SE_POOL": (["Y", "BNV", "POOL"], [], ["B", "C", "HW", "PRO"], []),
     # HPRE = W1 pool + B1; GATE = sigmoid(W2 silu(HPRE) + B2)
     "SE_FC": (["POOL", "W1", "B1", "W2", "B2", "HPRE", "GATE"], [], ["B", "C", "CSQ"], []),
-    "SE_FC_BWD": (["DGATE", "GATE", "HPRE", "POOL", "W1", "W2", "DW1", "DB1", "DW2", "DB2", "DPOOL"], [],
+    # DGATE is overwritten with d(pre-sigmoid), HPRE with d(pre-SiLU); HS = scratch [B][CSQ] for silu(HPRE)
+    "SE_FC_BWD": (["DGATE", "GATE", "HPRE", "POOL", "W1", "W2", "DW1", "DB1", "DW2", "DB2", "DPOOL", "HS"], [],
                   ["B", "C", "CSQ"], []),
     # DGATE[b][c] = sum_hw G * act(scale*Y+shift)
     "SE_BWD_REDUCE": (["G", "Y", "BNV", "DGATE"], [], ["B", "C", "HW", "PRO"], []),

@@ -370,9 +370,10 @@ def squeeze_excite(p: _P, prefix: str, a: Act, se: int) -> Act:
     def backward():
         dgate = p.alloc("dgate:" + prefix, (B, C))
         dpool = p.alloc("dpool:" + prefix, (B, C))
+        hs = p.alloc("hs:" + prefix, (B, se))
         p.bwd.add("SE_BWD_REDUCE", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, B=B, C=C, HW=HW, PRO=a.pro)
         p.bwd.add("SE_FC_BWD", DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=p.param(w1), W2=p.param(w2),
-                  DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2), DB2=p.pgrad(b2), DPOOL=dpool,
+                  DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2), DB2=p.pgrad(b2), DPOOL=dpool, HS=hs,
                   B=B, C=C, CSQ=se)
         a.mulbc, a.addbc, a.addscale = gate, dpool, 1.0 / HW
 

@@ -1,0 +1,440 @@
+"""GPU parity, stage by stage: every HIP kernel family is launched through the C ABI
+(`s2k_program_run` on a one-record program) and compared with the oracle's CPU statement of the
+same stage (oracle/ops_ref.py) on identical seeded bytes.  fp32 tolerance is stated per case
+(float atomics make sums order-dependent; 1e-4 relative to the tensor's max is the bar here, the
+network-level bar of BASELINE.json is 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import ops_ref
+from s2lc_amd.plan import opdefs as D
+from s2lc_amd.plan.program import Arena, Program
+
+pytestmark = pytest.mark.gpu
+
+WS = D.BASE["WS"]
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32}
+
+
+class Case:
+    def __init__(self, seed=0):
+        self.arena = Arena(WS)
+        self.items = {}
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def t(self, name, shape, fill="randn", dtype="f32", scale=1.0):
+        ref = self.arena.alloc(name, shape, dtype)
+        if isinstance(fill, torch.Tensor):
+            data = fill.to(_DT[dtype]).reshape(shape).clone()
+        elif fill == "randn":
+            data = torch.randn(shape, generator=self.gen) * scale
+        elif fill == "rand":
+            data = torch.rand(shape, generator=self.gen) * scale
+        elif fill == "pos":
+            data = torch.rand(shape, generator=self.gen) * scale + 0.5
+        elif fill == "zeros":
+            data = torch.zeros(shape)
+        elif fill == "nan":
+            data = torch.full(shape, float("nan"))
+        else:
+            raise ValueError(fill)
+        self.items[name] = (ref, data.to(_DT[dtype]))
+        return ref
+
+    def bnv(self, name, C):
+        """{scale, shift, mean, invstd} of a plausible BatchNorm."""
+        scale = torch.rand(C, generator=self.gen) + 0.5
+        shift = torch.randn(C, generator=self.gen) * 0.3
+        mean = torch.randn(C, generator=self.gen) * 0.3
+        invstd = torch.rand(C, generator=self.gen) + 0.7
+        return self.t(name, (4, C), torch.stack([scale, shift, mean, invstd]))
+
+    def run(self, kind, outputs, tol=1e-4, **fields):
+        from s2lc_amd import _lib
+
+        prog = Program()
+        prog.add(kind, **fields)
+        packed = prog.pack()
+        cpu = torch.zeros(self.arena.top + 256, dtype=torch.uint8)
+        for name, (ref, data) in self.items.items():
+            cpu[ref.off:ref.off + ref.nbytes] = data.contiguous().reshape(-1).view(torch.uint8)
+        gpu = cpu.cuda()
+        _lib.run(packed, _lib.Bases().set("WS", gpu), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = gpu.cpu()
+        ops_ref.run_program(packed, {WS: cpu}, D)
+        for name in outputs:
+            ref, _ = self.items[name]
+            a = got[ref.off:ref.off + ref.nbytes].view(_DT[ref.dtype]).double()
+            b = cpu[ref.off:ref.off + ref.nbytes].view(_DT[ref.dtype]).double()
+            assert torch.isfinite(b).all(), f"{kind}:{name}: oracle produced non-finite values"
+            assert torch.isfinite(a).all(), f"{kind}:{name}: GPU produced non-finite values"
+            denom = max(b.abs().max().item(), 1e-20)
+            err = (a - b).abs().max().item() / denom
+            assert err < tol, f"{kind}:{name}: rel err {err:.3e} (max |ref| {denom:.3e})"
+
+
+def test_mfma_lane_maps_exact():
+    """A = asymmetric small integers, B likewise: D must equal A@B exactly (guide: always check
+    the C/D map with an asymmetric operand)."""
+    from s2lc_amd import _lib
+
+    a = (torch.arange(64).reshape(32, 2) % 7 - 3).float()
+    b = ((torch.arange(64).reshape(2, 32) * 5) % 11 - 4).float()
+    d = torch.zeros(32, 32).cuda()
+    ac, bc = a.cuda(), b.cuda()
+    _lib.check(_lib.lib().s2k_selftest_mfma(ac.data_ptr(), bc.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), a @ b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CONV (implicit GEMM)
+# ---------------------------------------------------------------------------------------------------
+def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias, stats, beta=0, mode=0, flip=0,
+               strides=None, seed=0, tol=1e-4, yc=None):
+    c = Case(seed)
+    T = k * k
+    Ct = C1 + C2
+    if mode == D.MODE_GATHER2X2:
+        x1 = c.t("x1", (B, C1 // 4, 2 * H, 2 * W))
+    else:
+        x1 = c.t("x1", (B, C1, H, W))
+    x2 = c.t("x2", (B, C2, H, W)) if C2 else None
+    bnv1 = c.bnv("bnv1", C1) if pro1 else None
+    bnv2 = c.bnv("bnv2", C2) if (C2 and pro2) else None
+    g1 = c.t("gate1", (B, C1), "rand") if gate else None
+    if strides is None:
+        wt = c.t("wt", (M, Ct, T), scale=(1.0 / (Ct * T)) ** 0.5)
+        sm, sk, st = Ct * T, T, 1
+    else:
+        wshape, (sm, sk, st) = strides
+        wt = c.t("wt", wshape, scale=(1.0 / (Ct * T)) ** 0.5)
+    nb = M // 4 if mode == D.MODE_CONVT_SCATTER else M
+    bs = c.t("bias", (nb,)) if bias else None
+    YC = yc or (M // 4 if mode == D.MODE_CONVT_SCATTER else M)
+    if mode == D.MODE_CONVT_SCATTER:
+        y = c.t("y", (B, YC, 2 * Ho, 2 * Wo), "nan")
+    else:
+        y = c.t("y", (B, YC, Ho, Wo), "randn" if beta else "nan")
+    st_ref = c.t("stats", (2, M), "zeros", "f64") if stats else None
+    outs = ["y"] + (["stats"] if stats else [])
+    c.run("CONV", outs, tol, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wt, BIAS=bs, Y=y, STATS=st_ref,
+          B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo,
+          PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=sm, W_SK=sk, W_ST=st, FLIP=flip, BETA=beta, YC=YC)
+
+
+@pytest.mark.parametrize("B,C1,H,W,M,pro,gate", [
+    (3, 24, 16, 16, 144, 0, False),      # expand 1x1, BM=32 config
+    (2, 144, 16, 16, 40, 2, True),       # project 1x1: BN+SiLU+SE gate prologue, BM=64
+    (2, 40, 12, 20, 240, 0, False),      # BM=128
+    (3, 304, 7, 7, 1824, 0, False),      # 7x7 maps: ragged pixel tail, HW=49
+    (2, 1824, 8, 8, 304, 2, True),       # deep project: small-problem 64x64 tiles, long K
+    (2, 32, 24, 24, 4, 3, False),        # out_conv1x1: M=4
+    (1, 13, 8, 8, 48, 0, False),         # K tail (13 channels)
+])
+def test_conv1x1(B, C1, H, W, M, pro, gate):
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, pro, 0, gate, bias=(M == 4), stats=(M != 4))
+
+
+@pytest.mark.parametrize("B,C1,C2,H,W,M,pro1,pro2", [
+    (2, 40, 24, 20, 20, 64, 0, 0),      # decoder concat (up-conv output + skip), BM=64
+    (2, 32, 13, 32, 32, 32, 0, 0),      # input_double_conv.0: concat with the raw 13-band input
+    (2, 64, 0, 14, 14, 64, 3, 0),       # second conv of a double conv: BN+ReLU prologue; 14x14 (224 path)
+    (1, 88, 0, 28, 28, 128, 3, 0),      # BM=128
+    (1, 32, 0, 8, 72, 32, 3, 0),        # wide rows: row segments
+    (1, 16, 8, 40, 300, 32, 0, 0),      # width > tile: several x tiles per row
+])
+def test_conv3x3(B, C1, C2, H, W, M, pro1, pro2):
+    _conv_case(B, C1, C2, H, W, M, 3, 1, 1, 1, H, W, pro1, pro2, False, bias=True, stats=True)
+
+
+@pytest.mark.parametrize("C,H,W", [(13, 32, 32), (6, 30, 26), (4, 64, 64)])
+def test_stem_conv_tf_same_stride2(C, H, W):
+    from s2lc_amd.plan.unet_plan import same_pads
+
+    Ho, pt = same_pads(H, 3, 2)
+    Wo, pl = same_pads(W, 3, 2)
+    _conv_case(2, C, 0, H, W, 48, 3, 2, pt, pl, Ho, Wo, 0, 0, False, bias=False, stats=True)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pro", [(2, 24, 16, 8, 8, 3), (1, 2048, 512, 2, 2, 2), (2, 64, 32, 16, 24, 3)])
+def test_conv_transpose_scatter(B, Cin, Cout, H, W, pro):
+    _conv_case(B, Cin, 0, H, W, 4 * Cout, 1, 1, 0, 0, H, W, pro, 0, False, bias=True, stats=False,
+               mode=D.MODE_CONVT_SCATTER, strides=((Cin, Cout, 4), (1, 4 * Cout, 1)))
+
+
+@pytest.mark.parametrize("beta", [0, 1])
+def test_conv_dgrad_3x3_flip(beta):
+    # dX[c] = sum_{m,tap} W[m][c_off+c][flip tap] dY[m]: rows = a channel slice of a concat conv
+    B, Mout, Ctot, c_off, Cs, H, W = 2, 64, 40, 16, 24, 12, 12
+    c = Case(3)
+    dy = c.t("x1", (B, Mout, H, W))
+    wfull = c.t("wt_full", (Mout, Ctot, 9), scale=0.1)
+    y = c.t("y", (B, Cs, H, W), "randn" if beta else "nan")
+    c.run("CONV", ["y"], 1e-4, X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wfull.at(c_off * 9), BIAS=None, Y=y,
+          STATS=None, B=B, C1=Mout, C2=0, H=H, W=W, M=Cs, KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=W, PRO1=0,
+          PRO2=0, MODE=0, W_SM=9, W_SK=Ctot * 9, W_ST=1, FLIP=1, BETA=beta, YC=Cs)
+
+
+def test_conv_dgrad_1x1_and_gather():
+    _conv_case(2, 144, 0, 10, 10, 24, 1, 1, 0, 0, 10, 10, 0, 0, False, False, False, beta=1,
+               strides=((144, 24, 1), (1, 24, 1)))  # dgrad of an expand conv: A[c][m] = W[m][c]
+    # ConvTranspose dgrad: pseudo-channels (co,dy,dx) gathered from the 2x-resolution gradient
+    _conv_case(2, 4 * 16, 0, 6, 10, 24, 1, 1, 0, 0, 6, 10, 0, 0, False, False, False, mode=D.MODE_GATHER2X2,
+               strides=((24, 16 * 4, 1), (64, 1, 1)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# WGRAD
+# ---------------------------------------------------------------------------------------------------
+def _wgrad_case(B, M, C, CT, c_off, H, W, k, s, pt, pl, Ho, Wo, prop, proq, gateq, mode=0, seed=0, tol=2e-4):
+    c = Case(seed)
+    T = k * k
+    P = c.t("p", (B, M, Ho, Wo))
+    Q = c.t("q", (B, C, H, W))
+    bp = c.bnv("bnvp", M) if prop else None
+    bq = c.bnv("bnvq", C) if proq else None
+    gq = c.t("gateq", (B, C), "rand") if gateq else None
+    wgs = c.t("wgs", (T, M, CT), "randn")  # accumulates on top of existing content
+    c.run("WGRAD", ["wgs"], tol, P=P, BNVP=bp, GATEP=None, Q=Q, BNVQ=bq, GATEQ=gq, WGS=wgs.at(c_off), B=B, M=M, C=C,
+          CTOT=CT, H=H, W=W, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=prop, PROQ=proq, MODE=mode)
+
+
+@pytest.mark.parametrize("B,M,C,H,W,proq,gate", [(2, 40, 144, 16, 16, 2, True), (3, 144, 24, 12, 12, 0, False),
+                                                   (2, 4, 32, 16, 16, 3, False), (3, 200, 130, 7, 7, 0, False)])
+def test_wgrad_1x1(B, M, C, H, W, proq, gate):
+    _wgrad_case(B, M, C, C, 0, H, W, 1, 1, 0, 0, H, W, 0, proq, gate)
+
+
+@pytest.mark.parametrize("B,M,C,CT,c_off,H,W,proq", [(2, 64, 24, 64, 40, 20, 20, 0), (2, 32, 32, 32, 0, 24, 40, 3),
+                                                       (1, 32, 13, 45, 32, 32, 32, 0), (2, 128, 88, 88, 0, 14, 14, 3),
+                                                       (1, 48, 40, 40, 0, 9, 130, 0)])
+def test_wgrad_3x3(B, M, C, CT, c_off, H, W, proq):
+    _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False)
+
+
+def test_wgrad_stem_stride2():
+    from s2lc_amd.plan.unet_plan import same_pads
+
+    H, W = 32, 40
+    Ho, pt = same_pads(H, 3, 2)
+    Wo, pl = same_pads(W, 3, 2)
+    _wgrad_case(2, 48, 13, 13, 0, H, W, 3, 2, pt, pl, Ho, Wo, 0, 0, False)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,prop", [(2, 64, 32, 8, 8, 3), (1, 200, 72, 4, 6, 2)])
+def test_wgrad_conv_transpose(B, Cin, Cout, H, W, prop):
+    _wgrad_case(B, Cin, Cout, Cout, 0, 2 * H, 2 * W, 2, 2, 0, 0, H, W, prop, 0, False, mode=D.MODE_GATHER2X2)
+
+
+def test_wgrad_finalize():
+    c = Case(5)
+    entries = [(0, 8, 5, 9), (512, 12, 7, 1), (1024, 6, 4, 4)]
+    table, start = [], 0
+    for off, M, C, T in entries:
+        table.append([off, M, C, T, start])
+        start += M * C * T
+    tab = c.t("table", (len(table), 5), torch.tensor(table), "i32")
+    wgs = c.t("wgs", (2048,))
+    grads = c.t("grads", (2048,))
+    c.run("WGRAD_FINALIZE", ["grads"], 1e-6, TABLE=tab, WGS=wgs, GRADS=grads, TOTAL=start, N_ENTRIES=len(table))
+
+
+# ---------------------------------------------------------------------------------------------------
+# depthwise
+# ---------------------------------------------------------------------------------------------------
+DW_GEOS = [(2, 24, 16, 16, 3, 1), (2, 40, 16, 16, 5, 2), (3, 16, 7, 7, 5, 1), (2, 8, 40, 40, 3, 2), (1, 6, 15, 13, 5, 2),
+           (1, 4, 64, 64, 5, 1), (2, 100, 8, 8, 3, 1), (1, 3, 130, 70, 3, 1)]
+
+
+def _dw_geo(B, C, H, W, K, S):
+    from s2lc_amd.plan.unet_plan import same_pads
+
+    Ho, pt = same_pads(H, K, S)
+    Wo, pl = same_pads(W, K, S)
+    return dict(B=B, C=C, H=H, W=W, K=K, STRIDE=S, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo), Ho, Wo
+
+
+@pytest.mark.parametrize("geo", DW_GEOS)
+@pytest.mark.parametrize("pro", [0, 2])
+def test_dwconv_fwd(geo, pro):
+    B, C, H, W, K, S = geo
+    g, Ho, Wo = _dw_geo(*geo)
+    c = Case(1)
+    x = c.t("x", (B, C, H, W))
+    bnv = c.bnv("bnv", C) if pro else None
+    w = c.t("w", (C, K, K), scale=0.3)
+    y = c.t("y", (B, C, Ho, Wo), "nan")
+    st = c.t("stats", (2, C), "zeros", "f64")
+    c.run("DWCONV_FWD", ["y", "stats"], 1e-4, X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=pro, **g)
+
+
+@pytest.mark.parametrize("geo", DW_GEOS)
+@pytest.mark.parametrize("pro,beta", [(0, 0), (0, 1), (2, 0)])
+def test_dwconv_dgrad(geo, pro, beta):
+    B, C, H, W, K, S = geo
+    g, Ho, Wo = _dw_geo(*geo)
+    c = Case(2)
+    dy = c.t("dy", (B, C, Ho, Wo))
+    w = c.t("w", (C, K, K), scale=0.3)
+    xr = c.t("xraw", (B, C, H, W)) if pro else None
+    bnv = c.bnv("bnv", C) if pro else None
+    gg = c.t("g", (B, C, H, W), "randn" if beta else "nan")
+    st = c.t("stats2", (2, C), "zeros", "f64") if pro else None
+    outs = ["g"] + (["stats2"] if pro else [])
+    c.run("DWCONV_DGRAD", outs, 1e-4, DY=dy, WT=w, XRAW=xr, BNV=bnv, G=gg, STATS2=st, PRO=pro, BETA=beta, **g)
+
+
+@pytest.mark.parametrize("geo", DW_GEOS)
+@pytest.mark.parametrize("pro", [0, 2])
+def test_dwconv_wgrad(geo, pro):
+    B, C, H, W, K, S = geo
+    g, Ho, Wo = _dw_geo(*geo)
+    c = Case(3)
+    dy = c.t("dy", (B, C, Ho, Wo))
+    x = c.t("x", (B, C, H, W))
+    bnv = c.bnv("bnv", C) if pro else None
+    dw = c.t("dw", (C, K, K), "randn")
+    c.run("DWCONV_WGRAD", ["dw"], 2e-4, DY=dy, X=x, BNV=bnv, DW=dw, PRO=pro, **g)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BatchNorm / SE / residual / reductions
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("train", [1, 0])
+def test_bn_finalize(train):
+    c = Case(4)
+    C, n = 70, 5000
+    mean = torch.randn(C, dtype=torch.float64)
+    var = torch.rand(C, dtype=torch.float64) + 0.1
+    stats = c.t("stats", (2, C), torch.stack([mean * n, (var + mean * mean) * n]), "f64")
+    gam, bet = c.t("gamma", (C,), "pos"), c.t("beta", (C,))
+    rm, rv = c.t("rm", (C,)), c.t("rv", (C,), "pos")
+    bnv = c.t("bnv", (4, C), "nan")
+    c.run("BN_FINALIZE", ["bnv", "rm", "rv"], 1e-5, STATS=stats if train else None, GAMMA=gam, BETA=bet, RM=rm, RV=rv,
+          BNV=bnv, COUNT=n, C=C, TRAIN=train, EPS=1e-3, MOM=0.01)
+
+
+@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 3, 10000)])
+@pytest.mark.parametrize("variant", ["relu", "silu_se", "none_dc"])
+def test_bn_backward_trio(B, C, HW, variant):
+    c = Case(6)
+    g = c.t("g", (B, C, HW))
+    y = c.t("y", (B, C, HW))
+    bnv = c.bnv("bnv", C)
+    gout = c.t("gout", (B, C, HW), "nan")
+    st2 = c.t("stats2", (2, C), "zeros", "f64")
+    mul = c.t("mul", (B, C), "rand") if variant == "silu_se" else None
+    add = c.t("add", (B, C)) if variant == "silu_se" else None
+    noise = c.t("noise", (B,), "rand") if variant == "none_dc" else None
+    act = {"relu": 3, "silu_se": 2, "none_dc": 0}[variant]
+    c.run("BN_BWD_REDUCE", ["gout", "stats2"], 1e-4, G=g, Y=y, BNV=bnv, MULBC=mul, ADDBC=add, NOISE=noise, GOUT=gout,
+          STATS2=st2, B=B, C=C, HW=HW, ACT=act, KEEP=0.6, ADDSCALE=1.0 / HW)
+    c2 = Case(7)
+    st2 = c2.t("stats2", (2, C), torch.randn(2, C, dtype=torch.float64) * 10, "f64")
+    gam = c2.t("gamma", (C,), "pos")
+    bnv = c2.bnv("bnv", C)
+    dg, db = c2.t("dgamma", (C,)), c2.t("dbeta", (C,))
+    coef = c2.t("coef", (3, C), "nan")
+    c2.run("BN_BWD_FINALIZE", ["dgamma", "dbeta", "coef"], 1e-5, STATS2=st2, GAMMA=gam, BNV=bnv, DGAMMA=dg, DBETA=db,
+           COEF=coef, COUNT=B * HW, C=C)
+    c3 = Case(8)
+    gp, y = c3.t("gp", (B, C, HW)), c3.t("y", (B, C, HW))
+    bnv, coef = c3.bnv("bnv", C), c3.t("coef", (3, C))
+    dy = c3.t("dy", (B, C, HW), "nan")
+    c3.run("BN_BWD_APPLY", ["dy"], 1e-5, GP=gp, Y=y, BNV=bnv, COEF=coef, DY=dy, B=B, C=C, HW=HW)
+
+
+@pytest.mark.parametrize("B,C,HW,ident,noise", [(2, 24, 256, True, True), (3, 10, 49, False, False), (1, 3, 9000, True, False)])
+def test_bn_residual(B, C, HW, ident, noise):
+    c = Case(9)
+    y, bnv = c.t("y", (B, C, HW)), c.bnv("bnv", C)
+    idt = c.t("ident", (B, C, HW)) if ident else None
+    nz = c.t("noise", (B,), "rand") if noise else None
+    out = c.t("xout", (B, C, HW), "nan")
+    c.run("BN_RESIDUAL", ["xout"], 1e-6, Y=y, BNV=bnv, IDENT=idt, NOISE=nz, XOUT=out, B=B, C=C, HW=HW, KEEP=0.55)
+
+
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000)])
+def test_se_pool_bwd_reduce_channel_sum(B, C, HW):
+    c = Case(10)
+    y, bnv = c.t("y", (B, C, HW)), c.bnv("bnv", C)
+    pool = c.t("pool", (B, C), "nan")
+    c.run("SE_POOL", ["pool"], 1e-5, Y=y, BNV=bnv, POOL=pool, B=B, C=C, HW=HW, PRO=2)
+    c = Case(11)
+    g, y, bnv = c.t("g", (B, C, HW)), c.t("y", (B, C, HW)), c.bnv("bnv", C)
+    dg = c.t("dgate", (B, C), "nan")
+    c.run("SE_BWD_REDUCE", ["dgate"], 1e-4, G=g, Y=y, BNV=bnv, DGATE=dg, B=B, C=C, HW=HW, PRO=2)
+    c = Case(12)
+    g = c.t("g", (B, C, HW))
+    out = c.t("out", (C,), "randn")
+    c.run("CHANNEL_SUM", ["out"], 1e-4, G=g, OUT=out, B=B, C=C, HW=HW)
+
+
+@pytest.mark.parametrize("B,C,Q", [(2, 48, 4), (3, 144, 6), (2, 3072, 128), (1, 1056, 44)])
+def test_se_fc_and_backward(B, C, Q):
+    c = Case(13)
+    pool = c.t("pool", (B, C), "rand")
+    w1, b1 = c.t("w1", (Q, C), scale=C ** -0.5), c.t("b1", (Q,))
+    w2, b2 = c.t("w2", (C, Q), scale=Q ** -0.5), c.t("b2", (C,))
+    hpre, gate = c.t("hpre", (B, Q), "nan"), c.t("gate", (B, C), "nan")
+    c.run("SE_FC", ["hpre", "gate"], 1e-5, POOL=pool, W1=w1, B1=b1, W2=w2, B2=b2, HPRE=hpre, GATE=gate, B=B, C=C, CSQ=Q)
+    c = Case(14)
+    dgate, gate = c.t("dgate", (B, C)), c.t("gate", (B, C), "rand")
+    hpre, pool = c.t("hpre", (B, Q)), c.t("pool", (B, C), "rand")
+    w1, w2 = c.t("w1", (Q, C), scale=C ** -0.5), c.t("w2", (C, Q), scale=Q ** -0.5)
+    dw1, db1, dw2, db2 = c.t("dw1", (Q, C)), c.t("db1", (Q,)), c.t("dw2", (C, Q)), c.t("db2", (C,))
+    dpool, hs = c.t("dpool", (B, C), "nan"), c.t("hs", (B, Q), "nan")
+    c.run("SE_FC_BWD", ["dw1", "db1", "dw2", "db2", "dpool"], 1e-4, DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=w1,
+          W2=w2, DW1=dw1, DB1=db1, DW2=dw2, DB2=db2, DPOOL=dpool, HS=hs, B=B, C=C, CSQ=Q)
+
+
+def test_axpy_memset():
+    c = Case(15)
+    x, y = c.t("x", (10007,)), c.t("y", (10007,))
+    c.run("AXPY", ["y"], 1e-7, X=x, Y=y, COUNT=10007)
+    c = Case(16)
+    z = c.t("z", (1000,))
+    c.run("MEMSET", ["z"], 1e-7, DST=z.at(16), BYTES=4 * 500)
+
+
+# ---------------------------------------------------------------------------------------------------
+# loss / argmax
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,ignore,gamma,smooth,alpha,rsum", [
+    (1, 0, 2.0, 0.0, False, 0), (1, 0, 0.5, 0.1, True, 0), (1, -100, 2.0, 0.0, False, 1),
+    (0, 0, 0.0, 0.0, False, 0), (0, 0, 0.0, 0.1, True, 0), (0, -100, 0.0, 0.0, False, 0)])
+def test_loss_fwd_bwd(mode, ignore, gamma, smooth, alpha, rsum):
+    B, C, HW = 2, 4, 33 * 17
+    c = Case(17)
+    lg = c.t("logits", (B, C, HW), scale=2.0)
+    lab = c.t("labels", (B, HW), torch.randint(0, C, (B, HW), generator=c.gen), "i64")
+    al = c.t("alpha", (C,), "pos") if alpha else None
+    acc = c.t("acc", (2,), "zeros", "f64")
+    loss = c.t("loss", (1,), "nan")
+    common = dict(B=B, C=C, HW=HW, MODE=mode, IGNORE=ignore, REDUCE_SUM=rsum, GAMMA=gamma, SMOOTH=smooth)
+    c.run("LOSS_FWD", ["loss"], 1e-5, LOGITS=lg, LABELS=lab, ALPHA=al, LOSS=loss, ACC=acc, **common)
+    # backward needs ACC[1] (the CE denominator): give it the true weight sum
+    c2 = Case(17)
+    lg = c2.t("logits", (B, C, HW), scale=2.0)
+    labels = torch.randint(0, C, (B, HW), generator=c2.gen)
+    lab = c2.t("labels", (B, HW), labels, "i64")
+    al = c2.t("alpha", (C,), "pos") if alpha else None
+    w = c2.items["alpha"][1] if alpha else torch.ones(C)
+    valid = labels != ignore
+    acc = c2.t("acc", (2,), torch.tensor([0.0, float(w[labels][valid].sum())], dtype=torch.float64), "f64")
+    gout = c2.t("gout", (1,), torch.tensor([1.7]))
+    dl = c2.t("dlogits", (B, C, HW), "nan")
+    c2.run("LOSS_BWD", ["dlogits"], 1e-4, LOGITS=lg, LABELS=lab, ALPHA=al, ACC=acc, GOUT=gout, DLOGITS=dl, **common)
+
+
+def test_argmax_first_max_wins():
+    c = Case(18)
+    B, C, HW = 2, 5, 777
+    lg = torch.randn(B, C, HW, generator=c.gen).round()  # many exact ties
+    lt = c.t("logits", (B, C, HW), lg)
+    mask = c.t("mask", (B, HW), torch.full((B, HW), -1), "i64")
+    c.run("ARGMAX", ["mask"], 1e-12, LOGITS=lt, MASK=mask, B=B, C=C, HW=HW)

@@ -1,0 +1,241 @@
+"""GPU parity of the whole EfficientNet-UNet hot path through the C ABI:
+  * stage-by-stage: every intermediate tensor of the planned forward/backward programs vs the CPU
+    emulation of the same program (pinpoints the first diverging stage);
+  * model level: logits / class masks / loss / gradients / running stats vs the golden fixtures
+    captured from the reference and vs the CPU oracle, at the reference-native 224x224x6 shape and
+    at the BASELINE shapes (13 bands 256x256, 4 bands 128x128).
+Bars: logits 1e-3 relative (BASELINE.json north_star); class masks identical wherever the oracle's
+top-2 margin exceeds fp32 noise; gradients judged against a float64 oracle relative to the fp32
+oracle's own error (see tests/test_plan_cpu.py for why)."""
+import numpy as np
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import detgen, losses_ref
+from oracle import efficientnet_unet_ref as R
+from s2lc_amd.plan import opdefs as D
+from tests.helpers import UNET_CASES, checks, load, rel_err, sub
+from tests.plan_harness import emulate, make_bases
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(version, C, ncls, seed, dcr=0.2):
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+    net = R.build(version, C, ncls, drop_connect_rate=dcr)
+    sd = detgen.fill_state(R.state_shapes(net), seed=seed)
+    model = EfficientnetUnet(EfficientNetConfig(version, C, ncls, class_distribution=[1.0 / ncls] * ncls, drop_connect_rate=dcr))
+    model.load_state_dict(sd)
+    return model, net, sd
+
+
+def _compare_tensors(plan, ws_gpu_bytes, bases_cpu, names, what):
+    ws_cpu = bases_cpu[D.BASE["WS"]]
+    bad = []
+    for name in names:
+        t = plan.tensors[name]
+        if t.dtype != "f32":
+            continue
+        a = ws_gpu_bytes[t.off:t.off + t.nbytes].view(torch.float32).double()
+        b = ws_cpu[t.off:t.off + t.nbytes].view(torch.float32).double()
+        if not torch.isfinite(b).all():
+            continue  # never written by this program (e.g. backward temporaries during forward)
+        denom = max(b.abs().max().item(), 1e-20)
+        err = ((a - b).abs().max().item() / denom) if torch.isfinite(a).all() else float("inf")
+        if err > 2e-3:
+            bad.append((name, err, denom))
+    assert not bad, f"{what}: first diverging tensors: {bad[:6]}"
+
+
+@pytest.mark.parametrize("version,C,H,B", [("b0", 6, 64, 2), ("b0", 4, 96, 1), ("b3", 13, 64, 2)])
+def test_programs_stage_by_stage_vs_emulator(version, C, H, B):
+    from s2lc_amd import _lib, engine
+
+    ncls = 4
+    model, net, sd = _model(version, C, ncls, seed=31)
+    x = detgen.normal("gpu.x", (B, C, H, H), seed=31)
+    y = detgen.labels("gpu.y", (B, H, H), ncls, seed=31)
+    noise = detgen.uniform("gpu.dc", (len(net.blocks), B), 0.0, 1.0, seed=31)
+    plan = model._make_plan(B, H, H, True)
+    bases_cpu = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H)
+    emulate(plan.fwd.pack(), bases_cpu)
+
+    dev = torch.device("cuda:0")
+    model.to(dev).train()
+    eng = engine.UnetEngine(model, B, H, H, True, dev)
+    eng.ws.view(torch.float32)[: eng.ws.numel() // 4].fill_(float("nan"))
+    out = torch.empty(B, ncls, H, H, device=dev)
+    xg, ng = x.to(dev), noise.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.run(eng.fwd, eng.bases(model, xg, out, noise=ng), st)
+    torch.cuda.synchronize()
+    fwd_names = [n for n in plan.tensors if not n.startswith(("g:", "gp:", "coef:", "dgate:", "dpool:", "hs:"))]
+    _compare_tensors(plan, eng.ws.cpu(), bases_cpu, fwd_names, "forward")
+    ref_logits = bases_cpu[D.BASE["OUT"]].view(torch.float32).view(B, ncls, H, H)
+    assert rel_err(out.cpu().numpy(), ref_logits.numpy()) < 1e-3
+    bufs_ref = bases_cpu[D.BASE["BUFS"]].view(torch.float32)
+    assert rel_err(model._flat_bufs.cpu().numpy(), bufs_ref.numpy()) < 1e-4
+
+    # backward from the same upstream gradient
+    lg = ref_logits.clone().requires_grad_(True)
+    loss = losses_ref.focal(lg, y, torch.ones(ncls), 2.0, 0.0, ignore_index=0)
+    (dlogits,) = torch.autograd.grad(loss, lg)
+    bases_cpu[D.BASE["DOUT"]].view(torch.float32).copy_(dlogits.reshape(-1))
+    # the emulator must continue from the GPU's forward state to isolate backward-stage errors
+    ws_after_fwd = eng.ws.cpu()
+    bases_cpu[D.BASE["WS"]][: ws_after_fwd.numel()].copy_(ws_after_fwd[: bases_cpu[D.BASE["WS"]].numel()])
+    bases_cpu[D.BASE["AUX"]][: eng.aux.numel()].copy_(eng.aux.cpu()[: bases_cpu[D.BASE["AUX"]].numel()])
+    emulate(plan.bwd.pack(), bases_cpu)
+    grads = torch.zeros_like(model._flat_params)
+    _lib.run(eng.bwd, eng.bases(model, xg, None, dout=dlogits.to(dev), noise=ng, grads=grads), st)
+    torch.cuda.synchronize()
+    bwd_names = [n for n in plan.tensors if n.startswith(("g:", "gp:", "coef:", "dpool:"))]
+    _compare_tensors(plan, eng.ws.cpu(), bases_cpu, bwd_names, "backward")
+    gref = bases_cpu[D.BASE["GRADS"]].view(torch.float32)
+    scale = gref.abs().max().item()
+    worst = []
+    for name, (off, shape) in plan.layout.params.items():
+        n = int(np.prod(shape))
+        a, b = grads[off:off + n].cpu().double(), gref[off:off + n].double()
+        if b.abs().max().item() < 1e-7 * scale:
+            assert a.abs().max().item() < 1e-5 * scale, name
+            continue
+        e = (a - b).abs().max().item() / b.abs().max().item()
+        if e > 2e-3:
+            worst.append((name, e))
+    assert not worst, worst[:8]
+
+
+def _run_case(tag):
+    from s2lc_amd.losses import CrossEntropyLoss, FocalLoss, class_mask
+
+    version, C, H, B, ncls, train, seed = UNET_CASES[tag]
+    model, net, sd = _model(version, C, ncls, seed)
+    x = detgen.normal(f"{tag}.x", (B, C, H, H), seed=seed)
+    y = detgen.labels(f"{tag}.y", (B, H, H), ncls, seed=seed)
+    noise = detgen.uniform(f"{tag}.dc", (len(net.blocks), B), 0.0, 1.0, seed=seed)
+    dev = torch.device("cuda:0")
+    model.to(dev)
+    model.train(train)
+    model.drop_connect_noise = noise if train else None
+    xg, yg = x.to(dev), y.to(dev)
+    if train:
+        logits = model(xg)
+    else:
+        with torch.no_grad():
+            logits = model(xg)
+    fl = FocalLoss(torch.ones(ncls), 2.0, 0.0, ignore_index=0)(logits, yg)
+    ce = CrossEntropyLoss(ignore_index=0)(logits.detach(), yg)
+    mask = class_mask(logits.detach())
+    return model, net, sd, x, y, noise, logits, fl, ce, mask
+
+
+def _check_masks(mask_gpu, logits_ref, mask_golden):
+    """bit-exact class masks, except where the reference's own top-2 margin is inside fp32 noise."""
+    m = mask_gpu.cpu().to(torch.uint8).numpy()
+    if np.array_equal(m, mask_golden):
+        return
+    top2 = logits_ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    diff = m != mask_golden
+    assert diff.mean() < 1e-3 and margin[diff].max() < 1e-4 * max(1.0, float(logits_ref.abs().max())), \
+        f"{diff.sum()} mask mismatches, max margin at mismatch {margin[diff].max()}"
+
+
+@pytest.mark.parametrize("tag", [t for t, v in UNET_CASES.items() if not v[5]])
+def test_eval_matches_reference_golden(tag):
+    g = load(f"unet_{tag}.npz")
+    model, net, sd, x, y, noise, logits, fl, ce, mask = _run_case(tag)
+    with torch.no_grad():
+        ref = R.unet_forward(sd, net, x, training=False)
+    lc = logits.float().cpu()
+    assert rel_err(sub(lc, 4096), g["logits_sub"]) < 1e-3          # vs the reference (subsample)
+    assert rel_err(lc.numpy(), ref.numpy()) < 1e-3                  # vs the oracle (every element)
+    assert abs(checks(lc)[1] - g["logits_ck"][1]) / g["logits_ck"][1] < 1e-4
+    _check_masks(mask, ref, g["mask"])
+    assert abs(fl.item() - g["loss_focal"][0]) < 1e-4 * abs(g["loss_focal"][0])
+    assert abs(ce.item() - g["loss_ce"][0]) < 1e-4 * abs(g["loss_ce"][0])
+
+
+@pytest.mark.parametrize("tag", [t for t, v in UNET_CASES.items() if v[5]])
+def test_train_step_matches_reference_golden(tag):
+    from tests.test_plan_cpu import oracle_grads
+
+    g = load(f"unet_{tag}.npz")
+    model, net, sd, x, y, noise, logits, fl, ce, mask = _run_case(tag)
+    version, C, H, B, ncls, train, seed = UNET_CASES[tag]
+    nbt_before = int(sd["encoder.stem.1.num_batches_tracked"])
+    fl.backward()
+    torch.cuda.synchronize()
+    lc = logits.detach().cpu()
+    assert rel_err(sub(lc, 4096), g["logits_sub"]) < 1e-3
+    assert abs(fl.item() - g["loss_focal"][0]) < 1e-4 * abs(g["loss_focal"][0])
+    assert abs(ce.item() - g["loss_ce"][0]) < 1e-4 * abs(g["loss_ce"][0])
+    sd64, logits64, _, newbuf64 = oracle_grads(net, sd, x, y, noise, ncls, torch.float64)
+    sd32, _, _, _ = oracle_grads(net, sd, x, y, noise, ncls, torch.float32)
+    assert rel_err(lc.numpy(), logits64.numpy()) < 1e-3
+    _check_masks(mask, logits64.float(), g["mask"])
+    named = dict(model.named_parameters())
+    scale = max(v.grad.abs().max().item() for v in sd64.values() if v.requires_grad and v.grad is not None)
+    e_gpu, e_or = [], []
+    for name, p in named.items():
+        ref = sd64[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        if ref.abs().max().item() < 1e-9 * scale:
+            assert p.grad.abs().max().item() <= 1e-6 * scale, name
+            continue
+        e_gpu.append(rel_err(p.grad.cpu().numpy(), ref.numpy()))
+        e_or.append(rel_err(sd32[name].grad.numpy(), ref.numpy()))
+    e_gpu, e_or = np.array(e_gpu), np.array(e_or)
+    assert np.median(e_gpu) < 3 * np.median(e_or) + 1e-4, (np.median(e_gpu), np.median(e_or))
+    assert e_gpu.max() < 5 * e_or.max() + 1e-3, (e_gpu.max(), e_or.max())
+    # golden gradient subsamples straight from the reference, same noise-aware bar
+    for key in g.files:
+        if key.startswith("grad:"):
+            name = key[5:]
+            e = rel_err(sub(named[name].grad, 512), g[key])
+            assert e < 5 * e_or.max() + 1e-3, (name, e)
+    new_sd = model.state_dict()
+    for key in g.files:
+        if key.startswith("rm:"):
+            assert rel_err(new_sd[key[3:] + ".running_mean"].cpu().numpy(), g[key]) < 1e-4, key
+        if key.startswith("rv:"):
+            assert rel_err(new_sd[key[3:] + ".running_var"].cpu().numpy(), g[key]) < 1e-4, key
+        if key.startswith("nbt:"):
+            assert int(new_sd[key[4:] + ".num_batches_tracked"]) == int(g[key][0]) == nbt_before + 1
+
+
+def test_gradient_accumulation_and_zero_grad_semantics():
+    from s2lc_amd.losses import FocalLoss
+
+    model, net, sd = _model("b0", 4, 4, seed=41)
+    dev = torch.device("cuda:0")
+    model.to(dev).train()
+    x = detgen.normal("acc.x", (2, 4, 64, 64), seed=41).to(dev)
+    y = detgen.labels("acc.y", (2, 64, 64), 4, seed=41).to(dev)
+    model.drop_connect_noise = detgen.uniform("acc.dc", (len(net.blocks), 2), 0, 1, seed=41)
+    loss_fn = FocalLoss(torch.ones(4), 2.0, 0.0, ignore_index=0)
+    bufs0 = model._flat_bufs.clone()
+    loss_fn(model(x), y).backward()
+    g1 = model.out_conv1x1.weight.grad.clone()
+    w1 = model.encoder.stem[0].weight.grad.clone()
+    model._flat_bufs.copy_(bufs0)  # same BN running state is irrelevant to grads, but keep the step identical
+    loss_fn(model(x), y).backward()  # second backward without zero_grad: gradients accumulate
+    assert torch.allclose(model.out_conv1x1.weight.grad, 2 * g1, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(model.encoder.stem[0].weight.grad, 2 * w1, rtol=2e-3, atol=1e-6)
+    for p in model.parameters():
+        p.grad = None
+    loss_fn(model(x), y).backward()
+    assert torch.allclose(model.out_conv1x1.weight.grad, g1, rtol=1e-4, atol=1e-7)
+    assert model.encoder.fc[3].weight.grad is None
+    # torch.optim.Adam steps the views in place (reference configure_optimizers)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.05)
+    before = model._flat_params.clone()
+    opt.step()
+    assert not torch.equal(before, model._flat_params)
+    assert model.out_conv1x1.weight.data_ptr() >= model._flat_params.data_ptr()
