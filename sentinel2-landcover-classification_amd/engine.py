@@ -80,7 +80,9 @@ class _UnetFunction(torch.autograd.Function):
         module, eng = ctx.module, ctx.eng
         (x,) = ctx.saved_tensors
         dout = dout.contiguous()
-        accumulate = module._grads_live()
+        live = module._grads_live()
+        accumulate = live and not getattr(module, "_overwrite_next", False)
+        module._overwrite_next = False
         grads = module._grad_buffer() if not accumulate else module._grad_scratch()
         grads.zero_()
         bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads)
@@ -94,7 +96,8 @@ class _UnetFunction(torch.autograd.Function):
                 hook(lo, grads)
         if accumulate:
             module._grad_buffer().add_(grads)
-        module._publish_grads(module._no_grad_params)
+        if not live:
+            module._publish_grads(module._no_grad_params)
         return None, None, None, None, None
 
 
