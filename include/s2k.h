@@ -68,6 +68,10 @@ int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream
 int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
                         float* ms_by_kind, int* launches_by_kind);
 
+/* same, one entry per stage: ms_per_op[end - begin] */
+int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
+                            float* ms_per_op);
+
 /* fused Adam step (L2-coupled decay, train_segmentation.py:109-127): p, g, m, v flat fp32 [n]. */
 int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, void* stream);

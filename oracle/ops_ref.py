@@ -135,7 +135,7 @@ def op_conv(m: Mem, o):
             y = y + bias.view(1, -1, 1, 1)
         dst = m.view(o["Y"], (B, M, Ho, Wo), strides=(YC * Ho * Wo, Ho * Wo, Wo, 1))
     if o["STATS"] >= 0:
-        st = m.view(o["STATS"], (2, M), "f64")
+        st = m.view(o["STATS"], (max(o["NREP"], 1), 2, M), "f64")[0]   # any replica: finalize sums them all
         st[0] += y.double().sum((0, 2, 3))
         st[1] += (y.double() ** 2).sum((0, 2, 3))
     if o["BETA"]:
@@ -179,7 +179,7 @@ def op_dwconv_fwd(m: Mem, o):
     y = F.conv2d(_pad_to(x, pt, pl, K, K, S, Ho, Wo), w, None, S, 0, 1, C)
     m.view(o["Y"], (B, C, Ho, Wo)).copy_(y)
     if o["STATS"] >= 0:
-        st = m.view(o["STATS"], (2, C), "f64")
+        st = m.view(o["STATS"], (max(o["NREP"], 1), 2, C), "f64")[-1]
         st[0] += y.double().sum((0, 2, 3))
         st[1] += (y.double() ** 2).sum((0, 2, 3))
 
@@ -198,7 +198,7 @@ def op_dwconv_dgrad(m: Mem, o):
         gx = gx * _act_grad(u, o["PRO"])
         if o["STATS2"] >= 0:
             xhat = (xr - bnv[2].view(1, C, 1, 1)) * bnv[3].view(1, C, 1, 1)
-            st = m.view(o["STATS2"], (2, C), "f64")
+            st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64")[0]
             st[0] += gx.double().sum((0, 2, 3))
             st[1] += (gx.double() * xhat.double()).sum((0, 2, 3))
     g = m.view(o["G"], (B, C, H, W))
@@ -225,7 +225,7 @@ def op_bn_finalize(m: Mem, o):
     bnv = m.view(o["BNV"], (4, C))
     if o["TRAIN"]:
         n = float(o["COUNT"])
-        st = m.view(o["STATS"], (2, C), "f64")
+        st = m.view(o["STATS"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
         mean = st[0] / n
         var = (st[1] / n - mean * mean).clamp_min(0.0)
         invstd = 1.0 / torch.sqrt(var + float(np.float32(o["EPS"])))
@@ -303,7 +303,7 @@ def op_bn_bwd_reduce(m: Mem, o):
     u = y * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)
     g = g * _act_grad(u, act)
     xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
-    st = m.view(o["STATS2"], (2, C), "f64")
+    st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64")[0]
     st[0] += g.double().sum((0, 2))
     st[1] += (g.double() * xhat.double()).sum((0, 2))
     m.view(o["GOUT"], (B, C, HW)).copy_(g)
@@ -311,7 +311,7 @@ def op_bn_bwd_reduce(m: Mem, o):
 
 def op_bn_bwd_finalize(m: Mem, o):
     C, n = o["C"], float(o["COUNT"])
-    st = m.view(o["STATS2"], (2, C), "f64")
+    st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
     gamma, bnv = m.view(o["GAMMA"], (C,)), m.view(o["BNV"], (4, C))
     m.view(o["DGAMMA"], (C,)).add_(st[1].to(m.fdtype))
     m.view(o["DBETA"], (C,)).add_(st[0].to(m.fdtype))

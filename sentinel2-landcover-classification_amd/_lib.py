@@ -41,6 +41,8 @@ def lib() -> ctypes.CDLL:
     L.s2k_op_launch.argtypes = [vp, vp, i32, vp]
     L.s2k_program_profile.restype = i32
     L.s2k_program_profile.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp]
+    L.s2k_program_profile_ops.restype = i32
+    L.s2k_program_profile_ops.argtypes = [vp, i32, i32, vp, i32, vp, vp]
     f32 = ctypes.c_float
     L.s2k_adam_step.restype = i32
     L.s2k_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, vp]
@@ -93,3 +95,10 @@ def profile(packed: np.ndarray, bases: Bases, stream: int):
                                     ms.ctypes.data, cnt.ctypes.data))
     names = {v: k for k, v in D.KIND.items()}
     return {names[k]: (float(ms[k]), int(cnt[k])) for k in range(1, nk) if cnt[k]}
+
+
+def profile_ops(packed: np.ndarray, bases: Bases, stream: int) -> np.ndarray:
+    """Per-stage device milliseconds (HIP events on the launch stream)."""
+    ms = np.zeros(len(packed), dtype=np.float32)
+    check(lib().s2k_program_profile_ops(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream, ms.ctypes.data))
+    return ms

@@ -20,7 +20,7 @@ struct DwP {
     const float* dy;     // dgrad/wgrad
     float* out;          // fwd: Y; dgrad: G; wgrad: DW (atomics)
     double* stats;       // fwd: [2][C] sum/sumsq of Y;  dgrad: [2][C] sum g, sum g*xhat
-    int B, C, H, W, K, S, PT, PL, HO, WO, pro, beta;
+    int B, C, H, W, K, S, PT, PL, HO, WO, pro, beta, nrep;
     int PPB, RT, bands, IRt, ICt, LW;   // tiling
 };
 
@@ -65,30 +65,44 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
 
     const int n_out = rows * p.WO;
     const int chunks_per_plane = (n_out + 63) >> 6;
-    for (int ch = wave; ch < p.PPB * chunks_per_plane; ch += 4) {
-        const int pl = ch / chunks_per_plane;
+    // waves own whole planes when there are >= 4 of them, else they split one plane's chunks; either
+    // way a wave keeps its running sums in registers and issues ONE atomic pair per plane it touched
+    const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
+    double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
+    for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
         const int64_t plane = pl0 + pl;
         if (plane >= nplanes) break;
-        const int o = (ch - pl * chunks_per_plane) * 64 + lane;
         float s = 0.0f, q = 0.0f;
-        if (o < n_out) {
-            const int r = o / p.WO, xo = o - r * p.WO;
-            const float* t0 = tile + pl * per_plane + (r * p.S) * p.LW + xo * p.S;
-            const float* wk = wsm + pl * K2;
-            float acc = 0.0f;
-            for (int ky = 0; ky < p.K; ++ky)
-                for (int kx = 0; kx < p.K; ++kx) acc = fmaf(wk[ky * p.K + kx], t0[ky * p.LW + kx], acc);
-            p.out[plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo] = acc;
-            s = acc;
-            q = acc * acc;
+        const float* wk = wsm + pl * K2;
+        for (int chn = wave % wpp; chn < chunks_per_plane; chn += wpp) {
+            const int o = chn * 64 + lane;
+            if (o < n_out) {
+                const int r = o / p.WO, xo = o - r * p.WO;
+                const float* t0 = tile + pl * per_plane + (r * p.S) * p.LW + xo * p.S;
+                float acc = 0.0f;
+                if (p.K == 3) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(wk[ky * 3 + kx], t0[ky * p.LW + kx], acc);
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) acc = fmaf(wk[ky * 5 + kx], t0[ky * p.LW + kx], acc);
+                }
+                p.out[plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo] = acc;
+                s += acc;
+                q = fmaf(acc, acc, q);
+            }
         }
-        if (p.stats) {
+        if (st) {
             s = wave_sum(s);
             q = wave_sum(q);
             if (lane == 0) {
                 const int c = (int)(plane % p.C);
-                atomic_add_d(p.stats + c, (double)s);
-                atomic_add_d(p.stats + p.C + c, (double)q);
+                atomic_add_d(st + c, (double)s);
+                atomic_add_d(st + p.C + c, (double)q);
             }
         }
     }
@@ -197,50 +211,54 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_kernel(const DwP p) {
     __syncthreads();
     const int n_in = rows * p.W;
     const int chunks_per_plane = (n_in + 63) >> 6;
-    for (int ch = wave; ch < p.PPB * chunks_per_plane; ch += 4) {
-        const int pl = ch / chunks_per_plane;
+    const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
+    double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
+    for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
         const int64_t plane = pl0 + pl;
         if (plane >= nplanes) break;
-        const int o = (ch - pl * chunks_per_plane) * 64 + lane;
         const int c = (int)(plane % p.C);
         float s1 = 0.0f, s2 = 0.0f;
-        if (o < n_in) {
-            const int r = o / p.W, ix = o - r * p.W;
-            const int iy = iy0 + r;
-            const float* tp = tile + pl * per_plane;
-            const float* wk = wsm + pl * K2;
-            float acc = 0.0f;
-            for (int ky = 0; ky < p.K; ++ky) {
-                const int ty = iy + p.PT - ky;
-                if (ty < 0) continue;
-                const int yo = (p.S == 1) ? ty : (ty >> 1);
-                if ((p.S == 2 && (ty & 1)) || yo >= p.HO) continue;
-                const int rr = yo - yo_lo;   // >= 0 by construction of yo_lo
-                for (int kx = 0; kx < p.K; ++kx) {
-                    const int tx = ix + p.PL - kx;
-                    if (tx < 0) continue;
-                    const int xo = (p.S == 1) ? tx : (tx >> 1);
-                    if ((p.S == 2 && (tx & 1)) || xo >= p.WO) continue;
-                    acc = fmaf(wk[ky * p.K + kx], tp[rr * p.LW + xo], acc);
+        float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
+        if (p.pro != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
+        const float* tp = tile + pl * per_plane;
+        const float* wk = wsm + pl * K2;
+        for (int chn = wave % wpp; chn < chunks_per_plane; chn += wpp) {
+            const int o = chn * 64 + lane;
+            if (o < n_in) {
+                const int r = o / p.W, ix = o - r * p.W;
+                const int iy = iy0 + r;
+                float acc = 0.0f;
+                for (int ky = 0; ky < p.K; ++ky) {
+                    const int ty = iy + p.PT - ky;
+                    if (ty < 0) continue;
+                    const int yo = (p.S == 1) ? ty : (ty >> 1);
+                    if ((p.S == 2 && (ty & 1)) || yo >= p.HO) continue;
+                    const int rr = yo - yo_lo;   // >= 0 by construction of yo_lo
+                    for (int kx = 0; kx < p.K; ++kx) {
+                        const int tx = ix + p.PL - kx;
+                        if (tx < 0) continue;
+                        const int xo = (p.S == 1) ? tx : (tx >> 1);
+                        if ((p.S == 2 && (tx & 1)) || xo >= p.WO) continue;
+                        acc = fmaf(wk[ky * p.K + kx], tp[rr * p.LW + xo], acc);
+                    }
                 }
+                const int64_t off = plane * p.H * p.W + (int64_t)iy * p.W + ix;
+                if (p.pro != S2K_PRO_NONE) {
+                    const float xr = p.x[off];
+                    acc *= act_grad(fmaf(xr, scale, shift), p.pro);
+                    s1 += acc;
+                    s2 = fmaf(acc, (xr - mean) * invstd, s2);
+                }
+                if (p.beta) acc += p.out[off];
+                p.out[off] = acc;
             }
-            const int64_t off = plane * p.H * p.W + (int64_t)iy * p.W + ix;
-            if (p.pro != S2K_PRO_NONE) {
-                const float xr = p.x[off];
-                const float u = fmaf(xr, p.bnv[c], p.bnv[p.C + c]);
-                acc *= act_grad(u, p.pro);
-                s1 = acc;
-                s2 = acc * ((xr - p.bnv[2 * p.C + c]) * p.bnv[3 * p.C + c]);
-            }
-            if (p.beta) acc += p.out[off];
-            p.out[off] = acc;
         }
-        if (p.stats) {
+        if (st) {
             s1 = wave_sum(s1);
             s2 = wave_sum(s2);
             if (lane == 0) {
-                atomic_add_d(p.stats + c, (double)s1);
-                atomic_add_d(p.stats + p.C + c, (double)s2);
+                atomic_add_d(st + c, (double)s1);
+                atomic_add_d(st + p.C + c, (double)s2);
             }
         }
     }
@@ -260,7 +278,7 @@ static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
 
 static int fill_geo(DwP& p, const int32_t* d) {
     p.B = d[0]; p.C = d[1]; p.H = d[2]; p.W = d[3]; p.K = d[4]; p.S = d[5]; p.PT = d[6]; p.PL = d[7];
-    p.HO = d[8]; p.WO = d[9]; p.pro = d[10];
+    p.HO = d[8]; p.WO = d[9]; p.pro = d[10]; p.nrep = 1;
     if (p.B <= 0 || p.C <= 0 || p.H <= 0 || p.W <= 0 || (p.K != 3 && p.K != 5) || (p.S != 1 && p.S != 2)) {
         set_error("dwconv: unsupported geometry K=%d S=%d", p.K, p.S);
         return S2K_EINVAL;
@@ -289,6 +307,7 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     p.w = ref_ptr<const float>(c, op.t[S2K_DWCONV_FWD_T_WT]);
     p.out = ref_ptr<float>(c, op.t[S2K_DWCONV_FWD_T_Y]);
     p.stats = ref_ptr<double>(c, op.t[S2K_DWCONV_FWD_T_STATS]);
+    if (op.d[S2K_DWCONV_FWD_D_NREP] > 0) p.nrep = op.d[S2K_DWCONV_FWD_D_NREP];
     if (bad(p.x) || bad(p.bnv) || bad(p.w) || bad(p.out) || bad(p.stats)) { set_error("dwconv_fwd: null base"); return S2K_EFAULT; }
     if (!p.x || !p.w || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_fwd: missing tensor"); return S2K_EINVAL; }
     const size_t lds = tile_out(p, true);
@@ -318,6 +337,7 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
     DwP p{};
     if (int e = fill_geo(p, op.d)) return e;
     p.beta = op.d[S2K_DWCONV_DGRAD_D_BETA];
+    if (op.d[S2K_DWCONV_DGRAD_D_NREP] > 0) p.nrep = op.d[S2K_DWCONV_DGRAD_D_NREP];
     p.dy = ref_ptr<const float>(c, op.t[S2K_DWCONV_DGRAD_T_DY]);
     p.w = ref_ptr<const float>(c, op.t[S2K_DWCONV_DGRAD_T_WT]);
     p.x = ref_ptr<const float>(c, op.t[S2K_DWCONV_DGRAD_T_XRAW]);

@@ -109,13 +109,15 @@ int launch_wgrad_finalize(const S2kOp& op, const Ctx& c) {
 
 // ---------------- BN_FINALIZE ----------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const double* stats, const float* gamma, const float* beta, float* rm, float* rv,
-                                   float* bnv, int C, int train, double count, float eps, float mom) {
+                                   float* bnv, int C, int train, double count, float eps, float mom, int nrep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float mean, invstd;
     if (train) {
-        const double m = stats[c] / count;
-        double var = stats[C + c] / count - m * m;
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < nrep; ++r) { s += stats[(int64_t)r * 2 * C + c]; q += stats[(int64_t)r * 2 * C + C + c]; }
+        const double m = s / count;
+        double var = q / count - m * m;
         if (var < 0.0) var = 0.0;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
         mean = (float)m;
@@ -144,7 +146,8 @@ int launch_bn_finalize(const S2kOp& op, const Ctx& c) {
     const int C = op.d[S2K_BN_FINALIZE_D_C], train = op.d[S2K_BN_FINALIZE_D_TRAIN];
     if (!gamma || !beta || !rm || !rv || !bnv || C <= 0 || (train && !stats)) { set_error("bn_finalize: bad args"); return S2K_EINVAL; }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, stats, gamma, beta, rm, rv, bnv, C,
-                       train, (double)op.n[S2K_BN_FINALIZE_N_COUNT], op.f[S2K_BN_FINALIZE_F_EPS], op.f[S2K_BN_FINALIZE_F_MOM]);
+                       train, (double)op.n[S2K_BN_FINALIZE_N_COUNT], op.f[S2K_BN_FINALIZE_F_EPS], op.f[S2K_BN_FINALIZE_F_MOM],
+                       op.d[S2K_BN_FINALIZE_D_NREP] > 0 ? op.d[S2K_BN_FINALIZE_D_NREP] : 1);
     return S2K_OK;
 }
 
@@ -393,7 +396,7 @@ template <bool VEC>
 __global__ void __launch_bounds__(NTHREADS) bn_bwd_reduce_kernel(const float* g, const float* y, const float* bnv,
                                                                  const float* mulbc, const float* addbc, const float* noise,
                                                                  float* gout, double* stats2, int C, int HW, int64_t nplanes,
-                                                                 int act, float keep, float addscale) {
+                                                                 int act, float keep, float addscale, int nrep) {
     Task t;
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
@@ -435,8 +438,9 @@ __global__ void __launch_bounds__(NTHREADS) bn_bwd_reduce_kernel(const float* g,
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) {
-        atomic_add_d(stats2 + c, (double)s1);
-        atomic_add_d(stats2 + C + c, (double)s2);
+        double* st = stats2 + (int64_t)(blockIdx.x % nrep) * 2 * C;
+        atomic_add_d(st + c, (double)s1);
+        atomic_add_d(st + C + c, (double)s2);
     }
 }
 
@@ -456,20 +460,22 @@ int launch_bn_bwd_reduce(const S2kOp& op, const Ctx& c) {
     const unsigned blocks = task_blocks(HW, nplanes);
     const int act = op.d[S2K_BN_BWD_REDUCE_D_ACT];
     const float keep = op.f[S2K_BN_BWD_REDUCE_F_KEEP], addscale = op.f[S2K_BN_BWD_REDUCE_F_ADDSCALE];
+    const int nrep = op.d[S2K_BN_BWD_REDUCE_D_NREP] > 0 ? op.d[S2K_BN_BWD_REDUCE_D_NREP] : 1;
     if ((HW & 3) == 0)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, mulbc, addbc, noise,
-                           gout, st2, C, HW, nplanes, act, keep, addscale);
+                           gout, st2, C, HW, nplanes, act, keep, addscale, nrep);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, mulbc, addbc, noise,
-                           gout, st2, C, HW, nplanes, act, keep, addscale);
+                           gout, st2, C, HW, nplanes, act, keep, addscale, nrep);
     return S2K_OK;
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* st2, const float* gamma, const float* bnv, float* dgamma, float* dbeta,
-                                       float* coef, int C, double count) {
+                                       float* coef, int C, double count, int nrep) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double s1 = st2[c], s2 = st2[C + c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrep; ++r) { s1 += st2[(int64_t)r * 2 * C + c]; s2 += st2[(int64_t)r * 2 * C + C + c]; }
     dgamma[c] += (float)s2;
     dbeta[c] += (float)s1;
     const double a = (double)gamma[c] * (double)bnv[3 * C + c];
@@ -489,7 +495,7 @@ int launch_bn_bwd_finalize(const S2kOp& op, const Ctx& c) {
     const int C = op.d[S2K_BN_BWD_FINALIZE_D_C];
     if (!st2 || !gamma || !bnv || !dgamma || !dbeta || !coef || C <= 0) { set_error("bn_bwd_finalize: bad args"); return S2K_EINVAL; }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, st2, gamma, bnv, dgamma, dbeta, coef, C,
-                       (double)op.n[S2K_BN_BWD_FINALIZE_N_COUNT]);
+                       (double)op.n[S2K_BN_BWD_FINALIZE_N_COUNT], op.d[S2K_BN_BWD_FINALIZE_D_NREP] > 0 ? op.d[S2K_BN_BWD_FINALIZE_D_NREP] : 1);
     return S2K_OK;
 }
 

@@ -13,12 +13,15 @@
 // LDS: As[k][m] (row stride BM+1) and Bs[k][pixels]; with pixels on the lanes every ds_read_b32
 // is 32 consecutive words per half-wave (conflict-free), and the im2col of a KxK conv is just a
 // per-tap constant added to the per-lane pixel offset inside a halo tile.
+//
+// Pipeline: the operands of K-chunk i+1 are fetched global->registers *before* the MFMAs of chunk
+// i are issued and written to LDS after them (one LDS buffer, two barriers per chunk), so HBM/L2
+// latency hides under 64..288 MFMAs per wave; all index arithmetic of the stagers is incremental
+// or compile-time (no runtime divisions in the K loop).  Workgroup ids are remapped so that the
+// m-tiles sharing one activation tile run on the same XCD (shared L2).
 #include "common.h"
 
 namespace s2k {
-
-constexpr int KC = 8;        // input channels per K chunk
-constexpr int EPT_MAX = 5;   // halo-tile elements per thread per channel (<= 1280 floats / channel)
 
 enum { BM_PIX = 0, BM_SPATIAL = 1 };
 
@@ -27,43 +30,41 @@ struct ConvP {
     float* y;
     double* stats;
     int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
-    int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC;
-    int T, KT, Ctot, n_mtiles, HW, Ntot, a_mfast, a_floats;
+    int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC, nrep;
+    int Ctot, n_mtiles, n_tiles, HW, Ntot, a_mfast;
     int R, XW, tiles_x, tiles_y, IR, IC, WS, CS;
 };
 
-__device__ __forceinline__ float load_src(const ConvP& p, int c, int64_t off1, int64_t off2, int64_t cstride,
-                                          int gate_row) {
-    // value of concat channel c at the element whose within-plane offsets are off1/off2
-    if (c < p.C1) {
-        float v = p.x1[off1 + (int64_t)c * cstride];
-        if (p.pro1 != S2K_PRO_NONE) v = apply_pro(v, p.pro1, p.bnv1[c], p.bnv1[p.C1 + c]);
-        if (p.gate1) v *= p.gate1[gate_row + c];
-        return v;
-    }
-    const int c2 = c - p.C1;
-    float v = p.x2[off2 + (int64_t)c2 * cstride];
-    if (p.pro2 != S2K_PRO_NONE) v = apply_pro(v, p.pro2, p.bnv2[c2], p.bnv2[p.C2 + c2]);
-    return v;
+// bijective remap: consecutive logical tiles land on the same XCD (hardware deals blocks round-robin
+// over the 8 XCDs; which XCD is irrelevant, only that ids congruent mod 8 share one)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BMODE, int WM, int WN, int WVM, int WVN>
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT>
 __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BN = WN * WVN * 32;
     constexpr int AS = BM + 1;
+    constexpr int KT = KCH * TT;
+    constexpr int NA = KT * BM / NTHREADS;                                   // A elements per thread per chunk
+    constexpr int NB = (BMODE == BM_PIX) ? KCH * BN / NTHREADS : KCH * EPT;  // B elements per thread per chunk
+    constexpr int A_FLOATS = (KT * AS + 3) & ~3;
     static_assert(WVM * WVN == 4, "4 waves per workgroup");
+    static_assert((KT * BM) % NTHREADS == 0 && NA >= 1, "A tile must split evenly");
+    static_assert(BMODE != BM_PIX || (NTHREADS % BN == 0 || BN % NTHREADS == 0), "pixel tile vs threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
-    float* Bs = smem + p.a_floats;
+    float* Bs = smem + A_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WVN) * (WM * 32);
     const int wn0 = (wave % WVN) * (WN * 32);
-    const int mt = blockIdx.x % p.n_mtiles;
-    const int nt = blockIdx.x / p.n_mtiles;
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int mt = tile % p.n_mtiles;
+    const int nt = tile / p.n_mtiles;
     const int m0 = mt * BM;
-    const int T = p.T, KT = p.KT;
     const bool gather = (p.mode == S2K_MODE_GATHER2X2);
     const bool scatter = (p.mode == S2K_MODE_CONVT_SCATTER);
     const int HWo = p.HO * p.WO;
@@ -72,13 +73,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
     int boff[WN];
     bool cval[WN];
     int64_t ycol[WN];
-    // ---- stager bookkeeping -----------------------------------------------------------------
-    // PIX: one pixel per thread;  SPATIAL: up to EPT_MAX halo elements per thread
-    int sp_goff[EPT_MAX];
+    // ---- B stager bookkeeping ---------------------------------------------------------------
+    int sp_goff[(BMODE == BM_SPATIAL) ? EPT : 1];
     int64_t st_off1 = 0, st_off2 = 0, st_cstride = 0;
     int st_gate = 0;
     bool st_valid = false;
-    int sb = 0;  // SPATIAL: image index of this tile
 
     if (BMODE == BM_PIX) {
         const int n0 = nt * BN;
@@ -103,7 +102,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
         const int nn = st_valid ? n : 0;
         const int b = nn / p.HW, pp = nn - b * p.HW;
         st_gate = b * p.C1;
-        if (gather) {  // X1 is [B][C1/4][2H][2W]; pseudo-channel k=(co,dy,dx) handled in the chunk loop
+        if (gather) {  // X1 is [B][C1/4][2H][2W]; pseudo-channel k=(co,dy,dx)
             const int yy = pp / p.W, xx = pp - yy * p.W;
             st_off1 = (int64_t)b * (p.C1 / 4) * 4 * p.HW + (int64_t)(2 * yy) * (2 * p.W) + 2 * xx;
         } else {
@@ -114,7 +113,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
     } else {
         const int tx = nt % p.tiles_x;
         const int ty = (nt / p.tiles_x) % p.tiles_y;
-        sb = nt / (p.tiles_x * p.tiles_y);
+        const int sb = nt / (p.tiles_x * p.tiles_y);
         const int y0 = ty * p.R, x0 = tx * p.XW;
 #pragma unroll
         for (int rn = 0; rn < WN; ++rn) {
@@ -127,7 +126,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
         const int iy0 = y0 * p.S - p.PT, ix0 = x0 * p.S - p.PL;
         const int used = p.IR * p.WS;
 #pragma unroll
-        for (int i = 0; i < EPT_MAX; ++i) {
+        for (int i = 0; i < EPT; ++i) {
             const int e = tid + NTHREADS * i;
             int g = -1;
             if (e < used) {
@@ -135,7 +134,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
                 const int iy = iy0 + rr, ix = ix0 + cc;
                 if (cc < p.IC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) g = iy * p.W + ix;
             }
-            sp_goff[i] = g;
+            sp_goff[(BMODE == BM_SPATIAL) ? i : 0] = g;
         }
         st_off1 = (int64_t)sb * p.C1 * p.H * p.W;
         st_off2 = (int64_t)sb * p.C2 * p.H * p.W;
@@ -152,85 +151,152 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int CSB = (BMODE == BM_PIX) ? BN : p.CS;
-    const int nchunks = (p.Ctot + KC - 1) / KC;
+    const int nchunks = (p.Ctot + KCH - 1) / KCH;
+    const int used_sp = p.IR * p.WS;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * KC;
-        __syncthreads();  // all MFMA reads of the previous chunk are done
-        // ---------------- A tile: As[kk][m] = Wv[m0+m][c0 + kk/T][kk%T] ------------------------
-        {
-            const int total = KT * BM;
-            if (p.a_mfast) {
-                for (int idx = tid; idx < total; idx += NTHREADS) {
-                    const int m = idx % BM, kk = idx / BM;
-                    const int kc = (T == 1) ? kk : ((T == 9) ? kk / 9 : kk / T);
-                    const int tap = kk - kc * T;
-                    const int gm = m0 + m, c = c0 + kc;
-                    float v = 0.0f;
-                    if (gm < p.M && c < p.Ctot)
-                        v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? T - 1 - tap : tap) * p.w_st];
-                    As[kk * AS + m] = v;
-                }
-            } else {
-                for (int idx = tid; idx < total; idx += NTHREADS) {
-                    const int m = idx / KT, kk = idx - m * KT;
-                    const int kc = (T == 1) ? kk : ((T == 9) ? kk / 9 : kk / T);
-                    const int tap = kk - kc * T;
-                    const int gm = m0 + m, c = c0 + kc;
-                    float v = 0.0f;
-                    if (gm < p.M && c < p.Ctot)
-                        v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? T - 1 - tap : tap) * p.w_st];
-                    As[kk * AS + m] = v;
-                }
+    float areg[NA], breg[NB];
+
+    // ---------------- global -> registers ----------------------------------------------------------
+    auto fetch = [&](int c0) {
+        // A: Wv[m0+m][c0 + kk/TT][kk%TT]
+        if (p.a_mfast) {
+            constexpr int KSTEP = NTHREADS / BM;  // kk rows covered per pass (BM <= 256)
+            const int m = tid % BM;
+            const int gm = m0 + m;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int kk = tid / BM + i * KSTEP;
+                const int kc = kk / TT, tap = kk - kc * TT;
+                const int c = c0 + kc;
+                float v = 0.0f;
+                if (gm < p.M && c < p.Ctot)
+                    v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? TT - 1 - tap : tap) * p.w_st];
+                areg[i] = v;
+            }
+        } else {
+            int m = tid / KT, kk = tid - m * KT;   // tid < 256: one division by a constant
+            constexpr int DM = NTHREADS / KT, DK = NTHREADS % KT;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int kc = kk / TT, tap = kk - kc * TT;
+                const int gm = m0 + m, c = c0 + kc;
+                float v = 0.0f;
+                if (gm < p.M && c < p.Ctot)
+                    v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? TT - 1 - tap : tap) * p.w_st];
+                areg[i] = v;
+                kk += DK; m += DM;
+                if (kk >= KT) { kk -= KT; ++m; }
             }
         }
-        // ---------------- B tile --------------------------------------------------------------
+        // B: raw values (prologue applied at LDS-store time)
         if (BMODE == BM_PIX) {
-            constexpr int KSTEP = NTHREADS / BN;
-            const int j = tid % BN, kq = tid / BN;
+            constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
 #pragma unroll
-            for (int i = 0; i < KC / KSTEP; ++i) {
-                const int kc = kq + i * KSTEP;
+            for (int i = 0; i < NB; ++i) {
+                const int kc = tid / BN + i * KSTEP;
                 const int c = c0 + kc;
                 float v = 0.0f;
                 if (st_valid && c < p.Ctot) {
                     if (gather) {
                         const int co = c >> 2, dy = (c >> 1) & 1, dx = c & 1;
                         v = p.x1[st_off1 + (int64_t)co * 4 * p.HW + dy * (2 * p.W) + dx];
+                    } else if (c < p.C1) {
+                        v = p.x1[st_off1 + (int64_t)c * st_cstride];
                     } else {
-                        v = load_src(p, c, st_off1, st_off2, st_cstride, st_gate);
+                        v = p.x2[st_off2 + (int64_t)(c - p.C1) * st_cstride];
                     }
                 }
-                Bs[kc * BN + j] = v;
+                breg[i] = v;
             }
         } else {
-            const int used = p.IR * p.WS;
-            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
                 const int c = c0 + kc;
                 const bool cok = c < p.Ctot;
+                const bool first = c < p.C1;
+                const float* src = first ? p.x1 + st_off1 + (int64_t)c * st_cstride
+                                         : p.x2 + st_off2 + (int64_t)(c - p.C1) * st_cstride;
 #pragma unroll
-                for (int i = 0; i < EPT_MAX; ++i) {
-                    const int e = tid + NTHREADS * i;
-                    if (e < used) {
-                        float v = 0.0f;
-                        if (cok && sp_goff[i] >= 0)
-                            v = load_src(p, c, st_off1 + sp_goff[i], st_off2 + sp_goff[i], st_cstride, st_gate);
-                        Bs[kc * p.CS + e] = v;
-                    }
+                for (int i = 0; i < EPT; ++i) {
+                    const int g = sp_goff[(BMODE == BM_SPATIAL) ? i : 0];
+                    breg[kc * EPT + i] = (cok && g >= 0) ? src[g] : 0.0f;
                 }
             }
         }
-        __syncthreads();
-        // ---------------- MFMA ------------------------------------------------------------------
+    };
+
+    // ---------------- registers -> LDS (B gets the BN/activation/gate prologue here) ---------------
+    auto prologue = [&](float v, int c, bool inb) -> float {
+        if (!inb) return 0.0f;  // zero padding is applied AFTER the activation (reference pads activated maps)
+        if (c < p.C1) {
+            if (p.pro1 != S2K_PRO_NONE) v = apply_pro(v, p.pro1, p.bnv1[c], p.bnv1[p.C1 + c]);
+            if (p.gate1) v *= p.gate1[st_gate + c];
+        } else {
+            const int c2 = c - p.C1;
+            if (p.pro2 != S2K_PRO_NONE) v = apply_pro(v, p.pro2, p.bnv2[c2], p.bnv2[p.C2 + c2]);
+        }
+        return v;
+    };
+    auto commit = [&](int c0) {
+        if (p.a_mfast) {
+            constexpr int KSTEP = NTHREADS / BM;
+            const int m = tid % BM;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) As[(tid / BM + i * KSTEP) * AS + m] = areg[i];
+        } else {
+            int m = tid / KT, kk = tid - m * KT;
+            constexpr int DM = NTHREADS / KT, DK = NTHREADS % KT;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                As[kk * AS + m] = areg[i];
+                kk += DK; m += DM;
+                if (kk >= KT) { kk -= KT; ++m; }
+            }
+        }
+        if (BMODE == BM_PIX) {
+            constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
+            const int j = tid % BN;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int kc = tid / BN + i * KSTEP;
+                const int c = c0 + kc;
+                float v = breg[i];
+                if (!gather) v = prologue(v, c, st_valid && c < p.Ctot);
+                Bs[kc * BN + j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                const int c = c0 + kc;
+                const bool cok = c < p.Ctot;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = tid + NTHREADS * i;
+                    if (e < used_sp)
+                        Bs[kc * p.CS + e] = prologue(breg[kc * EPT + i], c, cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0);
+                }
+            }
+        }
+    };
+
+    fetch(0);
+    commit(0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) fetch((ch + 1) * KCH);
+        // ---------------- MFMA over the chunk in LDS --------------------------------------------
         int tdy = 0, tdx = 0;
-        for (int tap = 0; tap < T; ++tap) {
+#pragma unroll 1
+        for (int tap = 0; tap < TT; ++tap) {
             const int toff = (BMODE == BM_PIX) ? 0 : tdy * p.WS + tdx;
 #pragma unroll
-            for (int ks = 0; ks < KC / 2; ++ks) {
+            for (int ks = 0; ks < KCH / 2; ++ks) {
                 const int k = 2 * ks + lh;
                 float a[WM], b[WN];
 #pragma unroll
-                for (int rm = 0; rm < WM; ++rm) a[rm] = As[(k * T + tap) * AS + wm0 + rm * 32 + l31];
+                for (int rm = 0; rm < WM; ++rm) a[rm] = As[(k * TT + tap) * AS + wm0 + rm * 32 + l31];
 #pragma unroll
                 for (int rn = 0; rn < WN; ++rn) b[rn] = Bs[k * CSB + boff[rn] + toff];
 #pragma unroll
@@ -240,6 +306,11 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
                         acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], b[rn], acc[rm][rn], 0, 0, 0);
             }
             if (++tdx == p.KW) { tdx = 0; ++tdy; }
+        }
+        __syncthreads();  // every wave is done reading this chunk
+        if (more) {
+            commit((ch + 1) * KCH);
+            __syncthreads();
         }
     }
 
@@ -269,6 +340,13 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
             }
         return;
     }
+    // row sums for BatchNorm: lanes -> half-wave shuffle, waves -> LDS, then ONE f64 atomic pair per
+    // row per workgroup, into the statistics replica of this tile
+    float* srow = smem;  // [2][BM], the K loop is over: LDS is free
+    if (p.stats) {
+        for (int i = tid; i < 2 * BM; i += NTHREADS) srow[i] = 0.0f;
+        __syncthreads();
+    }
 #pragma unroll
     for (int rm = 0; rm < WM; ++rm)
 #pragma unroll
@@ -293,11 +371,19 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
                 s = half_sum(s);
                 q = half_sum(q);
                 if (l31 == 0 && rok) {
-                    atomic_add_d(p.stats + gm, (double)s);
-                    atomic_add_d(p.stats + p.M + gm, (double)q);
+                    atomicAdd(srow + row, s);
+                    atomicAdd(srow + BM + row, q);
                 }
             }
         }
+    if (p.stats) {
+        __syncthreads();
+        double* st = p.stats + (int64_t)(tile % p.nrep) * 2 * p.M;
+        for (int i = tid; i < 2 * BM; i += NTHREADS) {
+            const int row = i % BM, gm = m0 + row;
+            if (gm < p.M) atomic_add_d(st + (i / BM) * p.M + gm, (double)srow[i]);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -325,27 +411,30 @@ static int pick_bm(int M) {
     return best;
 }
 
-template <int BMODE, int WM, int WN, int WVM, int WVN>
-static int launch_cfg(ConvP& p, int n_ntiles, size_t b_floats, hipStream_t st) {
-    constexpr int BM = WM * WVM * 32;
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT>
+static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st) {
+    constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;
+    constexpr int A_FLOATS = (KCH * TT * (BM + 1) + 3) & ~3;
     p.n_mtiles = cdiv(p.M, BM);
-    p.a_floats = (p.KT * (BM + 1) + 3) & ~3;
-    const size_t lds = (p.a_floats + b_floats) * sizeof(float);
-    auto kern = conv_igemm_kernel<BMODE, WM, WN, WVM, WVN>;
+    const size_t b_floats = (BMODE == BM_PIX) ? (size_t)KCH * BN : (size_t)KCH * p.CS;
+    const size_t lds = (A_FLOATS + b_floats) * sizeof(float);
+    auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (lds > 160 * 1024) { set_error("conv: LDS %zu too large", lds); return S2K_EINVAL; }
+    if (BMODE == BM_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("conv: halo tile exceeds EPT"); return S2K_EINVAL; }
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
+    p.n_tiles = (int)blocks;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, p);
     return S2K_OK;
 }
 
-// tile geometry for the SPATIAL stager; BN = output pixels per tile
-static bool spatial_tiling(ConvP& p, int BN) {
+// tile geometry for the SPATIAL stager; BN = output pixels per tile, cap = halo floats per channel
+static bool spatial_tiling(ConvP& p, int BN, int cap) {
     p.XW = p.WO <= BN ? p.WO : BN;
     int R = BN / p.XW;
     if (R > p.HO) R = p.HO;
@@ -355,7 +444,7 @@ static bool spatial_tiling(ConvP& p, int BN) {
         p.IR = (R - 1) * p.S + p.KH;
         p.IC = (p.XW - 1) * p.S + p.KW;
         p.WS = p.IC;
-        if (p.IR * p.WS <= NTHREADS * EPT_MAX) break;
+        if (p.IR * p.WS <= cap) break;
         if (R == 1) return false;
     }
     p.CS = p.IR * p.WS;
@@ -386,12 +475,13 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.pro1 = d[S2K_CONV_D_PRO1]; p.pro2 = d[S2K_CONV_D_PRO2]; p.mode = d[S2K_CONV_D_MODE];
     p.w_sm = d[S2K_CONV_D_W_SM]; p.w_sk = d[S2K_CONV_D_W_SK]; p.w_st = d[S2K_CONV_D_W_ST];
     p.flip = d[S2K_CONV_D_FLIP]; p.beta = d[S2K_CONV_D_BETA]; p.YC = d[S2K_CONV_D_YC];
-    p.T = p.KH * p.KW;
-    p.KT = KC * p.T;
+    p.nrep = d[S2K_CONV_D_NREP] > 0 ? d[S2K_CONV_D_NREP] : 1;
+    const int T = p.KH * p.KW;
     p.Ctot = p.C1 + p.C2;
     p.HW = p.H * p.W;
     p.a_mfast = p.w_sm < p.w_sk;
     p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
+    p.n_tiles = p.n_mtiles = 0;
     if (!p.x1 || !p.wt || !p.y || p.B <= 0 || p.C1 <= 0 || p.M <= 0 || p.H <= 0 || p.W <= 0) {
         set_error("conv: missing tensor or non-positive dimension");
         return S2K_EINVAL;
@@ -400,9 +490,9 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if ((p.pro1 != S2K_PRO_NONE && !p.bnv1) || (p.C2 > 0 && p.pro2 != S2K_PRO_NONE && !p.bnv2)) {
         set_error("conv: prologue without BNV"); return S2K_EINVAL;
     }
-    const bool pix = (p.T == 1 && p.S == 1) || p.mode != S2K_MODE_CONV;
+    const bool pix = (T == 1 && p.S == 1) || p.mode != S2K_MODE_CONV;
     if (p.mode != S2K_MODE_CONV) {
-        if (p.T != 1 || p.S != 1 || p.C2 != 0 || p.HO != p.H || p.WO != p.W) {
+        if (T != 1 || p.S != 1 || p.C2 != 0 || p.HO != p.H || p.WO != p.W) {
             set_error("conv: scatter/gather modes are 1x1 over the low-resolution grid"); return S2K_EINVAL;
         }
         if (p.mode == S2K_MODE_CONVT_SCATTER && ((p.M & 3) || p.beta || p.stats)) {
@@ -420,29 +510,36 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     const int bm = pick_bm(p.M);
     hipStream_t st = c.stream;
     if (pix) {
-        // small problems (deep 8x8 maps): 64x64 tiles keep more CUs busy
-        const int64_t tiles128 = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
-        if (bm >= 64 && tiles128 < 200) return launch_cfg<BM_PIX, 1, 1, 2, 2>(p, cdiv(p.Ntot, 64), KC * 64, st);
-        if (bm == 128) return launch_cfg<BM_PIX, 2, 2, 2, 2>(p, cdiv(p.Ntot, 128), KC * 128, st);
-        if (bm == 64) return launch_cfg<BM_PIX, 2, 2, 1, 4>(p, cdiv(p.Ntot, 256), KC * 256, st);
-        return launch_cfg<BM_PIX, 1, 2, 1, 4>(p, cdiv(p.Ntot, 256), KC * 256, st);
+        // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
+        const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
+        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 32, 1>(p, cdiv(p.Ntot, 64), st);
+        if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 32, 1>(p, cdiv(p.Ntot, 128), st);
+        if (bm == 64) return launch_cfg<BM_PIX, 1, 2, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
+        return launch_cfg<BM_PIX, 1, 1, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
     }
-    if (p.T > 25 || p.S > 2) { set_error("conv: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.S); return S2K_EINVAL; }
-    const int bn = (bm == 128) ? 128 : 256;
+    if (T != 9 || p.S > 2) { set_error("conv: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.S); return S2K_EINVAL; }
     int64_t tiles = 0;
-    auto geom = [&](int BN) -> bool {
-        if (!spatial_tiling(p, BN)) return false;
+    auto geom = [&](int BN, int cap) -> bool {
+        if (!spatial_tiling(p, BN, cap)) return false;
         tiles = (int64_t)p.B * p.tiles_x * p.tiles_y;
         return true;
     };
-    if (!geom(bn)) { set_error("conv: halo tile does not fit (W=%d)", p.W); return S2K_EINVAL; }
-    if (bm >= 64 && (int64_t)cdiv(p.M, bm) * tiles < 200) {
-        if (!geom(64)) { set_error("conv: halo tile does not fit"); return S2K_EINVAL; }
-        return launch_cfg<BM_SPATIAL, 1, 1, 2, 2>(p, (int)tiles, (size_t)KC * p.CS, st);
+    const int64_t out_px = (int64_t)p.B * p.HO * p.WO;
+    if (bm == 128) {
+        if (!geom(128, 2 * NTHREADS)) { set_error("conv: halo tile does not fit (W=%d)", p.W); return S2K_EINVAL; }
+        if (tiles * cdiv(p.M, 128) >= 160) return launch_cfg<BM_SPATIAL, 9, 2, 2, 2, 2, 8, 2>(p, (int)tiles, st);
     }
-    if (bm == 128) return launch_cfg<BM_SPATIAL, 2, 2, 2, 2>(p, (int)tiles, (size_t)KC * p.CS, st);
-    if (bm == 64) return launch_cfg<BM_SPATIAL, 2, 2, 1, 4>(p, (int)tiles, (size_t)KC * p.CS, st);
-    return launch_cfg<BM_SPATIAL, 1, 2, 1, 4>(p, (int)tiles, (size_t)KC * p.CS, st);
+    if (bm >= 64) {
+        if ((int64_t)cdiv(p.M, 64) * cdiv64(out_px, 256) >= 160 && geom(256, 4 * NTHREADS))
+            return launch_cfg<BM_SPATIAL, 9, 2, 2, 1, 4, 8, 4>(p, (int)tiles, st);
+        if (!geom(64, 2 * NTHREADS)) { set_error("conv: halo tile does not fit"); return S2K_EINVAL; }
+        return launch_cfg<BM_SPATIAL, 9, 1, 1, 2, 2, 8, 2>(p, (int)tiles, st);
+    }
+    // thin layers (M <= 32, full-resolution maps): 32 x 1024 tiles amortise the halo (6 rows per 4)
+    if (p.S == 1 && cdiv64(out_px, 1024) >= 200 && geom(1024, 7 * NTHREADS))
+        return launch_cfg<BM_SPATIAL, 9, 1, 8, 1, 4, 8, 7>(p, (int)tiles, st);
+    if (!geom(256, 4 * NTHREADS)) { set_error("conv: halo tile does not fit"); return S2K_EINVAL; }
+    return launch_cfg<BM_SPATIAL, 9, 1, 2, 1, 4, 8, 4>(p, (int)tiles, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -129,8 +129,23 @@ int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream
     return check_launch(dispatch(*op, c), *op, 0);
 }
 
+static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
+                        int* launches_by_kind, float* ms_per_op);
+
 int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
                         int* launches_by_kind) {
+    return profile_impl(ops, begin, end, bases, n_bases, stream, ms_by_kind, launches_by_kind, nullptr);
+}
+
+int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
+                            float* ms_per_op) {
+    float ms[S2K_N_KINDS + 1];
+    int cnt[S2K_N_KINDS + 1];
+    return profile_impl(ops, begin, end, bases, n_bases, stream, ms, cnt, ms_per_op);
+}
+
+static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
+                        int* launches_by_kind, float* ms_per_op) {
     if (!ops || !bases || !ms_by_kind || !launches_by_kind || begin < 0 || end < begin) {
         set_error("program_profile: bad arguments");
         return S2K_EINVAL;
@@ -156,6 +171,7 @@ int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases
             float ms = 0.0f;
             hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             const int k = ops[begin + i].kind;
+            if (ms_per_op) ms_per_op[i] = ms;
             if (k > 0 && k <= S2K_N_KINDS) { ms_by_kind[k] += ms; launches_by_kind[k] += 1; }
         }
     }

@@ -29,7 +29,7 @@ class FlatParamsMixin:
         if list(named) != list(L.params):
             raise RuntimeError("parameter registration order differs from the planned layout")
         dev = next(iter(named.values())).device
-        flat = torch.empty(L.n_params, dtype=torch.float32, device=dev)
+        flat = torch.zeros(L.n_params, dtype=torch.float32, device=dev)
         for name, (off, shape) in L.params.items():
             p = named[name]
             if tuple(p.shape) != tuple(shape):

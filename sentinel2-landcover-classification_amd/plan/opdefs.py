@@ -21,6 +21,15 @@ assert OP_BYTES == 256
 BASES = ["WS", "PARAMS", "GRADS", "BUFS", "X", "OUT", "DOUT", "NOISE", "WGS", "CONST", "Y", "AUX"]
 BASE = {n: i for i, n in enumerate(BASES)}
 
+# ---- statistics replicas -------------------------------------------------------------------------
+# Per-channel sums are accumulated with f64 atomics, which execute at the memory side: thousands of
+# adds onto one address serialise (a 24-channel layer at 128x128 was 40x off its roofline).  Every
+# STATS / STATS2 tensor is therefore [NREP][2][C]; a workgroup adds into replica (its id % NREP)
+# and the finalize stages sum the replicas.
+def stats_replicas(C: int) -> int:
+    return max(1, min(64, 4096 // max(C, 1)))
+
+
 # ---- prologue / activation codes -----------------------------------------------------------
 PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU = 0, 1, 2, 3          # v' = act(scale[c]*v + shift[c])
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 2, 3                          # same numbering as PRO_*
@@ -41,7 +50,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # STATS (double [2][M]) accumulates sum(Y), sum(Y^2) per row for train-mode BatchNorm.
     "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
-              "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC"], []),
+              "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
     # Weight gradient on f32 MFMA, K = pixels:
     #   WGS[tap][m][c] += sum_{b,yo,xo} Ppro[b][m][yo][xo] * Qpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     # (MODE_GATHER2X2: Q tap (dy,dx) reads Q[b][c][2y+dy][2x+dx]).  Scratch layout [T][M][CTOT]
@@ -53,15 +62,15 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "WGRAD_FINALIZE": (["TABLE", "WGS", "GRADS"], ["TOTAL"], ["N_ENTRIES"], []),
     # depthwise KxK, TF-SAME pads, prologue on X, BN stats of Y
     "DWCONV_FWD": (["X", "BNV", "WT", "Y", "STATS"], [],
-                   ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO"], []),
+                   ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "NREP"], []),
     # G[b][c][iy][ix] (+)= (sum_taps W*DY) * act'(u), u = scale*XRAW+shift; STATS2 += {sum G, sum G*xhat}
     "DWCONV_DGRAD": (["DY", "WT", "XRAW", "BNV", "G", "STATS2"], [],
-                     ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "BETA"], []),
+                     ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "BETA", "NREP"], []),
     # DW[c][ky][kx] += sum DY[b][c][yo][xo] * Xpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     "DWCONV_WGRAD": (["DY", "X", "BNV", "DW"], [],
                      ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO"], []),
     # BNV = {scale, shift, mean, invstd}[C]; TRAIN: from STATS + running-stat update; else from RM/RV
-    "BN_FINALIZE": (["STATS", "GAMMA", "BETA", "RM", "RV", "BNV"], ["COUNT"], ["C", "TRAIN"], ["EPS", "MOM"]),
+    "BN_FINALIZE": (["STATS", "GAMMA", "BETA", "RM", "RV", "BNV"], ["COUNT"], ["C", "TRAIN", "NREP"], ["EPS", "MOM"]),
     # POOL[b][c] = mean_hw act(scale*Y+shift)
     "SE_POOL": (["Y", "BNV", "POOL"], [], ["B", "C", "HW", "PRO"], []),
     # HPRE = W1 pool + B1; GATE = sigmoid(W2 silu(HPRE) + B2)
@@ -75,9 +84,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # dcs[b] = floor(KEEP + NOISE[b]) / KEEP (drop-connect) when NOISE given;
     # STATS2 (double [2][C]) += {sum GOUT, sum GOUT*xhat}
     "BN_BWD_REDUCE": (["G", "Y", "BNV", "MULBC", "ADDBC", "NOISE", "GOUT", "STATS2"], [],
-                      ["B", "C", "HW", "ACT"], ["KEEP", "ADDSCALE"]),
+                      ["B", "C", "HW", "ACT", "NREP"], ["KEEP", "ADDSCALE"]),
     # DGAMMA += S2; DBETA += S1; COEF = {A, Bq, Cq}[C] with dY = A*g' + Bq*xhat + Cq
-    "BN_BWD_FINALIZE": (["STATS2", "GAMMA", "BNV", "DGAMMA", "DBETA", "COEF"], ["COUNT"], ["C"], []),
+    "BN_BWD_FINALIZE": (["STATS2", "GAMMA", "BNV", "DGAMMA", "DBETA", "COEF"], ["COUNT"], ["C", "NREP"], []),
     "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY"], [], ["B", "C", "HW"], []),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"], [], ["B", "C", "HW"], ["KEEP"]),

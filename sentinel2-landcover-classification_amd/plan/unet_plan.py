@@ -92,11 +92,13 @@ class ParamLayout:
     n_bufs: int = 0
 
     def add_param(self, name, shape):
+        """Every parameter starts on a 256-byte boundary of the flat buffer (vector loads of weight
+        rows; the padding floats are zero and stay zero under Adam)."""
         n = 1
         for s in shape:
             n *= s
         self.params[name] = (self.n_params, tuple(shape))
-        self.n_params += n
+        self.n_params += (n + 63) // 64 * 64
 
     def add_buf(self, name, shape):
         n = 1
@@ -181,8 +183,12 @@ def _bn_forward(p: _P, prefix: str, y: TRef, C: int, count: int, stats: TRef | N
     bnv = p.alloc("bnv:" + prefix, (4, C))
     p.fwd.add("BN_FINALIZE", STATS=stats, GAMMA=p.param(prefix + ".weight"), BETA=p.param(prefix + ".bias"),
               RM=p.buf(prefix + ".running_mean"), RV=p.buf(prefix + ".running_var"), BNV=bnv,
-              COUNT=count, C=C, TRAIN=int(p.training), EPS=eps, MOM=mom)
+              COUNT=count, C=C, TRAIN=int(p.training), NREP=D.stats_replicas(C), EPS=eps, MOM=mom)
     return bnv
+
+
+def _stats(p: _P, name: str, C: int) -> TRef:
+    return p.aux.alloc(name, (D.stats_replicas(C), 2, C), "f64")
 
 
 def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: int, act: int,
@@ -194,14 +200,14 @@ def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: in
     if pre_stats is not None:
         st2, gp = pre_stats, G
     else:
-        st2 = p.aux.alloc("stats2:" + prefix, (2, C), "f64")
+        st2 = _stats(p, "stats2:" + prefix, C)
         gp = G if inplace else p.alloc("gp:" + prefix, (B, C, HW))
         p.bwd.add("BN_BWD_REDUCE", G=G, Y=y, BNV=bnv, MULBC=mulbc, ADDBC=addbc, NOISE=noise, GOUT=gp, STATS2=st2,
-                  B=B, C=C, HW=HW, ACT=act, KEEP=keep, ADDSCALE=addscale)
+                  B=B, C=C, HW=HW, ACT=act, NREP=D.stats_replicas(C), KEEP=keep, ADDSCALE=addscale)
     coef = p.alloc("coef:" + prefix, (3, C))
     p.bwd.add("BN_BWD_FINALIZE", STATS2=st2, GAMMA=p.param(prefix + ".weight"), BNV=bnv,
               DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COEF=coef,
-              COUNT=B * HW, C=C)
+              COUNT=B * HW, C=C, NREP=D.stats_replicas(C))
     p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=coef, DY=gp, B=B, C=C, HW=HW)
     return gp
 
@@ -252,7 +258,7 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
     B = p.B
     Ho, Wo, pt, pl = _conv_geometry(srcs[0], k, stride, same)
     y = p.alloc("y:" + wname, (B, M, Ho, Wo))
-    stats = p.aux.alloc("stats:" + bnprefix, (2, M), "f64") if p.training else None
+    stats = _stats(p, "stats:" + bnprefix, M) if p.training else None
     s1 = srcs[0]
     s2 = srcs[1] if len(srcs) > 1 else None
     Ctot = sum(s.C for s in srcs)
@@ -261,7 +267,7 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
               BNV2=s2.bnv if s2 else None, WT=p.param(wname), BIAS=p.param(bias) if bias else None, Y=y,
               STATS=stats, B=B, C1=s1.C, C2=s2.C if s2 else 0, H=s1.H, W=s1.W, M=M, KH=k, KW=k, STRIDE=stride,
               PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO1=s1.pro, PRO2=s2.pro if s2 else 0, MODE=D.MODE_CONV,
-              W_SM=Ctot * T, W_SK=T, W_ST=1, FLIP=0, BETA=0, YC=M)
+              W_SM=Ctot * T, W_SK=T, W_ST=1, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
     if s2 is not None:
         assert s2.gate is None
     bnv = _bn_forward(p, bnprefix, y, M, B * Ho * Wo, stats, eps, mom)
@@ -286,10 +292,11 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
     B = p.B
     H, W = src.H, src.W
     y = p.alloc("y:" + wname, (B, M, H, W))
-    stats = p.aux.alloc("stats:" + bnprefix, (2, M), "f64") if p.training else None
+    stats = _stats(p, "stats:" + bnprefix, M) if p.training else None
     p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=p.param(wname), BIAS=None,
               Y=y, STATS=stats, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
-              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1, FLIP=0, BETA=0, YC=M)
+              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1, FLIP=0, BETA=0, YC=M,
+              NREP=D.stats_replicas(M))
     bnv = _bn_forward(p, bnprefix, y, M, B * H * W, stats, eps, mom)
     xout = p.alloc(f"x:block{idx}", (B, M, H, W))
     use_dc = bool(ident is not None and dc_rate and p.training)
@@ -322,10 +329,11 @@ def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, e
     Ho, pt = same_pads(src.H, k, stride)
     Wo, pl = same_pads(src.W, k, stride)
     y = p.alloc("y:" + wname, (B, C, Ho, Wo))
-    stats = p.aux.alloc("stats:" + bnprefix, (2, C), "f64") if p.training else None
+    stats = _stats(p, "stats:" + bnprefix, C) if p.training else None
     assert src.gate is None
     geo = dict(B=B, C=C, H=src.H, W=src.W, K=k, STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO=src.pro)
-    p.fwd.add("DWCONV_FWD", X=src.raw, BNV=src.bnv, WT=p.param(wname), Y=y, STATS=stats, **geo)
+    nrep = D.stats_replicas(C)
+    p.fwd.add("DWCONV_FWD", X=src.raw, BNV=src.bnv, WT=p.param(wname), Y=y, STATS=stats, NREP=nrep, **geo)
     bnv = _bn_forward(p, bnprefix, y, C, B * Ho * Wo, stats, eps, mom)
     out = Act(y, C, Ho, Wo, bnv, D.PRO_SILU)
 
@@ -337,16 +345,16 @@ def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, e
         if src.pro == D.PRO_NONE:
             g = p.grad_of(src, wname + ".src")
             p.bwd.add("DWCONV_DGRAD", DY=dY, WT=p.param(wname), XRAW=None, BNV=None, G=g, STATS2=None,
-                      BETA=int(src.grad_init), **geo)
+                      BETA=int(src.grad_init), NREP=1, **geo)
             src.grad_init = True
         else:
             # fused: dgrad * act'(u) and the BN-backward statistics of the producer; the producer's
             # backward then only runs FINALIZE + APPLY on this buffer.
             g = p.grad_of(src, wname + ".src")
             assert not src.grad_init
-            st2 = p.aux.alloc("stats2f:" + bnprefix, (2, C), "f64")
+            st2 = _stats(p, "stats2f:" + bnprefix, C)
             p.bwd.add("DWCONV_DGRAD", DY=dY, WT=p.param(wname), XRAW=src.raw, BNV=src.bnv, G=g, STATS2=st2,
-                      BETA=0, **geo)
+                      BETA=0, NREP=nrep, **geo)
             src.grad_init = True
             src.fused_stats2 = st2
 

@@ -51,7 +51,8 @@ class Case:
         invstd = torch.rand(C, generator=self.gen) + 0.7
         return self.t(name, (4, C), torch.stack([scale, shift, mean, invstd]))
 
-    def run(self, kind, outputs, tol=1e-4, **fields):
+    def run(self, kind, outputs, tol=1e-4, sum0=(), **fields):
+        """sum0: outputs compared after summing their leading (statistics-replica) dimension."""
         from s2lc_amd import _lib
 
         prog = Program()
@@ -69,6 +70,8 @@ class Case:
             ref, _ = self.items[name]
             a = got[ref.off:ref.off + ref.nbytes].view(_DT[ref.dtype]).double()
             b = cpu[ref.off:ref.off + ref.nbytes].view(_DT[ref.dtype]).double()
+            if name in sum0:
+                a, b = a.view(ref.shape).sum(0), b.view(ref.shape).sum(0)
             assert torch.isfinite(b).all(), f"{kind}:{name}: oracle produced non-finite values"
             assert torch.isfinite(a).all(), f"{kind}:{name}: GPU produced non-finite values"
             denom = max(b.abs().max().item(), 1e-20)
@@ -119,9 +122,10 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
         y = c.t("y", (B, YC, 2 * Ho, 2 * Wo), "nan")
     else:
         y = c.t("y", (B, YC, Ho, Wo), "randn" if beta else "nan")
-    st_ref = c.t("stats", (2, M), "zeros", "f64") if stats else None
+    nrep = D.stats_replicas(M)
+    st_ref = c.t("stats", (nrep, 2, M), "zeros", "f64") if stats else None
     outs = ["y"] + (["stats"] if stats else [])
-    c.run("CONV", outs, tol, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wt, BIAS=bs, Y=y, STATS=st_ref,
+    c.run("CONV", outs, tol, sum0=("stats",), NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wt, BIAS=bs, Y=y, STATS=st_ref,
           B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo,
           PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=sm, W_SK=sk, W_ST=st, FLIP=flip, BETA=beta, YC=YC)
 
@@ -268,8 +272,9 @@ def test_dwconv_fwd(geo, pro):
     bnv = c.bnv("bnv", C) if pro else None
     w = c.t("w", (C, K, K), scale=0.3)
     y = c.t("y", (B, C, Ho, Wo), "nan")
-    st = c.t("stats", (2, C), "zeros", "f64")
-    c.run("DWCONV_FWD", ["y", "stats"], 1e-4, X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=pro, **g)
+    nrep = D.stats_replicas(C)
+    st = c.t("stats", (nrep, 2, C), "zeros", "f64")
+    c.run("DWCONV_FWD", ["y", "stats"], 1e-4, sum0=("stats",), X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=pro, NREP=nrep, **g)
 
 
 @pytest.mark.parametrize("geo", DW_GEOS)
@@ -283,9 +288,11 @@ def test_dwconv_dgrad(geo, pro, beta):
     xr = c.t("xraw", (B, C, H, W)) if pro else None
     bnv = c.bnv("bnv", C) if pro else None
     gg = c.t("g", (B, C, H, W), "randn" if beta else "nan")
-    st = c.t("stats2", (2, C), "zeros", "f64") if pro else None
+    nrep = D.stats_replicas(C)
+    st = c.t("stats2", (nrep, 2, C), "zeros", "f64") if pro else None
     outs = ["g"] + (["stats2"] if pro else [])
-    c.run("DWCONV_DGRAD", outs, 1e-4, DY=dy, WT=w, XRAW=xr, BNV=bnv, G=gg, STATS2=st, PRO=pro, BETA=beta, **g)
+    c.run("DWCONV_DGRAD", outs, 1e-4, sum0=("stats2",), DY=dy, WT=w, XRAW=xr, BNV=bnv, G=gg, STATS2=st, PRO=pro, BETA=beta,
+          NREP=nrep, **g)
 
 
 @pytest.mark.parametrize("geo", DW_GEOS)
@@ -310,12 +317,16 @@ def test_bn_finalize(train):
     C, n = 70, 5000
     mean = torch.randn(C, dtype=torch.float64)
     var = torch.rand(C, dtype=torch.float64) + 0.1
-    stats = c.t("stats", (2, C), torch.stack([mean * n, (var + mean * mean) * n]), "f64")
+    nrep = 3
+    full = torch.stack([mean * n, (var + mean * mean) * n])
+    parts = torch.rand(nrep, 2, C, dtype=torch.float64)
+    parts = parts / parts.sum(0, keepdim=True) * full          # replicas that add up to the batch sums
+    stats = c.t("stats", (nrep, 2, C), parts, "f64")
     gam, bet = c.t("gamma", (C,), "pos"), c.t("beta", (C,))
     rm, rv = c.t("rm", (C,)), c.t("rv", (C,), "pos")
     bnv = c.t("bnv", (4, C), "nan")
     c.run("BN_FINALIZE", ["bnv", "rm", "rv"], 1e-5, STATS=stats if train else None, GAMMA=gam, BETA=bet, RM=rm, RV=rv,
-          BNV=bnv, COUNT=n, C=C, TRAIN=train, EPS=1e-3, MOM=0.01)
+          BNV=bnv, COUNT=n, C=C, TRAIN=train, NREP=nrep, EPS=1e-3, MOM=0.01)
 
 
 @pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 3, 10000)])
@@ -326,21 +337,22 @@ def test_bn_backward_trio(B, C, HW, variant):
     y = c.t("y", (B, C, HW))
     bnv = c.bnv("bnv", C)
     gout = c.t("gout", (B, C, HW), "nan")
-    st2 = c.t("stats2", (2, C), "zeros", "f64")
+    nrep = D.stats_replicas(C)
+    st2 = c.t("stats2", (nrep, 2, C), "zeros", "f64")
     mul = c.t("mul", (B, C), "rand") if variant == "silu_se" else None
     add = c.t("add", (B, C)) if variant == "silu_se" else None
     noise = c.t("noise", (B,), "rand") if variant == "none_dc" else None
     act = {"relu": 3, "silu_se": 2, "none_dc": 0}[variant]
-    c.run("BN_BWD_REDUCE", ["gout", "stats2"], 1e-4, G=g, Y=y, BNV=bnv, MULBC=mul, ADDBC=add, NOISE=noise, GOUT=gout,
-          STATS2=st2, B=B, C=C, HW=HW, ACT=act, KEEP=0.6, ADDSCALE=1.0 / HW)
+    c.run("BN_BWD_REDUCE", ["gout", "stats2"], 1e-4, sum0=("stats2",), G=g, Y=y, BNV=bnv, MULBC=mul, ADDBC=add, NOISE=noise,
+          GOUT=gout, STATS2=st2, B=B, C=C, HW=HW, ACT=act, NREP=nrep, KEEP=0.6, ADDSCALE=1.0 / HW)
     c2 = Case(7)
-    st2 = c2.t("stats2", (2, C), torch.randn(2, C, dtype=torch.float64) * 10, "f64")
+    st2 = c2.t("stats2", (2, 2, C), torch.randn(2, 2, C, dtype=torch.float64) * 10, "f64")
     gam = c2.t("gamma", (C,), "pos")
     bnv = c2.bnv("bnv", C)
     dg, db = c2.t("dgamma", (C,)), c2.t("dbeta", (C,))
     coef = c2.t("coef", (3, C), "nan")
     c2.run("BN_BWD_FINALIZE", ["dgamma", "dbeta", "coef"], 1e-5, STATS2=st2, GAMMA=gam, BNV=bnv, DGAMMA=dg, DBETA=db,
-           COEF=coef, COUNT=B * HW, C=C)
+           COEF=coef, COUNT=B * HW, C=C, NREP=2)
     c3 = Case(8)
     gp, y = c3.t("gp", (B, C, HW)), c3.t("y", (B, C, HW))
     bnv, coef = c3.bnv("bnv", C), c3.t("coef", (3, C))
