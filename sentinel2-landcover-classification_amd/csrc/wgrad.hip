@@ -35,12 +35,21 @@ __device__ __forceinline__ float ld_pro(const float* x, const float* bnv, const 
     return v;
 }
 
-// T taps, per-wave tile (WM*32) x (WN*32), waves arranged WVM x WVN x WVK (K = pixel pairs)
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK>
+// T taps, per-wave tile (WM*32) x (WN*32), waves arranged WVM x WVN x WVK (K = pixel pairs).
+// NPJ = pixel slots per tile (power of two >= pixels per tile), EPT = halo elements per thread per
+// channel.  A thread owns fixed (pixel | halo element) slots, only the tile origin changes, so no
+// index arithmetic is left in the tile loop; the operands of tile i+1 are fetched into registers
+// before the MFMAs of tile i are issued and written to LDS after them (latency hidden under
+// 72..288 MFMAs per wave).
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
 __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BC = WN * WVN * 32;
+    constexpr int RSTEP = NTHREADS / NPJ;   // P/Q rows staged per pass
+    constexpr int NPR = BM / RSTEP;         // P values per thread per tile
+    constexpr int NQR = (MODE == WG_SPATIAL) ? BC * EPT : (MODE == WG_GATHER ? 4 * (BC / RSTEP) : BC / RSTEP);
     static_assert(WVM * WVN * WVK == 4, "4 waves per workgroup");
+    static_assert(NTHREADS % NPJ == 0 && BM % RSTEP == 0 && BC % RSTEP == 0, "pixel slots vs threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [BM][PSTR]
     float* Qs = smem + BM * p.PSTR;      // [BC][CSQ]
@@ -57,6 +66,26 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     int tile_end = tile_begin + p.tiles_per_split;
     if (tile_end > p.ntiles) tile_end = p.ntiles;
 
+    // ---- fixed per-thread stager slots --------------------------------------------------------------
+    const int pj = tid % NPJ;            // pixel slot inside the tile
+    const int prow = tid / NPJ;          // first P/Q row of this thread
+    int pr = 0, pxx = 0;                 // SPATIAL: (row, col) of the slot inside the tile
+    int qrr[EPT], qcc[EPT];
+    if (MODE == WG_SPATIAL) {
+        pr = pj / p.XWe;
+        pxx = pj - pr * p.XWe;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + NTHREADS * i;
+            qrr[i] = e / p.WS;
+            qcc[i] = e - qrr[i] * p.WS;
+        }
+    }
+    const int np_sp = p.R * p.XWe;
+    const int used_sp = p.IR * p.WS;
+    const int half_xw = p.XWe >> 1;
+    const int npairs = (MODE == WG_SPATIAL) ? (np_sp >> 1) : (NPJ >> 1);
+
     f32x16 acc[T][WM][WN];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -67,105 +96,138 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        __syncthreads();
-        int npairs;  // pixel pairs in this tile (k steps)
+    float preg[NPR], qreg[NQR];
+    bool f_pok = false;           // the fetched tile's pixel slot is inside the image
+    unsigned f_qok = 0;           // SPATIAL: bit i = halo slot i inside the image
+    int f_b = 0;                  // image index of the fetched tile (gate rows)
+
+    // ---------------- global -> registers (raw values) ---------------------------------------------------
+    auto fetch = [&](int tile) {
         if (MODE == WG_SPATIAL) {
             const int tx = tile % p.tiles_x;
             const int ty = (tile / p.tiles_x) % p.tiles_y;
             const int b = tile / (p.tiles_x * p.tiles_y);
             const int y0 = ty * p.R, x0 = tx * p.XW;
-            // P tile: Ps[m][r*XWe + xx], zero outside the image / beyond M
-            const int np = p.R * p.XWe;
-            for (int idx = tid; idx < BM * np; idx += NTHREADS) {
-                const int m = idx / np, j = idx - m * np;
-                const int r = j / p.XWe, xx = j - r * p.XWe;
-                const int gm = m0 + m, yo = y0 + r, xo = x0 + xx;
-                float v = 0.0f;
-                if (gm < p.M && xx < p.XW && yo < p.HO && xo < p.WO)
-                    v = ld_pro(p.p, p.bnvp, p.gatep, p.prop, p.M, gm,
-                               ((int64_t)b * p.M + gm) * p.HWp + (int64_t)yo * p.WO + xo, b * p.M);
-                Ps[m * p.PSTR + j] = v;
-            }
-            // Q halo tile: Qs[c][rr*WS + cc]
+            const int yo = y0 + pr, xo = x0 + pxx;
+            f_b = b;
+            f_pok = pj < np_sp && pxx < p.XW && yo < p.HO && xo < p.WO;
+            const float* psrc = p.p + ((int64_t)b * p.M + m0 + prow) * p.HWp + (int64_t)yo * p.WO + xo;
+#pragma unroll
+            for (int i = 0; i < NPR; ++i)
+                preg[i] = (f_pok && m0 + prow + i * RSTEP < p.M) ? psrc[(int64_t)i * RSTEP * p.HWp] : 0.0f;
             const int iy0 = y0 * p.S - p.PT, ix0 = x0 * p.S - p.PL;
-            const int used = p.IR * p.WS;
-            int goff[WG_EPT_MAX];
+            int goff[EPT];
+            f_qok = 0;
 #pragma unroll
-            for (int i = 0; i < WG_EPT_MAX; ++i) {
-                const int e = tid + NTHREADS * i;
-                int g = -1;
-                if (e < used) {
-                    const int rr = e / p.WS, cc = e - rr * p.WS;
-                    const int iy = iy0 + rr, ix = ix0 + cc;
-                    if (cc < p.IC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) g = iy * p.W + ix;
-                }
-                goff[i] = g;
+            for (int i = 0; i < EPT; ++i) {
+                const int iy = iy0 + qrr[i], ix = ix0 + qcc[i];
+                const bool ok = (tid + NTHREADS * i) < used_sp && qcc[i] < p.IC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                goff[i] = ok ? iy * p.W + ix : 0;
+                f_qok |= ok ? (1u << i) : 0u;
             }
+            const float* qsrc = p.q + ((int64_t)b * p.C + c0) * p.HWq;
+#pragma unroll
             for (int c = 0; c < BC; ++c) {
-                const int gc = c0 + c;
-                const bool cok = gc < p.C;
-                const int64_t plane = ((int64_t)b * p.C + gc) * p.HWq;
+                const bool cok = c0 + c < p.C;
 #pragma unroll
-                for (int i = 0; i < WG_EPT_MAX; ++i) {
-                    const int e = tid + NTHREADS * i;
-                    if (e < used) {
-                        float v = 0.0f;
-                        if (cok && goff[i] >= 0)
-                            v = ld_pro(p.q, p.bnvq, p.gateq, p.proq, p.C, gc, plane + goff[i], b * p.C);
-                        Qs[c * p.CSQ + e] = v;
-                    }
-                }
+                for (int i = 0; i < EPT; ++i)
+                    qreg[c * EPT + i] = (cok && ((f_qok >> i) & 1u)) ? qsrc[(int64_t)c * p.HWq + goff[i]] : 0.0f;
             }
-            npairs = np >> 1;
         } else {
-            // flat pixel chunk [n0, n0 + NP) over (b, y, x) of the P-resolution grid
             const int64_t ntot = (int64_t)p.B * p.HWp;
-            const int64_t n0 = (int64_t)tile * p.NP;
-            const int j = tid % p.NP, rq = tid / p.NP, rstep = NTHREADS / p.NP;
-            const int64_t n = n0 + j;
-            const bool ok = n < ntot;
-            const int64_t nn = ok ? n : 0;
+            const int64_t n = (int64_t)tile * NPJ + pj;
+            f_pok = n < ntot;
+            const int64_t nn = f_pok ? n : 0;
             const int b = (int)(nn / p.HWp);
             const int pp = (int)(nn - (int64_t)b * p.HWp);
-            for (int m = rq; m < BM; m += rstep) {
-                const int gm = m0 + m;
-                float v = 0.0f;
-                if (ok && gm < p.M)
-                    v = ld_pro(p.p, p.bnvp, p.gatep, p.prop, p.M, gm, ((int64_t)b * p.M + gm) * p.HWp + pp, b * p.M);
-                Ps[m * p.PSTR + j] = v;
-            }
+            f_b = b;
+            const float* psrc = p.p + ((int64_t)b * p.M + m0 + prow) * p.HWp + pp;
+#pragma unroll
+            for (int i = 0; i < NPR; ++i)
+                preg[i] = (f_pok && m0 + prow + i * RSTEP < p.M) ? psrc[(int64_t)i * RSTEP * p.HWp] : 0.0f;
             if (MODE == WG_PIX) {
-                for (int c = rq; c < BC; c += rstep) {
-                    const int gc = c0 + c;
-                    float v = 0.0f;
-                    if (ok && gc < p.C)
-                        v = ld_pro(p.q, p.bnvq, p.gateq, p.proq, p.C, gc, ((int64_t)b * p.C + gc) * p.HWq + pp, b * p.C);
-                    Qs[c * p.CSQ + j] = v;
-                }
-            } else {  // GATHER: Q is [B][C][2HO][2WO]; tap (dy,dx) plane t at Qs[c][t*NP + j]
+                const float* qsrc = p.q + ((int64_t)b * p.C + c0 + prow) * p.HWq + pp;
+#pragma unroll
+                for (int i = 0; i < BC / RSTEP; ++i)
+                    qreg[i] = (f_pok && c0 + prow + i * RSTEP < p.C) ? qsrc[(int64_t)i * RSTEP * p.HWq] : 0.0f;
+            } else {  // GATHER: Q is [B][C][2HO][2WO]
                 const int yy = pp / p.WO, xx = pp - yy * p.WO;
-                const int64_t g0 = (int64_t)(2 * yy) * p.W + 2 * xx;
-                for (int c = rq; c < BC; c += rstep) {
-                    const int gc = c0 + c;
+                const float* qsrc = p.q + ((int64_t)b * p.C + c0 + prow) * p.HWq + (int64_t)(2 * yy) * p.W + 2 * xx;
+#pragma unroll
+                for (int i = 0; i < BC / RSTEP; ++i) {
                     float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
-                    if (ok && gc < p.C) {
-                        const float* src = p.q + ((int64_t)b * p.C + gc) * p.HWq + g0;
+                    if (f_pok && c0 + prow + i * RSTEP < p.C) {
+                        const float* src = qsrc + (int64_t)i * RSTEP * p.HWq;
                         r0 = *reinterpret_cast<const float2*>(src);
                         r1 = *reinterpret_cast<const float2*>(src + p.W);
                     }
-                    float* dst = Qs + c * p.CSQ + j;
-                    dst[0] = r0.x;
-                    dst[p.NP] = r0.y;
-                    dst[2 * p.NP] = r1.x;
-                    dst[3 * p.NP] = r1.y;
+                    qreg[4 * i + 0] = r0.x; qreg[4 * i + 1] = r0.y; qreg[4 * i + 2] = r1.x; qreg[4 * i + 3] = r1.y;
                 }
             }
-            npairs = p.NP >> 1;
         }
-        __syncthreads();
+    };
 
+    // ---------------- registers -> LDS (prologues applied here; zero padding stays zero) ----------------
+    auto pro_p = [&](float v, int gm, bool ok) -> float {
+        if (!ok || gm >= p.M) return 0.0f;
+        if (p.prop != S2K_PRO_NONE) v = apply_pro(v, p.prop, p.bnvp[gm], p.bnvp[p.M + gm]);
+        if (p.gatep) v *= p.gatep[f_b * p.M + gm];
+        return v;
+    };
+    auto pro_q = [&](float v, int gc, bool ok) -> float {
+        if (!ok || gc >= p.C) return 0.0f;
+        if (p.proq != S2K_PRO_NONE) v = apply_pro(v, p.proq, p.bnvq[gc], p.bnvq[p.C + gc]);
+        if (p.gateq) v *= p.gateq[f_b * p.C + gc];
+        return v;
+    };
+    auto commit = [&]() {
+        if (MODE != WG_SPATIAL || pj < np_sp) {
+#pragma unroll
+            for (int i = 0; i < NPR; ++i) {
+                const int m = prow + i * RSTEP;
+                Ps[m * p.PSTR + pj] = pro_p(preg[i], m0 + m, f_pok);
+            }
+        }
+        if (MODE == WG_SPATIAL) {
+#pragma unroll
+            for (int c = 0; c < BC; ++c)
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = tid + NTHREADS * i;
+                    if (e < used_sp) Qs[c * p.CSQ + e] = pro_q(qreg[c * EPT + i], c0 + c, (f_qok >> i) & 1u);
+                }
+        } else if (MODE == WG_PIX) {
+#pragma unroll
+            for (int i = 0; i < BC / RSTEP; ++i) {
+                const int c = prow + i * RSTEP;
+                Qs[c * p.CSQ + pj] = pro_q(qreg[i], c0 + c, f_pok);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BC / RSTEP; ++i) {
+                float* dst = Qs + (prow + i * RSTEP) * p.CSQ + pj;
+                dst[0] = qreg[4 * i + 0];
+                dst[NPJ] = qreg[4 * i + 1];
+                dst[2 * NPJ] = qreg[4 * i + 2];
+                dst[3 * NPJ] = qreg[4 * i + 3];
+            }
+        }
+    };
+
+    if (tile_begin < tile_end) {
+        fetch(tile_begin);
+        commit();
+    }
+    __syncthreads();
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const bool more = tile + 1 < tile_end;
+        if (more) fetch(tile + 1);
         // ---------------- MFMA over pixel pairs ----------------------------------------------------
+        // SPATIAL: pair s = (row r, column pair xp); walk (r, xp) incrementally, WVK pairs at a time
+        int r_run = 0, xp_run = wk;
+        if (MODE == WG_SPATIAL)
+            while (xp_run >= half_xw) { xp_run -= half_xw; ++r_run; }
         for (int s = wk; s < npairs; s += WVK) {
             const int n = 2 * s + lh;  // this lane's pixel inside the tile
             float a[WM];
@@ -173,8 +235,9 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             for (int rm = 0; rm < WM; ++rm) a[rm] = Ps[(wm0 + rm * 32 + l31) * p.PSTR + n];
             int qbase;
             if (MODE == WG_SPATIAL) {
-                const int r = n / p.XWe, xx = n - r * p.XWe;
-                qbase = (r * p.S) * p.WS + xx * p.S;
+                qbase = (r_run * p.S) * p.WS + (2 * xp_run + lh) * p.S;
+                xp_run += WVK;
+                while (xp_run >= half_xw) { xp_run -= half_xw; ++r_run; }
             } else {
                 qbase = n;
             }
@@ -183,7 +246,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             for (int t = 0; t < T; ++t) {
                 int toff;
                 if (MODE == WG_SPATIAL) toff = tdy * p.WS + tdx;
-                else if (MODE == WG_GATHER) toff = t * p.NP;
+                else if (MODE == WG_GATHER) toff = t * NPJ;
                 else toff = 0;
                 float bq[WN];
 #pragma unroll
@@ -195,6 +258,11 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                         acc[t][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], bq[rn], acc[t][rm][rn], 0, 0, 0);
                 if (++tdx == p.KW) { tdx = 0; ++tdy; }
             }
+        }
+        __syncthreads();
+        if (more) {
+            commit();
+            __syncthreads();
         }
     }
 
@@ -225,17 +293,19 @@ static T* ref_ptr(const Ctx& c, int64_t ref) {
     return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
 }
 
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK>
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
 static int launch_wg(WgradP& p, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
     const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ) * sizeof(float);
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
-    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK>;
+    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT>;
+    if (MODE == WG_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("wgrad: halo exceeds EPT"); return S2K_EINVAL; }
+    if (MODE == WG_SPATIAL && p.R * p.XWe > NPJ) { set_error("wgrad: tile exceeds pixel slots"); return S2K_EINVAL; }
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     // pixel splits: aim at ~3 workgroups per CU, at least 4 tiles per split to amortise the combine
@@ -288,8 +358,8 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         p.PSTR = p.NP + 1;
         p.CSQ = 4 * p.NP + 1;
         p.ntiles = (int)cdiv64(npix, p.NP);
-        if (p.M <= 32 || p.C <= 32) return launch_wg<WG_GATHER, 4, 1, 1, 2, 1, 2>(p, st);
-        return launch_wg<WG_GATHER, 4, 1, 2, 2, 2, 1>(p, st);
+        if (p.M <= 32 || p.C <= 32) return launch_wg<WG_GATHER, 4, 1, 1, 2, 1, 2, 32, 1>(p, st);
+        return launch_wg<WG_GATHER, 4, 1, 2, 2, 2, 1, 32, 1>(p, st);
     }
     if (p.T == 1 && p.S == 1) {
         if (p.H != p.HO || p.W != p.WO) { set_error("wgrad: 1x1 geometry"); return S2K_EINVAL; }
@@ -297,13 +367,15 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         p.PSTR = p.NP + 1;
         p.CSQ = p.NP + 1;
         p.ntiles = (int)cdiv64(npix, p.NP);
-        if (p.M <= 32 && p.C <= 32) return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4>(p, st);
-        if (p.M <= 64 || p.C <= 64) return launch_wg<WG_PIX, 1, 1, 1, 2, 2, 1>(p, st);
-        return launch_wg<WG_PIX, 1, 2, 2, 2, 2, 1>(p, st);
+        if (p.M <= 32 && p.C <= 32) return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 64, 1>(p, st);
+        if (p.M <= 64 || p.C <= 64) return launch_wg<WG_PIX, 1, 1, 1, 2, 2, 1, 64, 1>(p, st);
+        return launch_wg<WG_PIX, 1, 2, 2, 2, 2, 1, 64, 1>(p, st);
     }
     if (p.T != 9) { set_error("wgrad: only 1x1, 3x3 and 2x2-transpose kernels are on this path"); return S2K_EINVAL; }
-    // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles of <= 64 pixels
-    const int NPX = 64;
+    // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles; thin layers (few
+    // channels, huge maps) take 128-pixel tiles, the rest 64 (two workgroups per CU by LDS)
+    const bool thin = (p.M <= 32);
+    const int NPX = thin ? 128 : 64;
     int XW = p.WO <= NPX ? p.WO : NPX;
     int R = NPX / ((XW + 1) & ~1);
     if (R > p.HO) R = p.HO;
@@ -325,9 +397,10 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.tiles_y = cdiv(p.HO, p.R);
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.NP = 0;
-    if (p.M <= 32 && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4>(p, st);
-    if (p.M <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2>(p, st);
-    return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1>(p, st);
+    if (thin && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4, 128, 2>(p, st);
+    if (thin) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2, 128, 2>(p, st);
+    if (p.IR * p.WS <= NTHREADS) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1>(p, st);
+    return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 2>(p, st);
 }
 
 }  // namespace s2k
