@@ -104,6 +104,17 @@ def op_axpy(m: Mem, o):
     m.view(o["Y"], (o["COUNT"],)).add_(m.view(o["X"], (o["COUNT"],)))
 
 
+def op_weight_pack(m: Mem, o):
+    tab = m.view(o["TABLE"], (o["N_ENTRIES"], 12), "i32")
+    for src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP, _ in tab.tolist():
+        src = m.view(m.addr(o["SRC"], src_off), (M, K, T), strides=(s_m, s_k, s_t))
+        if flip:
+            src = src.flip(2)
+        dst = m.view(m.addr(o["DST"], dst_off), (KP, T, MP))
+        dst.zero_()
+        dst[:K, :, :M] = src.permute(1, 2, 0)
+
+
 def op_conv(m: Mem, o):
     B, C1, C2, H, W, M = o["B"], o["C1"], o["C2"], o["H"], o["W"], o["M"]
     KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
@@ -387,7 +398,7 @@ def op_argmax(m: Mem, o):
 
 
 DISPATCH = {
-    "MEMSET": op_memset, "AXPY": op_axpy, "CONV": op_conv, "WGRAD": op_wgrad, "WGRAD_FINALIZE": op_wgrad_finalize,
+    "MEMSET": op_memset, "AXPY": op_axpy, "WEIGHT_PACK": op_weight_pack, "CONV": op_conv, "WGRAD": op_wgrad, "WGRAD_FINALIZE": op_wgrad_finalize,
     "DWCONV_FWD": op_dwconv_fwd, "DWCONV_DGRAD": op_dwconv_dgrad, "DWCONV_WGRAD": op_dwconv_wgrad,
     "BN_FINALIZE": op_bn_finalize, "SE_POOL": op_se_pool, "SE_FC": op_se_fc, "SE_FC_BWD": op_se_fc_bwd,
     "SE_BWD_REDUCE": op_se_bwd_reduce, "BN_BWD_REDUCE": op_bn_bwd_reduce, "BN_BWD_FINALIZE": op_bn_bwd_finalize,

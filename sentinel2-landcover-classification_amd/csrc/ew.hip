@@ -107,6 +107,40 @@ int launch_wgrad_finalize(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
+// ---------------- WEIGHT_PACK ----------------------------------------------------------------------
+// table rows: {src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP, start}; one thread per packed element
+__global__ void weight_pack_kernel(const int* table, int n_entries, const float* src, float* dst, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int lo = 0, hi = n_entries - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)table[mid * 12 + 11] <= e) lo = mid; else hi = mid - 1;
+        }
+        const int* r = table + lo * 12;
+        const int M = r[2], K = r[3], T = r[4], MP = r[9];
+        const int local = (int)(e - r[11]);
+        const int kk = local / MP, m = local - kk * MP;
+        const int kc = kk / T, tap = kk - kc * T;
+        float v = 0.0f;
+        if (m < M && kc < K) v = src[(int64_t)r[0] + (int64_t)m * r[5] + (int64_t)kc * r[6] + (r[8] ? T - 1 - tap : tap) * r[7]];
+        dst[(int64_t)r[1] + local] = v;
+    }
+}
+
+int launch_weight_pack(const S2kOp& op, const Ctx& c) {
+    const int* table = ref_ptr<const int>(c, op.t[S2K_WEIGHT_PACK_T_TABLE]);
+    const float* src = ref_ptr<const float>(c, op.t[S2K_WEIGHT_PACK_T_SRC]);
+    float* dst = ref_ptr<float>(c, op.t[S2K_WEIGHT_PACK_T_DST]);
+    CHECK_PTRS("weight_pack", table, src, dst);
+    const int64_t total = op.n[S2K_WEIGHT_PACK_N_TOTAL];
+    const int n = op.d[S2K_WEIGHT_PACK_D_N_ENTRIES];
+    if (!table || !src || !dst || n <= 0 || total <= 0 || total > 0x7fffffff) { set_error("weight_pack: bad args"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 8192);
+    hipLaunchKernelGGL(weight_pack_kernel, dim3(blocks), dim3(256), 0, c.stream, table, n, src, dst, total);
+    return S2K_OK;
+}
+
 // ---------------- BN_FINALIZE ----------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const double* stats, const float* gamma, const float* beta, float* rm, float* rv,
                                    float* bnv, int C, int train, double count, float eps, float mom, int nrep) {

@@ -42,17 +42,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT>
-__global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW>
+__global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BN = WN * WVN * 32;
-    constexpr int AS = BM + 1;
+    constexpr int AS = BM;                                                   // A rows are copied whole: no padding needed
     constexpr int KT = KCH * TT;
-    constexpr int NA = KT * BM / NTHREADS;                                   // A elements per thread per chunk
+    constexpr int A4 = KT * BM / 4;                                          // float4 pieces of an A tile
+    constexpr int NA = (A4 + NTHREADS - 1) / NTHREADS;                       // float4 pieces per thread per chunk
     constexpr int NB = (BMODE == BM_PIX) ? KCH * BN / NTHREADS : KCH * EPT;  // B elements per thread per chunk
     constexpr int A_FLOATS = (KT * AS + 3) & ~3;
     static_assert(WVM * WVN == 4, "4 waves per workgroup");
-    static_assert((KT * BM) % NTHREADS == 0 && NA >= 1, "A tile must split evenly");
     static_assert(BMODE != BM_PIX || (NTHREADS % BN == 0 || BN % NTHREADS == 0), "pixel tile vs threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -154,40 +154,19 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
     const int nchunks = (p.Ctot + KCH - 1) / KCH;
     const int used_sp = p.IR * p.WS;
 
-    float areg[NA], breg[NB];
+    f32x4 areg[NA];
+    float breg[NB];
+    // A tile = rows [c0*TT, c0*TT + KT) x columns [m0, m0 + BM) of the packed weights (WEIGHT_PACK: row
+    // stride w_st = MP, zero padded in both directions): affine 16-byte loads, no bounds checks
+    const float* a_src = p.wt + (int64_t)(tid / (BM / 4)) * p.w_st + m0 + 4 * (tid % (BM / 4));
+    constexpr int A_ROWS_PER_PASS = NTHREADS / (BM / 4);
 
     // ---------------- global -> registers ----------------------------------------------------------
     auto fetch = [&](int c0) {
-        // A: Wv[m0+m][c0 + kk/TT][kk%TT]
-        if (p.a_mfast) {
-            constexpr int KSTEP = NTHREADS / BM;  // kk rows covered per pass (BM <= 256)
-            const int m = tid % BM;
-            const int gm = m0 + m;
+        const float* src = a_src + (int64_t)c0 * TT * p.w_st;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int kk = tid / BM + i * KSTEP;
-                const int kc = kk / TT, tap = kk - kc * TT;
-                const int c = c0 + kc;
-                float v = 0.0f;
-                if (gm < p.M && c < p.Ctot)
-                    v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? TT - 1 - tap : tap) * p.w_st];
-                areg[i] = v;
-            }
-        } else {
-            int m = tid / KT, kk = tid - m * KT;   // tid < 256: one division by a constant
-            constexpr int DM = NTHREADS / KT, DK = NTHREADS % KT;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int kc = kk / TT, tap = kk - kc * TT;
-                const int gm = m0 + m, c = c0 + kc;
-                float v = 0.0f;
-                if (gm < p.M && c < p.Ctot)
-                    v = p.wt[(int64_t)gm * p.w_sm + (int64_t)c * p.w_sk + (p.flip ? TT - 1 - tap : tap) * p.w_st];
-                areg[i] = v;
-                kk += DK; m += DM;
-                if (kk >= KT) { kk -= KT; ++m; }
-            }
-        }
+        for (int i = 0; i < NA; ++i)  // the last partial pass may read (never store) rows past the tile: the
+            areg[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)i * A_ROWS_PER_PASS * p.w_st);  // WPACK buffer has slack
         // B: raw values (prologue applied at LDS-store time)
         if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
@@ -238,21 +217,10 @@ __global__ void __launch_bounds__(NTHREADS) conv_igemm_kernel(const ConvP p) {
         return v;
     };
     auto commit = [&](int c0) {
-        if (p.a_mfast) {
-            constexpr int KSTEP = NTHREADS / BM;
-            const int m = tid % BM;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) As[(tid / BM + i * KSTEP) * AS + m] = areg[i];
-        } else {
-            int m = tid / KT, kk = tid - m * KT;
-            constexpr int DM = NTHREADS / KT, DK = NTHREADS % KT;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                As[kk * AS + m] = areg[i];
-                kk += DK; m += DM;
-                if (kk >= KT) { kk -= KT; ++m; }
-            }
-        }
+        for (int i = 0; i < NA; ++i)
+            if (A4 % NTHREADS == 0 || tid + NTHREADS * i < A4)
+                *reinterpret_cast<f32x4*>(As + (tid / (BM / 4) + i * A_ROWS_PER_PASS) * AS + 4 * (tid % (BM / 4))) = areg[i];
         if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
             const int j = tid % BN;
@@ -411,14 +379,14 @@ static int pick_bm(int M) {
     return best;
 }
 
-template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT>
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW = 2>
 static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;
-    constexpr int A_FLOATS = (KCH * TT * (BM + 1) + 3) & ~3;
+    constexpr int A_FLOATS = (KCH * TT * BM + 3) & ~3;
     p.n_mtiles = cdiv(p.M, BM);
     const size_t b_floats = (BMODE == BM_PIX) ? (size_t)KCH * BN : (size_t)KCH * p.CS;
     const size_t lds = (A_FLOATS + b_floats) * sizeof(float);
-    auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT>;
+    auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -479,7 +447,11 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     const int T = p.KH * p.KW;
     p.Ctot = p.C1 + p.C2;
     p.HW = p.H * p.W;
-    p.a_mfast = p.w_sm < p.w_sk;
+    p.a_mfast = 1;
+    if (p.w_sm != 1 || p.flip || (p.w_st & 3) || p.w_sk != T * p.w_st || p.w_st < ((p.M + 127) / 128) * 128) {
+        set_error("conv: weights must be in the WEIGHT_PACK layout (W_SM=1, W_ST=MP, W_SK=T*MP, FLIP=0)");
+        return S2K_EINVAL;
+    }
     p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
     p.n_tiles = p.n_mtiles = 0;
     if (!p.x1 || !p.wt || !p.y || p.B <= 0 || p.C1 <= 0 || p.M <= 0 || p.H <= 0 || p.W <= 0) {
@@ -537,7 +509,7 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     }
     // thin layers (M <= 32, full-resolution maps): 32 x 1024 tiles amortise the halo (6 rows per 4)
     if (p.S == 1 && cdiv64(out_px, 1024) >= 200 && geom(1024, 7 * NTHREADS))
-        return launch_cfg<BM_SPATIAL, 9, 1, 8, 1, 4, 8, 7>(p, (int)tiles, st);
+        return launch_cfg<BM_SPATIAL, 9, 1, 8, 1, 4, 8, 7, 1>(p, (int)tiles, st);
     if (!geom(256, 4 * NTHREADS)) { set_error("conv: halo tile does not fit"); return S2K_EINVAL; }
     return launch_cfg<BM_SPATIAL, 9, 1, 2, 1, 4, 8, 4>(p, (int)tiles, st);
 }

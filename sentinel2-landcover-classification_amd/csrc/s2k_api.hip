@@ -26,6 +26,7 @@ int launch_dwconv_fwd(const S2kOp&, const Ctx&);
 int launch_dwconv_dgrad(const S2kOp&, const Ctx&);
 int launch_dwconv_wgrad(const S2kOp&, const Ctx&);
 int launch_axpy(const S2kOp&, const Ctx&);
+int launch_weight_pack(const S2kOp&, const Ctx&);
 int launch_wgrad_finalize(const S2kOp&, const Ctx&);
 int launch_bn_finalize(const S2kOp&, const Ctx&);
 int launch_se_pool(const S2kOp&, const Ctx&);
@@ -55,7 +56,7 @@ static int launch_memset(const S2kOp& op, const Ctx& c) {
 }
 
 static const char* const kNames[S2K_N_KINDS + 1] = {
-    nullptr, "MEMSET", "AXPY", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
+    nullptr, "MEMSET", "AXPY", "WEIGHT_PACK", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
     "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
     "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX"};
 
@@ -63,6 +64,7 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
     switch (op.kind) {
         case S2K_OP_MEMSET: return launch_memset(op, c);
         case S2K_OP_AXPY: return launch_axpy(op, c);
+        case S2K_OP_WEIGHT_PACK: return launch_weight_pack(op, c);
         case S2K_OP_CONV: return launch_conv(op, c);
         case S2K_OP_WGRAD: return launch_wgrad(op, c);
         case S2K_OP_WGRAD_FINALIZE: return launch_wgrad_finalize(op, c);

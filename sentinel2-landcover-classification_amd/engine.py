@@ -25,7 +25,8 @@ class UnetEngine:
         pad = 256
         self.ws = torch.empty(plan.ws_bytes + pad, dtype=torch.uint8, device=device)
         self.aux = torch.zeros(max(plan.aux_bytes, 8) + pad, dtype=torch.uint8, device=device)
-        self.const = torch.tensor(plan.const_table if plan.const_table else [[0] * 5], dtype=torch.int32, device=device)
+        self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
+        self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)  # + slack: A-tile loads may overrun
         self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
         self.n_noise_rows = plan.n_noise_rows
         self.B = B
@@ -33,7 +34,7 @@ class UnetEngine:
 
     def bases(self, module, x, out, dout=None, noise=None, grads=None) -> _lib.Bases:
         b = _lib.Bases()
-        b.set("WS", self.ws).set("AUX", self.aux).set("CONST", self.const)
+        b.set("WS", self.ws).set("AUX", self.aux).set("CONST", self.const).set("WPACK", self.wpack)
         b.set("PARAMS", module._flat_params).set("BUFS", module._flat_bufs)
         b.set("X", x).set("OUT", out)
         if self.wgs is not None:

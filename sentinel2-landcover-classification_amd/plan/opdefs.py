@@ -18,7 +18,7 @@ OP_BYTES = 8 + 8 * N_T + 8 * N_N + 4 * N_D + 4 * N_F
 assert OP_BYTES == 256
 
 # ---- bases -------------------------------------------------------------------------------
-BASES = ["WS", "PARAMS", "GRADS", "BUFS", "X", "OUT", "DOUT", "NOISE", "WGS", "CONST", "Y", "AUX"]
+BASES = ["WS", "PARAMS", "GRADS", "BUFS", "X", "OUT", "DOUT", "NOISE", "WGS", "CONST", "Y", "AUX", "WPACK"]
 BASE = {n: i for i, n in enumerate(BASES)}
 
 # ---- statistics replicas -------------------------------------------------------------------------
@@ -41,9 +41,15 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "MEMSET": (["DST"], ["BYTES"], [], []),
     # Y[i] += X[i], COUNT floats
     "AXPY": (["X", "Y"], ["COUNT"], [], []),
+    # Pack weights for the implicit GEMM: for every TABLE row {src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP,
+    # start}:  DST[dst_off + (kc*T + tap)*MP + m] = SRC[src_off + m*s_m + kc*s_k + (flip ? T-1-tap : tap)*s_t]
+    # for m < M, kc < K, zero in the padding (MP = M rounded up to 128, KP = K rounded up to 32), so the
+    # conv kernel copies A tiles with aligned 16-byte loads and needs no bounds checks.  Runs once per step.
+    "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL"], ["N_ENTRIES"], []),
     # Implicit-GEMM convolution on f32 MFMA (fwd conv / convT fwd / conv dgrad / convT dgrad):
     #   Y[b][m][yo][xo] (+)= BIAS[m] + sum_{c,ky,kx} Wv[m][c][ky][kx] * Xpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
-    # with Wv[m][c][tap] = WT[m*W_SM + c*W_SK + (FLIP ? T-1-tap : tap)*W_ST]; c runs over X1's C1
+    # with Wv[m][c][tap] = WT[m*W_SM + c*W_SK + (FLIP ? T-1-tap : tap)*W_ST] (the HIP kernel requires the
+    # WEIGHT_PACK layout: W_SM = 1, W_ST = MP, W_SK = T*MP, FLIP = 0); c runs over X1's C1
     # channels then X2's C2 (channel concat without materialising it); Xpro = prologue(X, BNV, GATE).
     # MODE_CONVT_SCATTER: rows m = (co,dy,dx), stored to Y[b][co][2y+dy][2x+dx] (ConvTranspose k2 s2).
     # MODE_GATHER2X2: pseudo-channel k = (co,dy,dx) of X1 reads X1[b][co][2y+dy][2x+dx].

@@ -119,12 +119,13 @@ class UnetPlan:
     bwd: Program | None
     ws_bytes: int
     aux_bytes: int
-    const_table: list           # int32 rows for WGRAD_FINALIZE
+    const_table: list           # int32 blob of the CONST base (WEIGHT_PACK / WGRAD_FINALIZE tables)
     layout: ParamLayout
     n_noise_rows: int
     bwd_param_marks: list       # (op index in bwd, lowest float offset whose grads are final after it)
     logits_shape: tuple
     tensors: dict               # debug: name -> TRef
+    wpack_bytes: int = 0        # packed-weight scratch (WPACK base)
 
 
 class _P:
@@ -141,6 +142,20 @@ class _P:
         self.table_total = 0
         self.tensors: dict = {}
         self.marks: list = []
+        self.wpack = Arena(D.BASE["WPACK"])
+        self.pack_rows = {"fwd": [], "bwd": []}
+
+    def pack_weight(self, which: str, wname: str, M: int, K: int, T: int, s_m: int, s_k: int, s_t: int, flip: int,
+                    src_elem_off: int = 0):
+        """Schedule W -> padded K-major copy for the implicit GEMM; returns (packed ref, MP)."""
+        MP = (M + 127) // 128 * 128
+        KP = (K + 31) // 32 * 32
+        off, _ = self.layout.params[wname]
+        dst = self.wpack.alloc(f"pack:{which}:{wname}:{src_elem_off}", (KP * T, MP))
+        rows = self.pack_rows[which]
+        start = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9] if rows else 0
+        rows.append([off + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip, MP, KP, start])
+        return dst, MP
 
     # -- references into the flat parameter / grad / buffer bases --------------------------
     def param(self, name) -> TRef:
@@ -243,11 +258,12 @@ def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: i
             assert stride == 1, "dgrad of strided dense conv is never needed on this path"
             g = p.grad_of(s, f"{wname}.src{i}")
             # dX[b][c][y][x] = sum_{m,tap} W[m][c_off+c][flip(tap)] * dY[b][m][y+ky-(k-1-pt)][...]
+            wp, MP = p.pack_weight("bwd", wname, s.C, M, T, T, Ctot * T, 1, 1, src_elem_off=c_off * T)
             p.bwd.add("CONV", X1=dY, BNV1=None, GATE1=None, X2=None, BNV2=None,
-                      WT=p.param(wname).at(c_off * T), BIAS=None, Y=g, STATS=None,
+                      WT=wp, BIAS=None, Y=g, STATS=None,
                       B=B, C1=M, C2=0, H=Ho, W=Wo, M=s.C, KH=k, KW=k, STRIDE=1,
                       PAD_T=k - 1 - pt, PAD_L=k - 1 - pl, HO=s.H, WO=s.W, PRO1=D.PRO_NONE, PRO2=D.PRO_NONE,
-                      MODE=D.MODE_CONV, W_SM=T, W_SK=Ctot * T, W_ST=1, FLIP=1, BETA=int(s.grad_init), YC=s.C)
+                      MODE=D.MODE_CONV, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(s.grad_init), YC=s.C, NREP=1)
             s.grad_init = True
         c_off += s.C
 
@@ -263,11 +279,12 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
     s2 = srcs[1] if len(srcs) > 1 else None
     Ctot = sum(s.C for s in srcs)
     T = k * k
+    wp, MP = p.pack_weight("fwd", wname, M, Ctot, T, Ctot * T, T, 1, 0)
     p.fwd.add("CONV", X1=s1.raw, BNV1=s1.bnv, GATE1=s1.gate, X2=s2.raw if s2 else None,
-              BNV2=s2.bnv if s2 else None, WT=p.param(wname), BIAS=p.param(bias) if bias else None, Y=y,
+              BNV2=s2.bnv if s2 else None, WT=wp, BIAS=p.param(bias) if bias else None, Y=y,
               STATS=stats, B=B, C1=s1.C, C2=s2.C if s2 else 0, H=s1.H, W=s1.W, M=M, KH=k, KW=k, STRIDE=stride,
               PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO1=s1.pro, PRO2=s2.pro if s2 else 0, MODE=D.MODE_CONV,
-              W_SM=Ctot * T, W_SK=T, W_ST=1, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
+              W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
     if s2 is not None:
         assert s2.gate is None
     bnv = _bn_forward(p, bnprefix, y, M, B * Ho * Wo, stats, eps, mom)
@@ -293,9 +310,10 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
     H, W = src.H, src.W
     y = p.alloc("y:" + wname, (B, M, H, W))
     stats = _stats(p, "stats:" + bnprefix, M) if p.training else None
-    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=p.param(wname), BIAS=None,
+    wp, MP = p.pack_weight("fwd", wname, M, src.C, 1, src.C, 1, 1, 0)
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=wp, BIAS=None,
               Y=y, STATS=stats, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
-              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1, FLIP=0, BETA=0, YC=M,
+              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=M,
               NREP=D.stats_replicas(M))
     bnv = _bn_forward(p, bnprefix, y, M, B * H * W, stats, eps, mom)
     xout = p.alloc(f"x:block{idx}", (B, M, H, W))
@@ -393,10 +411,11 @@ def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
     """nn.ConvTranspose2d(k=2, s=2, bias) as one GEMM with M = (co,dy,dx) and an interleaved store."""
     B, Cin, H, W = p.B, src.C, src.H, src.W
     u = p.alloc("u:" + wname, (B, Cout, 2 * H, 2 * W))
-    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=p.param(wname),
+    wp, MP = p.pack_weight("fwd", wname, 4 * Cout, Cin, 1, 1, 4 * Cout, 1, 0)
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=wp,
               BIAS=p.param(bname), Y=u, STATS=None, B=B, C1=Cin, C2=0, H=H, W=W, M=4 * Cout, KH=1, KW=1, STRIDE=1,
               PAD_T=0, PAD_L=0, HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONVT_SCATTER,
-              W_SM=1, W_SK=4 * Cout, W_ST=1, FLIP=0, BETA=0, YC=Cout)
+              W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=Cout, NREP=1)
     out = Act(u, Cout, 2 * H, 2 * W)
 
     def backward():
@@ -409,10 +428,11 @@ def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
         if src.needs_grad:
             g = p.grad_of(src, wname + ".src")
             # dX[b][ci][y][x] = sum_{k=(co,dy,dx)} W[ci][k] * G[b][co][2y+dy][2x+dx]
-            p.bwd.add("CONV", X1=G, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=p.param(wname), BIAS=None, Y=g,
+            wp, MP = p.pack_weight("bwd", wname, Cin, 4 * Cout, 1, 4 * Cout, 1, 1, 0)
+            p.bwd.add("CONV", X1=G, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=g,
                       STATS=None, B=B, C1=4 * Cout, C2=0, H=H, W=W, M=Cin, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
-                      HO=H, WO=W, PRO1=D.PRO_NONE, PRO2=0, MODE=D.MODE_GATHER2X2, W_SM=4 * Cout, W_SK=1, W_ST=1,
-                      FLIP=0, BETA=int(src.grad_init), YC=Cin)
+                      HO=H, WO=W, PRO1=D.PRO_NONE, PRO2=0, MODE=D.MODE_GATHER2X2, W_SM=1, W_SK=MP, W_ST=MP,
+                      FLIP=0, BETA=int(src.grad_init), YC=Cin, NREP=1)
             src.grad_init = True
 
     p.tape.append(backward)
@@ -422,10 +442,11 @@ def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
 def out_conv(p: _P, wname: str, bname: str, src: Act, M: int) -> TRef:
     B, H, W = p.B, src.H, src.W
     logits = TRef(D.BASE["OUT"], 0, (B, M, H, W), "f32", "logits")
-    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=None, X2=None, BNV2=None, WT=p.param(wname),
+    wp, MP = p.pack_weight("fwd", wname, M, src.C, 1, src.C, 1, 1, 0)
+    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=None, X2=None, BNV2=None, WT=wp,
               BIAS=p.param(bname), Y=logits, STATS=None, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1,
-              PAD_T=0, PAD_L=0, HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=src.C, W_SK=1, W_ST=1,
-              FLIP=0, BETA=0, YC=M)
+              PAD_T=0, PAD_L=0, HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP,
+              FLIP=0, BETA=0, YC=M, NREP=1)
 
     def backward():
         dY = TRef(D.BASE["DOUT"], 0, (B, M, H, W), "f32", "dlogits")
@@ -554,6 +575,26 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
                   bias=pre + ".3.bias")
     logits = out_conv(p, "out_conv1x1.weight", "out_conv1x1.bias", cur, spec.num_classes)
 
+    # ---- constant tables (int32 blob in the CONST base) ------------------------------------------------
+    blob: list[int] = []
+
+    def table(rows, width):
+        off = len(blob) * 4
+        for r in rows:
+            assert len(r) == width
+            blob.extend(int(v) for v in r)
+        while len(blob) % 4:
+            blob.append(0)
+        return TRef(D.BASE["CONST"], off, (len(rows), width), "i32")
+
+    def pack_op(prog: Program, rows):
+        if not rows:
+            return
+        total = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9]
+        prog.ops.insert(0, ("WEIGHT_PACK", dict(TABLE=table(rows, 12), SRC=TRef(D.BASE["PARAMS"], 0, (layout.n_params,)),
+                                                DST=TRef(D.BASE["WPACK"], 0, (p.wpack.mark() // 4,)), TOTAL=total,
+                                                N_ENTRIES=len(rows))))
+
     fwd_aux_end = p.aux.mark()
     if training and fwd_aux_end:
         p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
@@ -569,10 +610,12 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
             pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
                                            BYTES=bwd_aux_end - fwd_aux_end)))
         p.bwd.ops[0:0] = pre_ops
-        p.bwd.add("WGRAD_FINALIZE", TABLE=TRef(D.BASE["CONST"], 0, (len(p.table), 5), "i32"),
+        p.bwd.add("WGRAD_FINALIZE", TABLE=table(p.table, 5),
                   WGS=TRef(D.BASE["WGS"], 0, (layout.n_params,)), GRADS=TRef(D.BASE["GRADS"], 0, (layout.n_params,)),
                   TOTAL=p.table_total, N_ENTRIES=len(p.table))
+        pack_op(p.bwd, p.pack_rows["bwd"])
         bwd = p.bwd
+    pack_op(p.fwd, p.pack_rows["fwd"])
 
-    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.table, layout, n,
-                    [], (B, spec.num_classes, H, W), p.tensors)
+    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), blob, layout, n,
+                    [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

@@ -31,7 +31,8 @@ def make_bases(plan, flat_params, flat_bufs, x, noise, n_out, wide: bool = False
         D.BASE["OUT"]: _bytes(torch.zeros(n_out, dtype=fd)),
         D.BASE["DOUT"]: _bytes(torch.zeros(n_out, dtype=fd)),
         D.BASE["NOISE"]: _bytes(noise.clone().to(fd)),
-        D.BASE["CONST"]: _bytes(torch.tensor(plan.const_table if plan.const_table else [[0] * 5], dtype=torch.int32)),
+        D.BASE["CONST"]: _bytes(torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32)),
+        D.BASE["WPACK"]: torch.zeros(k * pad8(plan.wpack_bytes) + 64, dtype=torch.uint8),
     }
     # poison the workspace so that reads of never-written memory show up as NaN
     bases[D.BASE["WS"]][: k * pad8(plan.ws_bytes)].view(fd).fill_(float("nan"))

@@ -51,11 +51,25 @@ class Case:
         invstd = torch.rand(C, generator=self.gen) + 0.7
         return self.t(name, (4, C), torch.stack([scale, shift, mean, invstd]))
 
-    def run(self, kind, outputs, tol=1e-4, sum0=(), **fields):
-        """sum0: outputs compared after summing their leading (statistics-replica) dimension."""
+    def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0):
+        """WEIGHT_PACK record for one weight tensor living in this arena; returns (pre-op, packed ref, MP)."""
+        MP, KP = (M + 127) // 128 * 128, (K + 31) // 32 * 32
+        dst = self.t(f"packed{len(self.items)}", (KP * T, MP), "nan")
+        row = [wt.off // 4 + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip, MP, KP, 0]
+        tab = self.t(f"packtab{len(self.items)}", (1, 12), torch.tensor([row]), "i32")
+        zero = self.arena.alloc("zero", (1,))  # offsets in the table are relative to SRC / DST = arena start
+        pre = ("WEIGHT_PACK", dict(TABLE=tab, SRC=zero.at(-(zero.off // 4)), DST=zero.at(-(zero.off // 4)),
+                                   TOTAL=KP * T * MP, N_ENTRIES=1))
+        return pre, dst, MP
+
+    def run(self, kind, outputs, tol=1e-4, sum0=(), pre=(), **fields):
+        """sum0: outputs compared after summing their leading (statistics-replica) dimension.
+        pre: stage records to run first (e.g. WEIGHT_PACK)."""
         from s2lc_amd import _lib
 
         prog = Program()
+        for k, f in pre:
+            prog.add(k, **f)
         prog.add(kind, **fields)
         packed = prog.pack()
         cpu = torch.zeros(self.arena.top + 256, dtype=torch.uint8)
@@ -125,9 +139,10 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     nrep = D.stats_replicas(M)
     st_ref = c.t("stats", (nrep, 2, M), "zeros", "f64") if stats else None
     outs = ["y"] + (["stats"] if stats else [])
-    c.run("CONV", outs, tol, sum0=("stats",), NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wt, BIAS=bs, Y=y, STATS=st_ref,
-          B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo,
-          PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=sm, W_SK=sk, W_ST=st, FLIP=flip, BETA=beta, YC=YC)
+    pre, wp, MP = c.pack(wt, M, Ct, T, sm, sk, st, flip)
+    c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
+          BIAS=bs, Y=y, STATS=st_ref, B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho,
+          WO=Wo, PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=beta, YC=YC)
 
 
 @pytest.mark.parametrize("B,C1,H,W,M,pro,gate", [
@@ -178,9 +193,10 @@ def test_conv_dgrad_3x3_flip(beta):
     dy = c.t("x1", (B, Mout, H, W))
     wfull = c.t("wt_full", (Mout, Ctot, 9), scale=0.1)
     y = c.t("y", (B, Cs, H, W), "randn" if beta else "nan")
-    c.run("CONV", ["y"], 1e-4, X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wfull.at(c_off * 9), BIAS=None, Y=y,
+    pre, wp, MP = c.pack(wfull, Cs, Mout, 9, 9, Ctot * 9, 1, 1, src_elem_off=c_off * 9)
+    c.run("CONV", ["y"], 1e-4, pre=[pre], X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=y,
           STATS=None, B=B, C1=Mout, C2=0, H=H, W=W, M=Cs, KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=W, PRO1=0,
-          PRO2=0, MODE=0, W_SM=9, W_SK=Ctot * 9, W_ST=1, FLIP=1, BETA=beta, YC=Cs)
+          PRO2=0, MODE=0, W_SM=1, W_SK=9 * MP, W_ST=MP, FLIP=0, BETA=beta, YC=Cs, NREP=1)
 
 
 def test_conv_dgrad_1x1_and_gather():
