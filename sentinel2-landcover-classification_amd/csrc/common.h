@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/s2k.h"
 
 namespace s2k {
@@ -25,6 +27,25 @@ __device__ __forceinline__ float apply_pro(float v, int pro, float scale, float 
     return v;
 }
 
+// compile-time activation: lets a kernel hoist the (launch-uniform) prologue kind out of its unrolled
+// element loops instead of branching per element
+template <int PRO>
+__device__ __forceinline__ float apply_pro_c(float v, float scale, float shift) {
+    if (PRO == S2K_PRO_NONE) return v;
+    const float u = fmaf(v, scale, shift);
+    if (PRO == S2K_PRO_SILU) return silu_f(u);
+    if (PRO == S2K_PRO_RELU) return fmaxf(u, 0.0f);
+    return u;
+}
+// call f(std::integral_constant<int, pro>) for the runtime value `pro`
+template <typename F>
+__device__ __forceinline__ void dispatch_pro(int pro, F&& f) {
+    if (pro == S2K_PRO_NONE) f(std::integral_constant<int, S2K_PRO_NONE>{});
+    else if (pro == S2K_PRO_SILU) f(std::integral_constant<int, S2K_PRO_SILU>{});
+    else if (pro == S2K_PRO_RELU) f(std::integral_constant<int, S2K_PRO_RELU>{});
+    else f(std::integral_constant<int, S2K_PRO_AFFINE>{});
+}
+
 // d act(u) / du for act in {none, silu, relu}
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (act == S2K_PRO_SILU) {
@@ -33,6 +54,25 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     }
     if (act == S2K_PRO_RELU) return u > 0.0f ? 1.0f : 0.0f;
     return 1.0f;
+}
+
+// ---- bounds-checked buffer loads ----------------------------------------------------------------------
+// Operand tiles that hang over a tensor edge are fetched through a buffer descriptor sized to the tensor:
+// the hardware returns 0 for any offset beyond it, so the stagers keep ONE affine address stream (base +
+// i*stride, 32-bit offsets) with no per-row clamping and no branch around any load.
+// IMPORTANT: invalid elements are expressed as an out-of-range OFFSET (BUF_OOB), never as
+// `cond ? load : 0` — hipcc sinks a load under a select into a branch and then waits for each one.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t BUF_OOB = 0x7ffffff0u;   // >= any descriptor size we create (tensors are < 2 GiB, checked on the host)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes), 0x00020000);
+}
+__device__ __forceinline__ float bload(rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float2 bload2(rsrc_t r, uint32_t byte_off) {
+    auto v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+    return make_float2(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]));
 }
 
 // ---- reductions -------------------------------------------------------------------------------

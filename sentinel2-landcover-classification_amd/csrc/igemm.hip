@@ -31,7 +31,7 @@ struct ConvP {
     double* stats;
     int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
     int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC, nrep;
-    int Ctot, n_mtiles, n_tiles, HW, Ntot, a_mfast;
+    int Ctot, n_mtiles, n_tiles, HW, Ntot, a_mfast, b_floats;
     int R, XW, tiles_x, tiles_y, IR, IC, WS, CS;
 };
 
@@ -57,6 +57,11 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + A_FLOATS;
+    // BatchNorm scale/shift of every (concat) input channel, staged once: the commit step below must
+    // not contain loads behind branches (each would be a dependent L2 round trip per element)
+    float* ssc = Bs + p.b_floats;   // [Ctot] scale
+    float* ssh = ssc + p.Ctot;      // [Ctot] shift
+    const bool has_pro = true;  // ssc/ssh are always staged (scale 1, shift 0 where a source has no prologue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wm0 = (wave / WVN) * (WM * 32);
@@ -142,6 +147,13 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         st_gate = sb * p.C1;
     }
 
+    // bounds-checked descriptors of the activation sources (+ the SE gate; zero-sized when absent)
+    const int64_t x1_elems = gather ? (int64_t)p.B * (p.C1 / 4) * 4 * p.HW : (int64_t)p.B * p.C1 * p.H * p.W;
+    const rsrc_t rx1 = make_rsrc(p.x1, x1_elems * 4);
+    const rsrc_t rx2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (int64_t)p.B * p.C2 * p.H * p.W * 4 : 0);
+    const rsrc_t rgt = make_rsrc(p.gate1 ? p.gate1 : p.x1, p.gate1 ? (int64_t)p.B * p.C1 * 4 : 0);
+    const uint32_t st_voff1 = (uint32_t)st_off1 * 4u, st_voff2 = (uint32_t)st_off2 * 4u, st_cs4 = (uint32_t)st_cstride * 4u;
+
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -156,6 +168,16 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
 
     f32x4 areg[NA];
     float breg[NB];
+    float greg[(BMODE == BM_PIX) ? NB : 1];   // SE gate of the fetched elements (1x1 project conv only)
+    if (has_pro) {
+        for (int c = tid; c < p.Ctot; c += NTHREADS) {
+            float sc = 1.0f, sh = 0.0f;
+            if (c < p.C1) { if (p.pro1 != S2K_PRO_NONE) { sc = p.bnv1[c]; sh = p.bnv1[p.C1 + c]; } }
+            else if (p.pro2 != S2K_PRO_NONE) { sc = p.bnv2[c - p.C1]; sh = p.bnv2[p.C2 + c - p.C1]; }
+            ssc[c] = sc;
+            ssh[c] = sh;
+        }
+    }
     // A tile = rows [c0*TT, c0*TT + KT) x columns [m0, m0 + BM) of the packed weights (WEIGHT_PACK: row
     // stride w_st = MP, zero padded in both directions): affine 16-byte loads, no bounds checks
     const float* a_src = p.wt + (int64_t)(tid / (BM / 4)) * p.w_st + m0 + 4 * (tid % (BM / 4));
@@ -167,25 +189,21 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
 #pragma unroll
         for (int i = 0; i < NA; ++i)  // the last partial pass may read (never store) rows past the tile: the
             areg[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)i * A_ROWS_PER_PASS * p.w_st);  // WPACK buffer has slack
-        // B: raw values (prologue applied at LDS-store time)
+        // B: raw values (prologue applied at LDS-store time) through bounds-checked buffer loads: invalid
+        // elements are an out-of-range OFFSET (hardware returns 0), so every load is unconditional and all
+        // of a chunk's loads are in flight together
         if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
+            const int kc0 = __builtin_amdgcn_readfirstlane(tid / BN);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int kc = tid / BN + i * KSTEP;
-                const int c = c0 + kc;
-                float v = 0.0f;
-                if (st_valid && c < p.Ctot) {
-                    if (gather) {
-                        const int co = c >> 2, dy = (c >> 1) & 1, dx = c & 1;
-                        v = p.x1[st_off1 + (int64_t)co * 4 * p.HW + dy * (2 * p.W) + dx];
-                    } else if (c < p.C1) {
-                        v = p.x1[st_off1 + (int64_t)c * st_cstride];
-                    } else {
-                        v = p.x2[st_off2 + (int64_t)(c - p.C1) * st_cstride];
-                    }
-                }
-                breg[i] = v;
+                const int c = c0 + kc0 + i * KSTEP;
+                const bool ok = st_valid && c < p.Ctot;
+                uint32_t off;
+                if (gather) off = st_voff1 + (uint32_t)(c >> 2) * 16u * p.HW + ((c >> 1) & 1) * 8u * p.W + (c & 1) * 4u;
+                else off = (c < p.C1) ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
+                breg[i] = bload((gather || c < p.C1) ? rx1 : rx2, ok ? off : BUF_OOB);
+                greg[(BMODE == BM_PIX) ? i : 0] = bload(rgt, (ok && c < p.C1) ? (uint32_t)(st_gate + c) * 4u : BUF_OOB);
             }
         } else {
 #pragma unroll
@@ -193,60 +211,96 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 const int c = c0 + kc;
                 const bool cok = c < p.Ctot;
                 const bool first = c < p.C1;
-                const float* src = first ? p.x1 + st_off1 + (int64_t)c * st_cstride
-                                         : p.x2 + st_off2 + (int64_t)(c - p.C1) * st_cstride;
+                const uint32_t cbase = first ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
+                const rsrc_t rr = first ? rx1 : rx2;
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) {
                     const int g = sp_goff[(BMODE == BM_SPATIAL) ? i : 0];
-                    breg[kc * EPT + i] = (cok && g >= 0) ? src[g] : 0.0f;
+                    breg[kc * EPT + i] = bload(rr, (cok && g >= 0) ? cbase + (uint32_t)g * 4u : BUF_OOB);
                 }
             }
         }
     };
 
     // ---------------- registers -> LDS (B gets the BN/activation/gate prologue here) ---------------
-    auto prologue = [&](float v, int c, bool inb) -> float {
-        if (!inb) return 0.0f;  // zero padding is applied AFTER the activation (reference pads activated maps)
-        if (c < p.C1) {
-            if (p.pro1 != S2K_PRO_NONE) v = apply_pro(v, p.pro1, p.bnv1[c], p.bnv1[p.C1 + c]);
-            if (p.gate1) v *= p.gate1[st_gate + c];
-        } else {
-            const int c2 = c - p.C1;
-            if (p.pro2 != S2K_PRO_NONE) v = apply_pro(v, p.pro2, p.bnv2[c2], p.bnv2[p.C2 + c2]);
-        }
-        return v;
-    };
+    // branch-free per element: parameters come from LDS, validity is a final select (zero padding is
+    // applied AFTER the activation: the reference pads activated maps)
     auto commit = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             if (A4 % NTHREADS == 0 || tid + NTHREADS * i < A4)
                 *reinterpret_cast<f32x4*>(As + (tid / (BM / 4) + i * A_ROWS_PER_PASS) * AS + 4 * (tid % (BM / 4))) = areg[i];
-        if (BMODE == BM_PIX) {
-            constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
-            const int j = tid % BN;
+        // the prologue kind is launch-uniform: dispatch once, outside the unrolled element loops (a concat
+        // of two differently-activated sources falls back to the affine+select form per source)
+        const int pro_u = (p.C2 > 0 && p.pro2 != p.pro1) ? -1 : p.pro1;
+        auto body = [&](auto tag) {
+            constexpr int PRO = decltype(tag)::value;
+            if (BMODE == BM_PIX) {
+                constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
+                const int j = tid % BN;
+                const int kc0 = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform (BN >= 64)
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int kc = tid / BN + i * KSTEP;
-                const int c = c0 + kc;
-                float v = breg[i];
-                if (!gather) v = prologue(v, c, st_valid && c < p.Ctot);
-                Bs[kc * BN + j] = v;
+                for (int i = 0; i < NB; ++i) {
+                    const int kc = kc0 + i * KSTEP;
+                    const int c = c0 + kc;
+                    const int cc = c < p.Ctot ? c : p.Ctot - 1;
+                    float v = breg[i];
+                    if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, ssc[cc], ssh[cc]);
+                    if (p.gate1) v *= greg[(BMODE == BM_PIX) ? i : 0];
+                    Bs[kc * BN + j] = (st_valid && c < p.Ctot) ? v : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) {
+                    const int c = c0 + kc;
+                    const bool cok = c < p.Ctot;
+                    const int cc = cok ? c : p.Ctot - 1;
+                    float sc = 1.0f, sh = 0.0f;
+                    if (PRO != S2K_PRO_NONE) { sc = ssc[cc]; sh = ssh[cc]; }
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) {
+                        const int e = tid + NTHREADS * i;
+                        float v = breg[kc * EPT + i];
+                        if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, sc, sh);
+                        v = (cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0) ? v : 0.0f;
+                        if (e < used_sp) Bs[kc * p.CS + e] = v;
+                    }
+                }
             }
-        } else {
+        };
+        if (pro_u >= 0) {
+            dispatch_pro(pro_u, body);
+        } else {  // mixed concat (not produced by the planner today): generic per-element form
+            if (BMODE == BM_PIX) {
+                constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
+                const int j = tid % BN;
 #pragma unroll
-            for (int kc = 0; kc < KCH; ++kc) {
-                const int c = c0 + kc;
-                const bool cok = c < p.Ctot;
+                for (int i = 0; i < NB; ++i) {
+                    const int kc = tid / BN + i * KSTEP;
+                    const int c = c0 + kc;
+                    const int cc = c < p.Ctot ? c : p.Ctot - 1;
+                    float v = apply_pro(breg[i], cc < p.C1 ? p.pro1 : p.pro2, ssc[cc], ssh[cc]);
+                    if (p.gate1) v *= greg[(BMODE == BM_PIX) ? i : 0];
+                    Bs[kc * BN + j] = (st_valid && c < p.Ctot) ? v : 0.0f;
+                }
+            } else {
+                for (int kc = 0; kc < KCH; ++kc) {
+                    const int c = c0 + kc;
+                    const bool cok = c < p.Ctot;
+                    const int cc = cok ? c : p.Ctot - 1;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int e = tid + NTHREADS * i;
-                    if (e < used_sp)
-                        Bs[kc * p.CS + e] = prologue(breg[kc * EPT + i], c, cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0);
+                    for (int i = 0; i < EPT; ++i) {
+                        const int e = tid + NTHREADS * i;
+                        float v = apply_pro(breg[kc * EPT + i], cc < p.C1 ? p.pro1 : p.pro2, ssc[cc], ssh[cc]);
+                        v = (cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0) ? v : 0.0f;
+                        if (e < used_sp) Bs[kc * p.CS + e] = v;
+                    }
                 }
             }
         }
     };
 
+    __syncthreads();  // ssc / ssh staged
     fetch(0);
     commit(0);
     __syncthreads();
@@ -385,7 +439,9 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr int A_FLOATS = (KCH * TT * BM + 3) & ~3;
     p.n_mtiles = cdiv(p.M, BM);
     const size_t b_floats = (BMODE == BM_PIX) ? (size_t)KCH * BN : (size_t)KCH * p.CS;
-    const size_t lds = (A_FLOATS + b_floats) * sizeof(float);
+    p.b_floats = (int)b_floats;
+    const size_t lds = (A_FLOATS + b_floats + 2 * (size_t)p.Ctot) * sizeof(float);
+    if (BMODE == BM_SPATIAL && p.gate1) { set_error("conv: SE gate is only supported on 1x1 convs"); return S2K_EINVAL; }
     auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW>;
     static bool attr_done = false;
     if (!attr_done) {

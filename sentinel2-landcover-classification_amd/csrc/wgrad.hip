@@ -41,7 +41,7 @@ __device__ __forceinline__ float ld_pro(const float* x, const float* bnv, const 
 // index arithmetic is left in the tile loop; the operands of tile i+1 are fetched into registers
 // before the MFMAs of tile i are issued and written to LDS after them (latency hidden under
 // 72..288 MFMAs per wave).
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ>
 __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BC = WN * WVN * 32;
@@ -53,6 +53,10 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [BM][PSTR]
     float* Qs = smem + BM * p.PSTR;      // [BC][CSQ]
+    float* psc = Qs + BC * p.CSQ;        // BatchNorm scale/shift of this workgroup's P rows / Q columns,
+    float* psh = psc + BM;               // staged once so that the commit step has no loads behind branches
+    float* qsc = psh + BM;
+    float* qsh = qsc + BC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wk = wave % WVK;
@@ -96,7 +100,26 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
 
+    // Operand loads are unconditional bounds-checked buffer loads (validity is a select afterwards): one
+    // affine 32-bit offset stream per operand, no branch around any load
+    const rsrc_t rp = make_rsrc(p.p, (int64_t)p.B * p.M * p.HWp * 4);
+    const rsrc_t rq = make_rsrc(p.q, (int64_t)p.B * p.C * p.HWq * 4);
+    const rsrc_t rg = make_rsrc(p.gateq ? p.gateq : p.q, p.gateq ? (int64_t)p.B * p.C * 4 : 0);
+    const uint32_t p_rstride = (uint32_t)RSTEP * p.HWp * 4u, q_rstride = (uint32_t)RSTEP * p.HWq * 4u;
     float preg[NPR], qreg[NQR];
+    float qgate[(MODE == WG_PIX) ? BC / RSTEP : 1];   // SE gate of the fetched Q elements (1x1 project conv)
+    for (int i = tid; i < BM; i += NTHREADS) {
+        const int gm = m0 + i;
+        const bool on = p.prop != S2K_PRO_NONE && gm < p.M;
+        psc[i] = on ? p.bnvp[gm] : 1.0f;
+        psh[i] = on ? p.bnvp[p.M + gm] : 0.0f;
+    }
+    for (int i = tid; i < BC; i += NTHREADS) {
+        const int gc = c0 + i;
+        const bool on = p.proq != S2K_PRO_NONE && gc < p.C;
+        qsc[i] = on ? p.bnvq[gc] : 1.0f;
+        qsh[i] = on ? p.bnvq[p.C + gc] : 0.0f;
+    }
     bool f_pok = false;           // the fetched tile's pixel slot is inside the image
     unsigned f_qok = 0;           // SPATIAL: bit i = halo slot i inside the image
     int f_b = 0;                  // image index of the fetched tile (gate rows)
@@ -111,28 +134,27 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int yo = y0 + pr, xo = x0 + pxx;
             f_b = b;
             f_pok = pj < np_sp && pxx < p.XW && yo < p.HO && xo < p.WO;
-            const float* psrc = p.p + ((int64_t)b * p.M + m0 + prow) * p.HWp + (int64_t)yo * p.WO + xo;
+            const uint32_t pbase = (uint32_t)(((int64_t)b * p.M + m0 + prow) * p.HWp + (f_pok ? yo * p.WO + xo : 0)) * 4u;
 #pragma unroll
             for (int i = 0; i < NPR; ++i)
-                preg[i] = (f_pok && m0 + prow + i * RSTEP < p.M) ? psrc[(int64_t)i * RSTEP * p.HWp] : 0.0f;
+                preg[i] = bload(rp, (f_pok && m0 + prow + i * RSTEP < p.M) ? pbase + i * p_rstride : BUF_OOB);
             const int iy0 = y0 * p.S - p.PT, ix0 = x0 * p.S - p.PL;
-            int goff[EPT];
+            uint32_t goff[EPT];
             f_qok = 0;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int iy = iy0 + qrr[i], ix = ix0 + qcc[i];
                 const bool ok = (tid + NTHREADS * i) < used_sp && qcc[i] < p.IC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                goff[i] = ok ? iy * p.W + ix : 0;
+                goff[i] = ok ? (uint32_t)(iy * p.W + ix) * 4u : BUF_OOB;
                 f_qok |= ok ? (1u << i) : 0u;
             }
-            const float* qsrc = p.q + ((int64_t)b * p.C + c0) * p.HWq;
+            const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0) * p.HWq) * 4u;
+            const uint32_t cstride = (uint32_t)p.HWq * 4u;
 #pragma unroll
-            for (int c = 0; c < BC; ++c) {
-                const bool cok = c0 + c < p.C;
+            for (int c = 0; c < BC; ++c)
 #pragma unroll
-                for (int i = 0; i < EPT; ++i)
-                    qreg[c * EPT + i] = (cok && ((f_qok >> i) & 1u)) ? qsrc[(int64_t)c * p.HWq + goff[i]] : 0.0f;
-            }
+                for (int i = 0; i < EPT; ++i)   // BUF_OOB + anything below 2^31 stays out of range -> 0
+                    qreg[c * EPT + i] = bload(rq, (c0 + c < p.C && goff[i] != BUF_OOB) ? qbase + c * cstride + goff[i] : BUF_OOB);
         } else {
             const int64_t ntot = (int64_t)p.B * p.HWp;
             const int64_t n = (int64_t)tile * NPJ + pj;
@@ -141,68 +163,46 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int b = (int)(nn / p.HWp);
             const int pp = (int)(nn - (int64_t)b * p.HWp);
             f_b = b;
-            const float* psrc = p.p + ((int64_t)b * p.M + m0 + prow) * p.HWp + pp;
+            const uint32_t pbase = (uint32_t)(((int64_t)b * p.M + m0 + prow) * p.HWp + pp) * 4u;
 #pragma unroll
             for (int i = 0; i < NPR; ++i)
-                preg[i] = (f_pok && m0 + prow + i * RSTEP < p.M) ? psrc[(int64_t)i * RSTEP * p.HWp] : 0.0f;
+                preg[i] = bload(rp, (f_pok && m0 + prow + i * RSTEP < p.M) ? pbase + i * p_rstride : BUF_OOB);
             if (MODE == WG_PIX) {
-                const float* qsrc = p.q + ((int64_t)b * p.C + c0 + prow) * p.HWq + pp;
-#pragma unroll
-                for (int i = 0; i < BC / RSTEP; ++i)
-                    qreg[i] = (f_pok && c0 + prow + i * RSTEP < p.C) ? qsrc[(int64_t)i * RSTEP * p.HWq] : 0.0f;
-            } else {  // GATHER: Q is [B][C][2HO][2WO]
-                const int yy = pp / p.WO, xx = pp - yy * p.WO;
-                const float* qsrc = p.q + ((int64_t)b * p.C + c0 + prow) * p.HWq + (int64_t)(2 * yy) * p.W + 2 * xx;
+                const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0 + prow) * p.HWq + pp) * 4u;
+                const uint32_t gbase = (uint32_t)((int64_t)b * p.C + c0 + prow) * 4u;
 #pragma unroll
                 for (int i = 0; i < BC / RSTEP; ++i) {
-                    float2 r0 = make_float2(0.f, 0.f), r1 = make_float2(0.f, 0.f);
-                    if (f_pok && c0 + prow + i * RSTEP < p.C) {
-                        const float* src = qsrc + (int64_t)i * RSTEP * p.HWq;
-                        r0 = *reinterpret_cast<const float2*>(src);
-                        r1 = *reinterpret_cast<const float2*>(src + p.W);
-                    }
-                    qreg[4 * i + 0] = r0.x; qreg[4 * i + 1] = r0.y; qreg[4 * i + 2] = r1.x; qreg[4 * i + 3] = r1.y;
+                    const bool ok = f_pok && c0 + prow + i * RSTEP < p.C;
+                    qreg[i] = bload(rq, ok ? qbase + i * q_rstride : BUF_OOB);
+                    qgate[(MODE == WG_PIX) ? i : 0] = bload(rg, ok ? gbase + i * RSTEP * 4u : BUF_OOB);  // 0-size descriptor without a gate
+                }
+            } else {  // GATHER: Q is [B][C][2HO][2WO]
+                const int yy = pp / p.WO, xx = pp - yy * p.WO;
+                const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0 + prow) * p.HWq + (int64_t)(2 * yy) * p.W + 2 * xx) * 4u;
+#pragma unroll
+                for (int i = 0; i < BC / RSTEP; ++i) {
+                    const bool ok = f_pok && c0 + prow + i * RSTEP < p.C;
+                    const uint32_t o = ok ? qbase + i * q_rstride : BUF_OOB, w4 = ok ? (uint32_t)p.W * 4u : 0u;
+                    qreg[4 * i + 0] = bload(rq, o); qreg[4 * i + 1] = bload(rq, o + 4u);
+                    qreg[4 * i + 2] = bload(rq, o + w4); qreg[4 * i + 3] = bload(rq, o + w4 + 4u);
                 }
             }
         }
     };
 
     // ---------------- registers -> LDS (prologues applied here; zero padding stays zero) ----------------
-    auto pro_p = [&](float v, int gm, bool ok) -> float {
-        if (!ok || gm >= p.M) return 0.0f;
-        if (p.prop != S2K_PRO_NONE) v = apply_pro(v, p.prop, p.bnvp[gm], p.bnvp[p.M + gm]);
-        if (p.gatep) v *= p.gatep[f_b * p.M + gm];
-        return v;
-    };
-    auto pro_q = [&](float v, int gc, bool ok) -> float {
-        if (!ok || gc >= p.C) return 0.0f;
-        if (p.proq != S2K_PRO_NONE) v = apply_pro(v, p.proq, p.bnvq[gc], p.bnvq[p.C + gc]);
-        if (p.gateq) v *= p.gateq[f_b * p.C + gc];
-        return v;
-    };
+    // branch-free per element: parameters from LDS, validity as a final select
     auto commit = [&]() {
         if (MODE != WG_SPATIAL || pj < np_sp) {
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
                 const int m = prow + i * RSTEP;
-                Ps[m * p.PSTR + pj] = pro_p(preg[i], m0 + m, f_pok);
+                float v = preg[i];
+                if (PROP != S2K_PRO_NONE) v = apply_pro_c<PROP>(v, psc[m], psh[m]);
+                Ps[m * p.PSTR + pj] = (f_pok && m0 + m < p.M) ? v : 0.0f;
             }
         }
-        if (MODE == WG_SPATIAL) {
-#pragma unroll
-            for (int c = 0; c < BC; ++c)
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int e = tid + NTHREADS * i;
-                    if (e < used_sp) Qs[c * p.CSQ + e] = pro_q(qreg[c * EPT + i], c0 + c, (f_qok >> i) & 1u);
-                }
-        } else if (MODE == WG_PIX) {
-#pragma unroll
-            for (int i = 0; i < BC / RSTEP; ++i) {
-                const int c = prow + i * RSTEP;
-                Qs[c * p.CSQ + pj] = pro_q(qreg[i], c0 + c, f_pok);
-            }
-        } else {
+        if (MODE == WG_GATHER) {
 #pragma unroll
             for (int i = 0; i < BC / RSTEP; ++i) {
                 float* dst = Qs + (prow + i * RSTEP) * p.CSQ + pj;
@@ -211,9 +211,33 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 dst[2 * NPJ] = qreg[4 * i + 2];
                 dst[3 * NPJ] = qreg[4 * i + 3];
             }
+        } else if (MODE == WG_SPATIAL) {
+#pragma unroll
+            for (int c = 0; c < BC; ++c) {
+                float sc = 1.0f, sh = 0.0f;
+                if (PROQ != S2K_PRO_NONE) { sc = qsc[c]; sh = qsh[c]; }
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = tid + NTHREADS * i;
+                    float v = qreg[c * EPT + i];
+                    if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, sc, sh);
+                    v = (c0 + c < p.C && ((f_qok >> i) & 1u)) ? v : 0.0f;
+                    if (e < used_sp) Qs[c * p.CSQ + e] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BC / RSTEP; ++i) {
+                const int c = prow + i * RSTEP;
+                float v = qreg[i];
+                if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, qsc[c], qsh[c]);
+                if (p.gateq) v *= qgate[(MODE == WG_PIX) ? i : 0];
+                Qs[c * p.CSQ + pj] = (f_pok && c0 + c < p.C) ? v : 0.0f;
+            }
         }
     };
 
+    __syncthreads();  // scale/shift staged
     if (tile_begin < tile_end) {
         fetch(tile_begin);
         commit();
@@ -293,14 +317,15 @@ static T* ref_ptr(const Ctx& c, int64_t ref) {
     return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
 }
 
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
-static int launch_wg(WgradP& p, hipStream_t st) {
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ>
+static int launch_wg2(WgradP& p, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
-    const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ) * sizeof(float);
+    const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ + 2 * (BM + BC)) * sizeof(float);
+    if (p.gatep || (p.gateq && MODE != WG_PIX)) { set_error("wgrad: SE gate is only supported on the Q operand of 1x1 convs"); return S2K_EINVAL; }
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
-    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT>;
+    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, PROP, PROQ>;
     if (MODE == WG_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("wgrad: halo exceeds EPT"); return S2K_EINVAL; }
     if (MODE == WG_SPATIAL && p.R * p.XWe > NPJ) { set_error("wgrad: tile exceeds pixel slots"); return S2K_EINVAL; }
     static bool attr_done = false;
@@ -319,6 +344,25 @@ static int launch_wg(WgradP& p, hipStream_t st) {
     splits = cdiv(p.ntiles, p.tiles_per_split);
     hipLaunchKernelGGL(kern, dim3(mc, splits), dim3(NTHREADS), lds, st, p);
     return S2K_OK;
+}
+
+// the prologue kinds are compile-time in the kernel (no per-element branches in the LDS commit); only the
+// combinations the planners emit are instantiated
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
+static int launch_wg(WgradP& p, hipStream_t st) {
+    const int pp = p.prop, pq = p.proq;
+    if constexpr (MODE == WG_GATHER) {
+        if (pq == S2K_PRO_NONE && pp == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
+        if (pq == S2K_PRO_NONE && pp == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_SILU, S2K_PRO_NONE>(p, st);
+        if (pq == S2K_PRO_NONE && pp == S2K_PRO_NONE) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+    } else {
+        if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+        if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
+        if constexpr (MODE == WG_PIX)
+            if (pp == S2K_PRO_NONE && pq == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_SILU>(p, st);
+    }
+    set_error("wgrad: prologue combination (P %d, Q %d) is not instantiated for this mode", pp, pq);
+    return S2K_EINVAL;
 }
 
 int launch_wgrad(const S2kOp& op, const Ctx& c) {

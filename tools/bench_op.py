@@ -1,0 +1,62 @@
+"""Micro-benchmark of one WGRAD / CONV stage (for rocprofv3 --pmc runs): python tools/bench_op.py wgrad3 --M 128 --C 128 --H 64"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+import s2lc_amd  # noqa: E402,F401
+from s2lc_amd import _lib  # noqa: E402
+from s2lc_amd.plan import opdefs as D  # noqa: E402
+from s2lc_amd.plan.program import Arena, Program  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["wgrad3", "wgrad1", "conv3", "conv1"])
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--M", type=int, default=128)
+    ap.add_argument("--C", type=int, default=128)
+    ap.add_argument("--H", type=int, default=64)
+    ap.add_argument("--pro", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    B, M, C, H = a.B, a.M, a.C, a.H
+    ar = Arena(D.BASE["WS"])
+    prog = Program()
+    k = 3 if a.what.endswith("3") else 1
+    T = k * k
+    if a.what.startswith("wgrad"):
+        P = ar.alloc("p", (B, M, H, H)); Q = ar.alloc("q", (B, C, H, H)); bq = ar.alloc("bnv", (4, C))
+        wgs = ar.alloc("wgs", (T, M, C))
+        prog.add("WGRAD", P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bq if a.pro else None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C,
+                 H=H, W=H, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PROP=0, PROQ=a.pro, MODE=0)
+        flops = 2.0 * M * C * T * B * H * H
+    else:
+        X = ar.alloc("x", (B, C, H, H)); bnv = ar.alloc("bnv", (4, C)); Y = ar.alloc("y", (B, M, H, H))
+        MP, KP = (M + 127) // 128 * 128, (C + 31) // 32 * 32
+        W = ar.alloc("w", (KP * T, MP)); st = ar.alloc("st", (D.stats_replicas(M), 2, M), "f64")
+        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=st, B=B, C1=C,
+                 C2=0, H=H, W=H, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PRO1=a.pro, PRO2=0, MODE=0,
+                 W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
+        flops = 2.0 * M * C * T * B * H * H
+    buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * 0.5).view(torch.uint8)
+    bases = _lib.Bases().set("WS", buf)
+    packed = prog.pack()
+    st_ = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        _lib.run(packed, bases, st_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        _lib.run(packed, bases, st_)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
