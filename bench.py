@@ -130,6 +130,7 @@ def main() -> None:
         from s2lc_amd.ddp import FlatGradReducer
 
         ddp = FlatGradReducer(model, dist)
+        ddp.broadcast_parameters(0)
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
     B, C, H = args.batch, args.bands, args.size

@@ -281,32 +281,39 @@ int launch_channel_sum(const S2kOp& op, const Ctx& c) {
 }
 
 // ---------------- SE FCs ---------------------------------------------------------------------------------
-// one workgroup (1024 threads = 16 waves) per sample
-__global__ void __launch_bounds__(1024) se_fc_kernel(const float* pool, const float* w1, const float* b1, const float* w2,
-                                                     const float* b2, float* hpre, float* gate, int C, int Q) {
+// Tiny GEMMs (B x C x C/24): parallelised over (sample, output) so that a few hundred workgroups exist
+// instead of one per sample.
+// hpre[b][j] = b1[j] + sum_c w1[j][c] * pool[b][c]            one wave per (b, j), lanes over c
+__global__ void __launch_bounds__(NTHREADS) se_fc1_kernel(const float* pool, const float* w1, const float* b1, float* hpre,
+                                                          int B, int C, int Q) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (j >= Q) return;
+    const float* wr = w1 + (int64_t)j * C;
+    const float* pr = pool + (int64_t)b * C;
+    float s = 0.0f;
+    for (int i = lane; i < C; i += 64) s = fmaf(wr[i], pr[i], s);
+    s = wave_sum(s);
+    if (lane == 0) hpre[(int64_t)b * Q + j] = s + b1[j];
+}
+
+// gate[b][c] = sigmoid(b2[c] + sum_j w2[c][j] * silu(hpre[b][j]))     one thread per (b, c)
+__global__ void __launch_bounds__(NTHREADS) se_fc2_kernel(const float* hpre, const float* w2, const float* b2, float* gate,
+                                                          int B, int C, int Q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sp = smem;       // [C]
-    float* sh = smem + C;   // [Q]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < C; i += 1024) sp[i] = pool[(int64_t)b * C + i];
+    const int b = blockIdx.y;
+    for (int j = threadIdx.x; j < Q; j += NTHREADS) smem[j] = silu_f(hpre[(int64_t)b * Q + j]);
     __syncthreads();
-    for (int j = wave; j < Q; j += 16) {
-        float s = 0.0f;
-        for (int i = lane; i < C; i += 64) s = fmaf(w1[(int64_t)j * C + i], sp[i], s);
-        s = wave_sum(s);
-        if (lane == 0) {
-            s += b1[j];
-            hpre[(int64_t)b * Q + j] = s;
-            sh[j] = silu_f(s);
-        }
-    }
-    __syncthreads();
-    for (int i = wave; i < C; i += 16) {
-        float s = 0.0f;
-        for (int j = lane; j < Q; j += 64) s = fmaf(w2[(int64_t)i * Q + j], sh[j], s);
-        s = wave_sum(s);
-        if (lane == 0) gate[(int64_t)b * C + i] = 1.0f / (1.0f + __expf(-(s + b2[i])));
-    }
+    const int c = blockIdx.x * NTHREADS + threadIdx.x;
+    if (c >= C) return;
+    const float* wr = w2 + (int64_t)c * Q;
+    float s = b2[c];
+    int j = 0;
+    for (; j + 4 <= Q; j += 4)
+        s += (wr[j] * smem[j] + wr[j + 1] * smem[j + 1]) + (wr[j + 2] * smem[j + 2] + wr[j + 3] * smem[j + 3]);
+    for (; j < Q; ++j) s = fmaf(wr[j], smem[j], s);
+    gate[(int64_t)b * C + c] = 1.0f / (1.0f + __expf(-s));
 }
 
 int launch_se_fc(const S2kOp& op, const Ctx& c) {
@@ -319,52 +326,56 @@ int launch_se_fc(const S2kOp& op, const Ctx& c) {
     float* gate = ref_ptr<float>(c, op.t[S2K_SE_FC_T_GATE]);
     CHECK_PTRS("se_fc", pool, w1, b1, w2, b2, hpre, gate);
     const int B = op.d[S2K_SE_FC_D_B], C = op.d[S2K_SE_FC_D_C], Q = op.d[S2K_SE_FC_D_CSQ];
-    if (!pool || !w1 || !b1 || !w2 || !b2 || !hpre || !gate || B <= 0 || C <= 0 || Q <= 0 || (size_t)(C + Q) * 4 > 60000) {
+    if (!pool || !w1 || !b1 || !w2 || !b2 || !hpre || !gate || B <= 0 || C <= 0 || Q <= 0 || Q > 8192 || B > 65535) {
         set_error("se_fc: bad args"); return S2K_EINVAL;
     }
-    hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(1024), (C + Q) * sizeof(float), c.stream, pool, w1, b1, w2, b2, hpre, gate, C, Q);
+    hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(Q, 4), B), dim3(NTHREADS), 0, c.stream, pool, w1, b1, hpre, B, C, Q);
+    hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, hpre, w2, b2, gate, B, C, Q);
     return S2K_OK;
 }
 
-// backward, phase A: per sample.  dgate -> dgp (in place), hs = silu(hpre), dhp (overwrites hpre), dpool
-__global__ void __launch_bounds__(1024) se_fc_bwd_a_kernel(float* dgate, const float* gate, float* hpre, const float* w1,
-                                                           const float* w2, float* hs, float* dpool, int C, int Q) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sg = smem;            // [C] dgp
-    float* sd = smem + C;        // [Q] dhp
-    float* part = smem + C + Q;  // [16][Q] per-wave partial dh
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < C; i += 1024) {
-        const float gt = gate[(int64_t)b * C + i];
-        const float v = dgate[(int64_t)b * C + i] * gt * (1.0f - gt);
-        sg[i] = v;
-        dgate[(int64_t)b * C + i] = v;
+// backward, phase A1: dgp = dgate*gate*(1-gate) (in place); dh[b][j] = sum_c w2[c][j]*dgp[b][c];
+// hs = silu(hpre); dhp = dh*silu'(hpre) (overwrites hpre).  One workgroup per (64 j's, sample): lanes over j
+// (coalesced rows of w2), the 4 waves split the channels, partials combined through LDS.
+__global__ void __launch_bounds__(NTHREADS) se_fc_bwd_a1_kernel(float* dgate, const float* gate, float* hpre, const float* w2,
+                                                                float* hs, int B, int C, int Q) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y;
+    const float* dg = dgate + (int64_t)b * C;
+    const float* gt = gate + (int64_t)b * C;
+    float s = 0.0f;
+    if (j < Q) {
+        for (int i = wave; i < C; i += 4) {
+            const float g = gt[i];
+            s = fmaf(w2[(int64_t)i * Q + j], dg[i] * g * (1.0f - g), s);
+        }
     }
+    part[wave][lane] = s;
     __syncthreads();
-    // dh[j] = sum_c w2[c][j] * dgp[c]: wave w takes channels c = w, w+16, ...; lanes run over j (coalesced rows)
-    for (int j0 = 0; j0 < Q; j0 += 64) {
-        const int j = j0 + lane;
-        float s = 0.0f;
-        if (j < Q)
-            for (int i = wave; i < C; i += 16) s = fmaf(w2[(int64_t)i * Q + j], sg[i], s);
-        if (j < Q) part[wave * Q + j] = s;
-    }
-    __syncthreads();
-    for (int j = tid; j < Q; j += 1024) {
-        float s = 0.0f;
-        for (int w = 0; w < 16; ++w) s += part[w * Q + j];
+    if (wave == 0 && j < Q) {
+        const float dh = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         const float hp = hpre[(int64_t)b * Q + j];
         hs[(int64_t)b * Q + j] = silu_f(hp);
-        const float v = s * act_grad(hp, S2K_PRO_SILU);
-        sd[j] = v;
-        hpre[(int64_t)b * Q + j] = v;  // hpre now holds dhp
+        hpre[(int64_t)b * Q + j] = dh * act_grad(hp, S2K_PRO_SILU);   // hpre now holds dhp
     }
+}
+
+// phase A2: dgate <- dgp (in place), dpool[b][c] = sum_j w1[j][c] * dhp[b][j]      one thread per (b, c)
+__global__ void __launch_bounds__(NTHREADS) se_fc_bwd_a2_kernel(float* dgate, const float* gate, const float* dhp, const float* w1,
+                                                                float* dpool, int B, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y;
+    for (int j = threadIdx.x; j < Q; j += NTHREADS) smem[j] = dhp[(int64_t)b * Q + j];
     __syncthreads();
-    for (int i = tid; i < C; i += 1024) {
-        float s = 0.0f;
-        for (int j = 0; j < Q; ++j) s = fmaf(w1[(int64_t)j * C + i], sd[j], s);
-        dpool[(int64_t)b * C + i] = s;
-    }
+    const int c = blockIdx.x * NTHREADS + threadIdx.x;
+    if (c >= C) return;
+    const float g = gate[(int64_t)b * C + c];
+    dgate[(int64_t)b * C + c] *= g * (1.0f - g);
+    float s = 0.0f;
+    for (int j = 0; j < Q; ++j) s = fmaf(w1[(int64_t)j * C + c], smem[j], s);
+    dpool[(int64_t)b * C + c] = s;
 }
 
 // backward, phase B: parameter gradients, summed over the batch inside the thread (no atomics)
@@ -416,9 +427,9 @@ int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
     if (!dgate || !gate || !hpre || !pool || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpool || !hs || B <= 0) {
         set_error("se_fc_bwd: bad args"); return S2K_EINVAL;
     }
-    const size_t lds = ((size_t)C + Q + 16 * (size_t)Q) * sizeof(float);
-    if (lds > 60000) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(se_fc_bwd_a_kernel, dim3(B), dim3(1024), lds, c.stream, dgate, gate, hpre, w1, w2, hs, dpool, C, Q);
+    if (Q > 8192 || B > 65535) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(se_fc_bwd_a1_kernel, dim3(cdiv(Q, 64), B), dim3(NTHREADS), 0, c.stream, dgate, gate, hpre, w2, hs, B, C, Q);
+    hipLaunchKernelGGL(se_fc_bwd_a2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, dgate, gate, hpre, w1, dpool, B, C, Q);
     const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
     hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);
     return S2K_OK;

@@ -362,13 +362,11 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
             }
         return;
     }
-    // row sums for BatchNorm: lanes -> half-wave shuffle, waves -> LDS, then ONE f64 atomic pair per
-    // row per workgroup, into the statistics replica of this tile
-    float* srow = smem;  // [2][BM], the K loop is over: LDS is free
-    if (p.stats) {
-        for (int i = tid; i < 2 * BM; i += NTHREADS) srow[i] = 0.0f;
-        __syncthreads();
-    }
+    // row sums for BatchNorm: lanes -> half-wave shuffle, waves -> LDS slots summed in a FIXED order (no
+    // float atomics: BatchNorm statistics stay run-to-run reproducible), then ONE f64 atomic pair per row
+    // per workgroup into the statistics replica of this tile
+    float* srow = smem;  // [WVN][2][BM], the K loop is over: LDS is free
+    const int wn_idx = wave % WVN;
 #pragma unroll
     for (int rm = 0; rm < WM; ++rm)
 #pragma unroll
@@ -392,9 +390,9 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
             if (p.stats) {
                 s = half_sum(s);
                 q = half_sum(q);
-                if (l31 == 0 && rok) {
-                    atomicAdd(srow + row, s);
-                    atomicAdd(srow + BM + row, q);
+                if (l31 == 0) {  // each (wave-column, row) slot has exactly one writer
+                    srow[(wn_idx * 2 + 0) * BM + row] = rok ? s : 0.0f;
+                    srow[(wn_idx * 2 + 1) * BM + row] = rok ? q : 0.0f;
                 }
             }
         }
@@ -402,8 +400,11 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         __syncthreads();
         double* st = p.stats + (int64_t)(tile % p.nrep) * 2 * p.M;
         for (int i = tid; i < 2 * BM; i += NTHREADS) {
-            const int row = i % BM, gm = m0 + row;
-            if (gm < p.M) atomic_add_d(st + (i / BM) * p.M + gm, (double)srow[i]);
+            const int row = i % BM, which = i / BM, gm = m0 + row;
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WVN; ++w) tot += srow[(w * 2 + which) * BM + row];
+            if (gm < p.M) atomic_add_d(st + which * p.M + gm, (double)tot);
         }
     }
 }

@@ -81,6 +81,9 @@ class _UnetFunction(torch.autograd.Function):
         module, eng = ctx.module, ctx.eng
         (x,) = ctx.saved_tensors
         dout = dout.contiguous()
+        scale = getattr(module, "_grad_scale", 1.0)
+        if scale != 1.0:
+            dout = dout * scale   # data-parallel mean folded into the upstream gradient
         live = module._grads_live()
         accumulate = live and not getattr(module, "_overwrite_next", False)
         module._overwrite_next = False
@@ -92,9 +95,11 @@ class _UnetFunction(torch.autograd.Function):
         if hook is None:
             _lib.run(eng.bwd, bases, st)
         else:
-            for (a, b, lo) in module._bwd_segments(eng):
+            if accumulate:
+                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+            for (a, b, lo, hi) in eng.bwd_marks:
                 _lib.run(eng.bwd, bases, st, a, b)
-                hook(lo, grads)
+                hook(lo, hi, grads)
         if accumulate:
             module._grad_buffer().add_(grads)
         if not live:

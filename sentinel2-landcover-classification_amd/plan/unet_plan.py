@@ -122,7 +122,8 @@ class UnetPlan:
     const_table: list           # int32 blob of the CONST base (WEIGHT_PACK / WGRAD_FINALIZE tables)
     layout: ParamLayout
     n_noise_rows: int
-    bwd_param_marks: list       # (op index in bwd, lowest float offset whose grads are final after it)
+    bwd_param_marks: list       # backward segments (op_begin, op_end, lo, hi): after ops [begin, end) ran, the
+                                # gradients of flat floats [lo, hi) are final (bucketed all-reduce can start)
     logits_shape: tuple
     tensors: dict               # debug: name -> TRef
     wpack_bytes: int = 0        # packed-weight scratch (WPACK base)
@@ -517,7 +518,79 @@ def build_layout(spec: UnetSpec) -> ParamLayout:
     return L
 
 
-def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None) -> UnetPlan:
+def _bucket_backward(p: "_P", layout: ParamLayout, make_table, bucket_floats: int):
+    """Split the backward program into segments after which a contiguous suffix bucket of the flat
+    gradient buffer is final, and fold each bucket's conv-weight scratch (WGRAD_FINALIZE) right there.
+
+    Backward visits layers in reverse, the flat layout is in registration order, so gradients become
+    final roughly from the end of the buffer towards its start: bucket k = floats [lo_k, hi_k) with
+    hi_0 = n_params, ready once every op writing into [lo_k, n_params) has been issued."""
+    ops = p.bwd.ops
+    last_write: dict[int, int] = {}   # param float offset -> index of the last op that writes its grad / scratch
+    size_of = {off: (int(_numel(shape)) + 63) // 64 * 64 for off, shape in layout.params.values()}
+    starts = sorted(size_of)
+    import bisect
+
+    for idx, (kind, fields) in enumerate(ops):
+        for v in fields.values():
+            if isinstance(v, TRef) and v.base in (D.BASE["GRADS"], D.BASE["WGS"]) and kind not in ("MEMSET",):
+                fo = v.off // 4
+                owner = starts[bisect.bisect_right(starts, fo) - 1]
+                last_write[owner] = idx
+    # suffix-ready index per parameter start (descending offsets)
+    cuts = []   # (lo, hi, ready_op_index)
+    hi = layout.n_params
+    acc = 0
+    ready = -1
+    for off in reversed(starts):
+        ready = max(ready, last_write.get(off, -1))
+        acc += size_of[off]
+        if acc >= bucket_floats or off == starts[0]:
+            cuts.append((off, hi, ready))
+            hi, acc = off, 0
+    # make ready indices monotone (a later bucket can never be ready before an earlier one) and insert
+    # the finalize ops back to front so indices stay valid
+    entries = sorted(p.table, key=lambda r: r[0])
+    inserts = []
+    prev = -1
+    for lo, hi_, r in cuts:
+        r = max(r, prev)
+        prev = r
+        rows = [e for e in entries if lo <= e[0] < hi_]
+        inserts.append((r, lo, hi_, rows))
+    segments = []
+    shift = 0
+    begin = 0
+    for r, lo, hi_, rows in inserts:
+        pos = r + 1 + shift
+        if rows:
+            start = 0
+            rel = []
+            for off, M, C, T, _ in rows:
+                rel.append([off, M, C, T, start])
+                start += M * C * T
+            ops.insert(pos, ("WGRAD_FINALIZE", dict(TABLE=make_table(rel, 5), WGS=TRef(D.BASE["WGS"], 0, (layout.n_params,)),
+                                                    GRADS=TRef(D.BASE["GRADS"], 0, (layout.n_params,)), TOTAL=start,
+                                                    N_ENTRIES=len(rel))))
+            shift += 1
+            pos += 1
+        segments.append((begin, pos, lo, hi_))
+        begin = pos
+    if begin < len(ops):   # trailing ops (none write gradients): attach to the last segment
+        a, b, lo, hi_ = segments[-1]
+        segments[-1] = (a, len(ops), lo, hi_)
+    return segments
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s_ in shape:
+        n *= s_
+    return n
+
+
+def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
+              bucket_floats: int = 8 << 20) -> UnetPlan:
     if H % 32 or W % 32:
         raise ValueError(f"EfficientnetUnet needs H, W multiples of 32, got {H}x{W}")
     layout = layout or build_layout(spec)
@@ -610,12 +683,11 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
             pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
                                            BYTES=bwd_aux_end - fwd_aux_end)))
         p.bwd.ops[0:0] = pre_ops
-        p.bwd.add("WGRAD_FINALIZE", TABLE=table(p.table, 5),
-                  WGS=TRef(D.BASE["WGS"], 0, (layout.n_params,)), GRADS=TRef(D.BASE["GRADS"], 0, (layout.n_params,)),
-                  TOTAL=p.table_total, N_ENTRIES=len(p.table))
+        segments = _bucket_backward(p, layout, table, bucket_floats)
         pack_op(p.bwd, p.pack_rows["bwd"])
+        segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]   # WEIGHT_PACK went in front
         bwd = p.bwd
     pack_op(p.fwd, p.pack_rows["fwd"])
 
     return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), blob, layout, n,
-                    [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())
+                    segments if training else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

@@ -1,0 +1,95 @@
+"""CPU, world_size 2 over gloo: the flat-gradient reducer averages gradients like DDP, and the backward
+program's segments make every parameter's gradient final before its bucket is reduced."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import s2lc_amd  # noqa: F401
+from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+from s2lc_amd.plan import opdefs as D
+from s2lc_amd.plan.program import TRef
+
+
+def test_backward_segments_cover_every_parameter_after_its_last_write():
+    m = EfficientnetUnet(EfficientNetConfig("b0", 6, 4, class_distribution=[.25] * 4))
+    plan = m._make_plan(2, 64, 64, True, ) if False else __import__("s2lc_amd.plan.unet_plan", fromlist=["plan_unet"]).plan_unet(
+        m.spec, 2, 64, 64, True, m._layout, bucket_floats=1 << 20)
+    segs = plan.bwd_param_marks
+    assert len(segs) >= 3
+    # contiguous op ranges covering the whole program, contiguous descending buckets covering all floats
+    assert segs[0][0] == 0 and segs[-1][1] == len(plan.bwd)
+    for (a0, b0, lo0, hi0), (a1, b1, lo1, hi1) in zip(segs, segs[1:]):
+        assert b0 == a1 and lo0 == hi1
+    assert segs[0][3] == plan.layout.n_params and segs[-1][2] == 0
+    # no op after a segment's end writes into that segment's bucket (grads or weight-grad scratch)
+    for (a, b, lo, hi) in segs:
+        for kind, fields in plan.bwd.ops[b:]:
+            for v in fields.values():
+                if isinstance(v, TRef) and v.base in (D.BASE["GRADS"], D.BASE["WGS"]) and kind not in ("MEMSET", "WGRAD_FINALIZE"):
+                    assert not (lo <= v.off // 4 < hi), (kind, v.name)
+    # every conv weight is folded exactly once
+    folded = 0
+    for kind, fields in plan.bwd.ops:
+        if kind == "WGRAD_FINALIZE":
+            folded += fields["N_ENTRIES"]
+    assert folded == sum(1 for k in plan.bwd.ops if k[0] == "WGRAD" and k[1]["WGS"].off // 4 in
+                         {off for off, _ in plan.layout.params.values()})
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from s2lc_amd.ddp import FlatGradReducer
+
+        torch.manual_seed(100 + rank)  # different initial weights: broadcast must fix that
+        m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[.25] * 4))
+        red = FlatGradReducer(m, dist)
+        red.broadcast_parameters(0)
+        w0 = m._flat_params.clone()
+        assert m._grad_scale == 0.5
+        grads = m._grad_buffer()
+        g = torch.Generator().manual_seed(rank)
+        local = torch.randn(grads.shape, generator=g)
+        # what the engine does: local gradients already carry the 1/world factor, buckets arrive back to front
+        grads.copy_(local * m._grad_scale)
+        n = grads.numel()
+        cuts = [n, 2 * n // 3, n // 3, 0]
+        for hi, lo in zip(cuts, cuts[1:]):
+            red.on_segment(lo, hi, grads)
+        red.finish()
+        torch.save((rank, grads.clone(), local, w0), os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_reducer_averages_like_ddp_gloo(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    out = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    out.sort(key=lambda t: t[0])
+    mean = (out[0][2] + out[1][2]) / 2
+    for rank, reduced, _, w0 in out:
+        assert torch.allclose(reduced, mean, rtol=1e-6, atol=1e-7)
+    assert torch.equal(out[0][3], out[1][3])  # identical weights after the broadcast
