@@ -16,7 +16,8 @@ constexpr int WAVE = 64;
 constexpr int NTHREADS = 256;
 
 // ---- prologue: v' = act(scale*v + shift) (* gate) -------------------------------------------
-__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// v_exp_f32 + v_rcp_f32 (~1 ulp each): far inside the 1e-3 logits bar, 3x fewer VALU ops than a true division
+__device__ __forceinline__ float silu_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
 
 __device__ __forceinline__ float apply_pro(float v, int pro, float scale, float shift) {
     if (pro != S2K_PRO_NONE) {

@@ -334,28 +334,40 @@ int launch_se_fc(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
-// backward, phase A1: dgp = dgate*gate*(1-gate) (in place); dh[b][j] = sum_c w2[c][j]*dgp[b][c];
-// hs = silu(hpre); dhp = dh*silu'(hpre) (overwrites hpre).  One workgroup per (64 j's, sample): lanes over j
-// (coalesced rows of w2), the 4 waves split the channels, partials combined through LDS.
-__global__ void __launch_bounds__(NTHREADS) se_fc_bwd_a1_kernel(float* dgate, const float* gate, float* hpre, const float* w2,
-                                                                float* hs, int B, int C, int Q) {
-    __shared__ float part[4][64];
+// backward, phase A1: dgp = dgate*gate*(1-gate); dh[b][j] = sum_c w2[c][j]*dgp[b][c];
+// hs = silu(hpre); dhp = dh*silu'(hpre) (overwrites hpre).  One workgroup (16 waves) per (64 j's, sample):
+// dgp of the sample staged in LDS, lanes over j (coalesced rows of w2), waves split the channels with 4
+// independent accumulators, partials combined through LDS.
+__global__ void __launch_bounds__(1024) se_fc_bwd_a1_kernel(const float* dgate, const float* gate, float* hpre, const float* w2,
+                                                            float* hs, int B, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sdg = smem;              // [C]
+    float* part = smem + C;         // [16][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
     const int b = blockIdx.y;
-    const float* dg = dgate + (int64_t)b * C;
-    const float* gt = gate + (int64_t)b * C;
-    float s = 0.0f;
-    if (j < Q) {
-        for (int i = wave; i < C; i += 4) {
-            const float g = gt[i];
-            s = fmaf(w2[(int64_t)i * Q + j], dg[i] * g * (1.0f - g), s);
-        }
+    for (int i = threadIdx.x; i < C; i += 1024) {
+        const float g = gate[(int64_t)b * C + i];
+        sdg[i] = dgate[(int64_t)b * C + i] * g * (1.0f - g);
     }
-    part[wave][lane] = s;
+    __syncthreads();
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (j < Q) {
+        int i = wave;
+        for (; i + 48 < C; i += 64) {
+            s0 = fmaf(w2[(int64_t)i * Q + j], sdg[i], s0);
+            s1 = fmaf(w2[(int64_t)(i + 16) * Q + j], sdg[i + 16], s1);
+            s2 = fmaf(w2[(int64_t)(i + 32) * Q + j], sdg[i + 32], s2);
+            s3 = fmaf(w2[(int64_t)(i + 48) * Q + j], sdg[i + 48], s3);
+        }
+        for (; i < C; i += 16) s0 = fmaf(w2[(int64_t)i * Q + j], sdg[i], s0);
+    }
+    part[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && j < Q) {
-        const float dh = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float dh = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) dh += part[w * 64 + lane];
         const float hp = hpre[(int64_t)b * Q + j];
         hs[(int64_t)b * Q + j] = silu_f(hp);
         hpre[(int64_t)b * Q + j] = dh * act_grad(hp, S2K_PRO_SILU);   // hpre now holds dhp
@@ -373,9 +385,16 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_a2_kernel(float* dgate, co
     if (c >= C) return;
     const float g = gate[(int64_t)b * C + c];
     dgate[(int64_t)b * C + c] *= g * (1.0f - g);
-    float s = 0.0f;
-    for (int j = 0; j < Q; ++j) s = fmaf(w1[(int64_t)j * C + c], smem[j], s);
-    dpool[(int64_t)b * C + c] = s;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int j = 0;
+    for (; j + 4 <= Q; j += 4) {
+        s0 = fmaf(w1[(int64_t)j * C + c], smem[j], s0);
+        s1 = fmaf(w1[(int64_t)(j + 1) * C + c], smem[j + 1], s1);
+        s2 = fmaf(w1[(int64_t)(j + 2) * C + c], smem[j + 2], s2);
+        s3 = fmaf(w1[(int64_t)(j + 3) * C + c], smem[j + 3], s3);
+    }
+    for (; j < Q; ++j) s0 = fmaf(w1[(int64_t)j * C + c], smem[j], s0);
+    dpool[(int64_t)b * C + c] = (s0 + s1) + (s2 + s3);
 }
 
 // backward, phase B: parameter gradients, summed over the batch inside the thread (no atomics)
@@ -388,12 +407,14 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_b_kernel(const float* dgp,
     for (int64_t e = t0; e < total; e += stride) {  // dw2[c][j], j fastest
         const int cc = (int)(e / Q), j = (int)(e - (int64_t)cc * Q);
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < B; ++b) s = fmaf(dgp[(int64_t)b * C + cc], hs[(int64_t)b * Q + j], s);
         dw2[e] += s;
     }
     for (int64_t e = t0; e < total; e += stride) {  // dw1[j][c], c fastest
         const int j = (int)(e / C), cc = (int)(e - (int64_t)j * C);
         float s = 0.0f;
+#pragma unroll 8
         for (int b = 0; b < B; ++b) s = fmaf(dhp[(int64_t)b * Q + j], pool[(int64_t)b * C + cc], s);
         dw1[e] += s;
     }
@@ -428,7 +449,8 @@ int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
         set_error("se_fc_bwd: bad args"); return S2K_EINVAL;
     }
     if (Q > 8192 || B > 65535) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(se_fc_bwd_a1_kernel, dim3(cdiv(Q, 64), B), dim3(NTHREADS), 0, c.stream, dgate, gate, hpre, w2, hs, B, C, Q);
+    if ((size_t)(C + 1024) * 4 > 64000) { set_error("se_fc_bwd: C too large"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(se_fc_bwd_a1_kernel, dim3(cdiv(Q, 64), B), dim3(1024), (C + 1024) * sizeof(float), c.stream, dgate, gate, hpre, w2, hs, B, C, Q);
     hipLaunchKernelGGL(se_fc_bwd_a2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, dgate, gate, hpre, w1, dpool, B, C, Q);
     const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
     hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);

@@ -541,8 +541,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
-        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 32, 1>(p, cdiv(p.Ntot, 64), st);
-        if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 32, 1>(p, cdiv(p.Ntot, 128), st);
+        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st);
+        if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 64, 1>(p, cdiv(p.Ntot, 128), st);
         if (bm == 64) return launch_cfg<BM_PIX, 1, 2, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
         return launch_cfg<BM_PIX, 1, 1, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
     }

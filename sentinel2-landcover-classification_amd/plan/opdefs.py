@@ -43,7 +43,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "AXPY": (["X", "Y"], ["COUNT"], [], []),
     # Pack weights for the implicit GEMM: for every TABLE row {src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP,
     # start}:  DST[dst_off + (kc*T + tap)*MP + m] = SRC[src_off + m*s_m + kc*s_k + (flip ? T-1-tap : tap)*s_t]
-    # for m < M, kc < K, zero in the padding (MP = M rounded up to 128, KP = K rounded up to 32), so the
+    # for m < M, kc < K, zero in the padding (MP = M rounded up to 128, KP = K rounded up to 64), so the
     # conv kernel copies A tiles with aligned 16-byte loads and needs no bounds checks.  Runs once per step.
     "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL"], ["N_ENTRIES"], []),
     # Implicit-GEMM convolution on f32 MFMA (fwd conv / convT fwd / conv dgrad / convT dgrad):

@@ -150,7 +150,7 @@ class _P:
                     src_elem_off: int = 0):
         """Schedule W -> padded K-major copy for the implicit GEMM; returns (packed ref, MP)."""
         MP = (M + 127) // 128 * 128
-        KP = (K + 31) // 32 * 32
+        KP = (K + 63) // 64 * 64
         off, _ = self.layout.params[wname]
         dst = self.wpack.alloc(f"pack:{which}:{wname}:{src_elem_off}", (KP * T, MP))
         rows = self.pack_rows[which]

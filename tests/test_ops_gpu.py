@@ -53,7 +53,7 @@ class Case:
 
     def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0):
         """WEIGHT_PACK record for one weight tensor living in this arena; returns (pre-op, packed ref, MP)."""
-        MP, KP = (M + 127) // 128 * 128, (K + 31) // 32 * 32
+        MP, KP = (M + 127) // 128 * 128, (K + 63) // 64 * 64
         dst = self.t(f"packed{len(self.items)}", (KP * T, MP), "nan")
         row = [wt.off // 4 + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip, MP, KP, 0]
         tab = self.t(f"packtab{len(self.items)}", (1, 12), torch.tensor([row]), "i32")
