@@ -1,14 +1,15 @@
 // Depthwise KxK convolution (k in {3,5}, stride in {1,2}, TF-"SAME" asymmetric padding) — the
 // HBM-bound part of every MBConv block (reference efficientnet_unet.py:335-352 via
-// Conv2dSamePadding.forward :288-297, groups = channels).
+// Conv2dSamePadding.forward :288-297, groups = channels) — forward, data gradient (+ fused act' and
+// BatchNorm-backward sums of the producer) and weight gradient.
 //
-// One workgroup owns PPB consecutive (b,c) planes x a band of RT output rows (whole small planes,
-// several per workgroup; row bands of large ones).  The input band + halo is read ONCE from HBM,
-// coalesced along W, normalised + SiLU'd on the fly (the producing conv stored raw values) and
-// staged in LDS with zero padding; each wave then works on 64-output chunks of ONE plane, so the
-// BatchNorm statistics of the output (forward), the BN-backward sums of the input gradient
-// (dgrad) and the K*K weight-gradient sums (wgrad) are wave shuffle reductions + one f64/f32
-// atomic per plane.
+// One workgroup owns PPB consecutive (b,c) planes x a band of rows.  The band (+ halo) is read ONCE from
+// HBM through bounds-checked buffer loads (zero padding = out-of-range offset), normalised + SiLU'd on
+// the fly (the producing conv stored raw values) and staged in LDS.  Compute is register-blocked: a lane
+// produces 4 consecutive outputs of a row from K x (K + 3*S) LDS values; small planes are packed several
+// per wave (LPP lanes per plane), so per-plane sums (BN statistics of the output, BN-backward sums of
+// the input gradient, the K*K weight-gradient sums) are log2(LPP) shuffle steps + one atomic per plane.
+// K and S are compile-time.
 #include "common.h"
 
 namespace s2k {
@@ -19,87 +20,123 @@ struct DwP {
     const float* w;      // [C][K][K]
     const float* dy;     // dgrad/wgrad
     float* out;          // fwd: Y; dgrad: G; wgrad: DW (atomics)
-    double* stats;       // fwd: [2][C] sum/sumsq of Y;  dgrad: [2][C] sum g, sum g*xhat
+    double* stats;       // fwd: [R][2][C] sum/sumsq of Y;  dgrad: [R][2][C] sum g, sum g*xhat
     int B, C, H, W, K, S, PT, PL, HO, WO, pro, beta, nrep;
-    int PPB, RT, bands, IRt, ICt, LW;   // tiling
+    int PPB, RT, bands, IRt, LW;     // tiling: planes per workgroup, rows per band, LDS rows / row stride
+    int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
 };
 
-constexpr int DW_MAXK2 = 25;
+__device__ __forceinline__ float group_sum(float v, int lpp) {   // sum over aligned groups of lpp lanes
+    for (int o = lpp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
-// ---- forward ------------------------------------------------------------------------------------
+// Stage rows [row0, row0 + nrows) x LW columns of PPB planes of `src` (plane size Hs x Ws) into
+// tile[pl][rr][LW]; element (rr, cc) is src row (row0 + rr), column (col0 + cc), zero outside the image.
+// PRO: prologue applied to in-image values (BatchNorm scale/shift of channel plane % C + activation).
+template <int PRO>
+__device__ __forceinline__ void stage_band(const DwP& p, const float* src, int Hs, int Ws, float* tile, int64_t pl0,
+                                           int64_t nplanes, int nrows, int row0, int col0) {
+    const rsrc_t rs = make_rsrc(src, nplanes * Hs * Ws * 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lwp = 1 << p.lwp_shift;                 // pow2 >= LW (capped at 64)
+    const int rpw = 64 >> p.lwp_shift;                // rows per wave pass
+    const int sub = lane >> p.lwp_shift, cc0 = lane & (lwp - 1);
+    const int total_rows = p.PPB * nrows;
+    for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
+        const int row = rbase + sub;
+        const int pl = row / nrows, rr = row - pl * nrows;
+        const int64_t plane = pl0 + pl;
+        const bool rok = row < total_rows && plane < nplanes;
+        const int iy = row0 + rr;
+        const bool yok = rok && iy >= 0 && iy < Hs;
+        float sc = 1.0f, sh = 0.0f;
+        if (PRO != S2K_PRO_NONE) {
+            const int c = (int)((rok ? plane : 0) % p.C);
+            sc = p.bnv[c];
+            sh = p.bnv[p.C + c];
+        }
+        const uint32_t rowoff = (uint32_t)((plane * Hs + iy) * Ws) * 4u;
+        for (int cc = cc0; cc < p.LW; cc += lwp) {
+            const int ix = col0 + cc;
+            const bool ok = yok && ix >= 0 && ix < Ws;
+            float v = bload(rs, ok ? rowoff + (uint32_t)ix * 4u : BUF_OOB);
+            if (PRO != S2K_PRO_NONE) v = ok ? apply_pro_c<PRO>(v, sc, sh) : 0.0f;
+            if (row < total_rows) tile[(pl * nrows + rr) * p.LW + cc] = v;
+        }
+    }
+}
+
+// ---- forward -------------------------------------------------------------------------------------
+template <int K, int S, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
+    constexpr int NX = 3 * S + K;   // LDS values of one row needed for 4 outputs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                               // [PPB][IRt][LW]
     float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K2 = p.K * p.K;
     const int64_t nplanes = (int64_t)p.B * p.C;
     const int64_t pl0 = (int64_t)(blockIdx.x / p.bands) * p.PPB;
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    const int iy0 = yo0 * p.S - p.PT;
-    const int ix0 = -p.PL;
-    const int per_plane = p.IRt * p.LW;
-
-    // stage input band (+halo) of every plane, prologue applied, zeros outside the image
-    for (int idx = tid; idx < p.PPB * per_plane; idx += NTHREADS) {
-        const int pl = idx / per_plane, e = idx - pl * per_plane;
-        const int rr = e / p.LW, cc = e - rr * p.LW;
+    stage_band<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT, -p.PL);
+    for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
+        const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
-        float v = 0.0f;
-        const int iy = iy0 + rr, ix = ix0 + cc;
-        if (plane < nplanes && cc < p.ICt && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            const int c = (int)(plane % p.C);
-            v = p.x[plane * p.H * p.W + (int64_t)iy * p.W + ix];
-            if (p.pro != S2K_PRO_NONE) v = apply_pro(v, p.pro, p.bnv[c], p.bnv[p.C + c]);
-        }
-        tile[idx] = v;
-    }
-    for (int idx = tid; idx < p.PPB * K2; idx += NTHREADS) {
-        const int pl = idx / K2;
-        const int64_t plane = pl0 + pl;
-        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * K2 + (idx - pl * K2)] : 0.0f;
+        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * (K * K) + (idx - pl * (K * K))] : 0.0f;
     }
     __syncthreads();
 
-    const int n_out = rows * p.WO;
-    const int chunks_per_plane = (n_out + 63) >> 6;
-    // waves own whole planes when there are >= 4 of them, else they split one plane's chunks; either
-    // way a wave keeps its running sums in registers and issues ONE atomic pair per plane it touched
-    const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
+    const int items = rows * p.XG;                    // 4-wide output groups per plane
+    const int lpp = p.LPP, ppw = 64 / lpp;            // lanes per plane, planes per wave
+    const int li = lane & (lpp - 1), lp = lane / lpp;
     double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
-    for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
+    const bool vec4 = (p.WO & 3) == 0;
+    // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
+    const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
+    const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
+    for (int pg = (wave / wpp) * ppw; pg < p.PPB; pg += (4 / wpp) * ppw) {
+        const int pl = pg + lp;
         const int64_t plane = pl0 + pl;
-        if (plane >= nplanes) break;
+        const bool pok = pl < p.PPB && plane < nplanes;
         float s = 0.0f, q = 0.0f;
-        const float* wk = wsm + pl * K2;
-        for (int chn = wave % wpp; chn < chunks_per_plane; chn += wpp) {
-            const int o = chn * 64 + lane;
-            if (o < n_out) {
-                const int r = o / p.WO, xo = o - r * p.WO;
-                const float* t0 = tile + pl * per_plane + (r * p.S) * p.LW + xo * p.S;
-                float acc = 0.0f;
-                if (p.K == 3) {
+        if (pok) {
+            float wk[K * K];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+            for (int i = 0; i < K * K; ++i) wk[i] = wsm[pl * K * K + i];
+            const float* tp = tile + pl * p.IRt * p.LW;
+            for (int it = it0; it < items; it += itstep) {
+                const int r = it / p.XG, xg = it - r * p.XG;
+                const float* t0 = tp + (r * S) * p.LW + xg * 4 * S;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc = fmaf(wk[ky * 3 + kx], t0[ky * p.LW + kx], acc);
+                for (int ky = 0; ky < K; ++ky) {
+                    float v[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) v[i] = t0[ky * p.LW + i];
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], v[j * S + kx], o[j]);
+                }
+                const int xo = xg * 4;
+                float* dst = p.out + plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo;
+                if (vec4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
                 } else {
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) acc = fmaf(wk[ky * 5 + kx], t0[ky * p.LW + kx], acc);
+                    for (int j = 0; j < 4; ++j)
+                        if (xo + j < p.WO) { dst[j] = o[j]; s += o[j]; q = fmaf(o[j], o[j], q); }
                 }
-                p.out[plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo] = acc;
-                s += acc;
-                q = fmaf(acc, acc, q);
             }
         }
         if (st) {
-            s = wave_sum(s);
-            q = wave_sum(q);
-            if (lane == 0) {
+            s = group_sum(s, lpp);
+            q = group_sum(q, lpp);
+            if (li == 0 && pok) {
                 const int c = (int)(plane % p.C);
                 atomic_add_d(st + c, (double)s);
                 atomic_add_d(st + p.C + c, (double)q);
@@ -109,77 +146,161 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------
+template <int K, int S, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
+    constexpr int NX = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;  // [PPB][IRt][LW]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K2 = p.K * p.K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t nplanes = (int64_t)p.B * p.C;
     const int64_t pl0 = (int64_t)(blockIdx.x / p.bands) * p.PPB;
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    const int iy0 = yo0 * p.S - p.PT;
-    const int ix0 = -p.PL;
-    const int per_plane = p.IRt * p.LW;
-    for (int idx = tid; idx < p.PPB * per_plane; idx += NTHREADS) {
-        const int pl = idx / per_plane, e = idx - pl * per_plane;
-        const int rr = e / p.LW, cc = e - rr * p.LW;
-        const int64_t plane = pl0 + pl;
-        float v = 0.0f;
-        const int iy = iy0 + rr, ix = ix0 + cc;
-        if (plane < nplanes && cc < p.ICt && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            const int c = (int)(plane % p.C);
-            v = p.x[plane * p.H * p.W + (int64_t)iy * p.W + ix];
-            if (p.pro != S2K_PRO_NONE) v = apply_pro(v, p.pro, p.bnv[c], p.bnv[p.C + c]);
-        }
-        tile[idx] = v;
-    }
+    stage_band<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT, -p.PL);
     __syncthreads();
-    const int n_out = rows * p.WO;
-    const int chunks_per_plane = (n_out + 63) >> 6;
-    // a wave keeps the K*K partial sums of ONE plane in registers across that plane's chunks
-    // (with fewer than 4 planes per workgroup, several waves share a plane and split its chunks)
-    const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
-    for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
+    const rsrc_t rdy = make_rsrc(p.dy, nplanes * p.HO * p.WO * 4);
+    const int items = rows * p.XG;
+    const int lpp = p.LPP, ppw = 64 / lpp;
+    const int li = lane & (lpp - 1), lp = lane / lpp;
+    // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
+    const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
+    const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
+    for (int pg = (wave / wpp) * ppw; pg < p.PPB; pg += (4 / wpp) * ppw) {
+        const int pl = pg + lp;
         const int64_t plane = pl0 + pl;
-        if (plane >= nplanes) break;
-        float acc[DW_MAXK2];
+        const bool pok = pl < p.PPB && plane < nplanes;
+        float acc[K * K];
 #pragma unroll
-        for (int i = 0; i < DW_MAXK2; ++i) acc[i] = 0.0f;
-        for (int chn = wave % wpp; chn < chunks_per_plane; chn += wpp) {
-            const int o = chn * 64 + lane;
-            if (o < n_out) {
-                const int r = o / p.WO, xo = o - r * p.WO;
-                const float g = p.dy[plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo];
-                const float* t0 = tile + pl * per_plane + (r * p.S) * p.LW + xo * p.S;
-                if (p.K == 3) {
+        for (int i = 0; i < K * K; ++i) acc[i] = 0.0f;
+        if (pok) {
+            const float* tp = tile + pl * p.IRt * p.LW;
+            for (int it = it0; it < items; it += itstep) {
+                const int r = it / p.XG, xg = it - r * p.XG;
+                const int xo = xg * 4;
+                const uint32_t goff = (uint32_t)(plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo) * 4u;
+                float g[4];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                for (int j = 0; j < 4; ++j) g[j] = bload(rdy, xo + j < p.WO ? goff + 4u * j : BUF_OOB);
+                const float* t0 = tp + (r * S) * p.LW + xo * S;
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(g, t0[ky * p.LW + kx], acc[ky * 3 + kx]);
-                } else {
+                for (int ky = 0; ky < K; ++ky) {
+                    float v[NX];
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky)
+                    for (int i = 0; i < NX; ++i) v[i] = t0[ky * p.LW + i];
 #pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(g, t0[ky * p.LW + kx], acc[ky * 5 + kx]);
+                    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(g[j], v[j * S + kx], acc[ky * K + kx]);
                 }
             }
         }
-        const int c = (int)(plane % p.C);
+        const int c = (int)((pok ? plane : 0) % p.C);
 #pragma unroll
-        for (int i = 0; i < DW_MAXK2; ++i) {
-            if (i < K2) {
-                const float v = wave_sum(acc[i]);
-                if (lane == 0) atomicAdd(p.out + (int64_t)c * K2 + i, v);
+        for (int i = 0; i < K * K; ++i) {
+            const float v = group_sum(acc[i], lpp);
+            if (li == 0 && pok) atomicAdd(p.out + (int64_t)c * (K * K) + i, v);
+        }
+    }
+}
+
+// ---- data gradient, stride 1 (the common case): a correlation with the flipped kernel ------------------
+// G[iy][ix] = sum_{ky,kx} w[ky][kx] * dY[iy + PT - ky][ix + PL - kx]; LDS band holds dY rows
+// [iy0 + PT - (K-1), ...) and columns [PL - (K-1), ...): tile(r + a, x + b) with a = K-1-ky, b = K-1-kx.
+template <int K, int PRO>
+__global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) {
+    constexpr int NX = 3 + K;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                               // [PPB][IRt][LW]
+    float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K] flipped
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nplanes = (int64_t)p.B * p.C;
+    const int64_t pl0 = (int64_t)(blockIdx.x / p.bands) * p.PPB;
+    const int band = blockIdx.x % p.bands;
+    const int iy0 = band * p.RT;
+    const int rows = min(p.RT, p.H - iy0);
+    stage_band<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, iy0 + p.PT - (K - 1), p.PL - (K - 1));
+    for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
+        const int pl = idx / (K * K);
+        const int64_t plane = pl0 + pl;
+        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * (K * K) + (K * K - 1 - (idx - pl * (K * K)))] : 0.0f;
+    }
+    __syncthreads();
+    const rsrc_t rxr = make_rsrc(p.x ? p.x : p.dy, p.x ? nplanes * p.H * p.W * 4 : 0);
+    const rsrc_t rout = make_rsrc(p.out, nplanes * p.H * p.W * 4);
+    const int items = rows * p.XG;
+    const int lpp = p.LPP, ppw = 64 / lpp;
+    const int li = lane & (lpp - 1), lp = lane / lpp;
+    double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
+    const bool vec4 = (p.W & 3) == 0;
+    // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
+    const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
+    const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
+    for (int pg = (wave / wpp) * ppw; pg < p.PPB; pg += (4 / wpp) * ppw) {
+        const int pl = pg + lp;
+        const int64_t plane = pl0 + pl;
+        const bool pok = pl < p.PPB && plane < nplanes;
+        const int c = (int)((pok ? plane : 0) % p.C);
+        float s1 = 0.0f, s2 = 0.0f;
+        if (pok) {
+            float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
+            if (PRO != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
+            float wk[K * K];
+#pragma unroll
+            for (int i = 0; i < K * K; ++i) wk[i] = wsm[pl * K * K + i];
+            const float* tp = tile + pl * p.IRt * p.LW;
+            for (int it = it0; it < items; it += itstep) {
+                const int r = it / p.XG, xg = it - r * p.XG;
+                const int ix = xg * 4;
+                const float* t0 = tp + r * p.LW + ix;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < K; ++a) {
+                    float v[NX];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) v[i] = t0[a * p.LW + i];
+#pragma unroll
+                    for (int b = 0; b < K; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], v[j + b], o[j]);
+                }
+                const int64_t off = plane * p.H * p.W + (int64_t)(iy0 + r) * p.W + ix;
+                const uint32_t boff = (uint32_t)off * 4u;
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xr = bload(rxr, ix + j < p.W ? boff + 4u * j : BUF_OOB);
+                        o[j] *= act_grad(fmaf(xr, scale, shift), PRO);
+                        if (ix + j < p.W) { s1 += o[j]; s2 = fmaf(o[j], (xr - mean) * invstd, s2); }
+                    }
+                }
+                if (p.beta) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += bload(rout, ix + j < p.W ? boff + 4u * j : BUF_OOB);
+                }
+                float* dst = p.out + off;
+                if (vec4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ix + j < p.W) dst[j] = o[j];
+                }
+            }
+        }
+        if (st) {
+            s1 = group_sum(s1, lpp);
+            s2 = group_sum(s2, lpp);
+            if (li == 0 && pok) {
+                atomic_add_d(st + c, (double)s1);
+                atomic_add_d(st + p.C + c, (double)s2);
             }
         }
     }
 }
 
-// ---- data gradient (+ fused act' and BN-backward sums of the producer) -----------------------------
-// tiles over INPUT rows: block = PPB planes x RT input rows; LDS holds the needed dY rows.
-__global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_kernel(const DwP p) {
+// ---- data gradient, stride 2 (4 layers of a b5): per-pixel gather with parity tests --------------------
+__global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s2_kernel(const DwP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                               // [PPB][IRt][LW]  (dY rows, zero outside)
     float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K]
@@ -190,19 +311,9 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_kernel(const DwP p) {
     const int band = blockIdx.x % p.bands;
     const int iy0 = band * p.RT;                 // first input row of the band
     const int rows = min(p.RT, p.H - iy0);
-    // output rows that can touch input rows [iy0, iy0+rows): yo*S + ky - PT = iy
     int yo_lo = iy0 + p.PT - (p.K - 1);
-    yo_lo = yo_lo >= 0 ? (yo_lo + p.S - 1) / p.S : 0;
-    const int per_plane = p.IRt * p.LW;
-    for (int idx = tid; idx < p.PPB * per_plane; idx += NTHREADS) {
-        const int pl = idx / per_plane, e = idx - pl * per_plane;
-        const int rr = e / p.LW, cc = e - rr * p.LW;
-        const int64_t plane = pl0 + pl;
-        const int yo = yo_lo + rr;
-        float v = 0.0f;
-        if (plane < nplanes && cc < p.WO && yo < p.HO) v = p.dy[plane * p.HO * p.WO + (int64_t)yo * p.WO + cc];
-        tile[idx] = v;
-    }
+    yo_lo = yo_lo >= 0 ? (yo_lo + 1) / 2 : 0;
+    stage_band<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, yo_lo, 0);
     for (int idx = tid; idx < p.PPB * K2; idx += NTHREADS) {
         const int pl = idx / K2;
         const int64_t plane = pl0 + pl;
@@ -212,6 +323,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_kernel(const DwP p) {
     const int n_in = rows * p.W;
     const int chunks_per_plane = (n_in + 63) >> 6;
     const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
+    const int per_plane = p.IRt * p.LW;
     double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
     for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
         const int64_t plane = pl0 + pl;
@@ -230,15 +342,15 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_kernel(const DwP p) {
                 float acc = 0.0f;
                 for (int ky = 0; ky < p.K; ++ky) {
                     const int ty = iy + p.PT - ky;
-                    if (ty < 0) continue;
-                    const int yo = (p.S == 1) ? ty : (ty >> 1);
-                    if ((p.S == 2 && (ty & 1)) || yo >= p.HO) continue;
-                    const int rr = yo - yo_lo;   // >= 0 by construction of yo_lo
+                    if (ty < 0 || (ty & 1)) continue;
+                    const int yo = ty >> 1;
+                    if (yo >= p.HO) continue;
+                    const int rr = yo - yo_lo;
                     for (int kx = 0; kx < p.K; ++kx) {
                         const int tx = ix + p.PL - kx;
-                        if (tx < 0) continue;
-                        const int xo = (p.S == 1) ? tx : (tx >> 1);
-                        if ((p.S == 2 && (tx & 1)) || xo >= p.WO) continue;
+                        if (tx < 0 || (tx & 1)) continue;
+                        const int xo = tx >> 1;
+                        if (xo >= p.WO) continue;
                         acc = fmaf(wk[ky * p.K + kx], tp[rr * p.LW + xo], acc);
                     }
                 }
@@ -278,25 +390,46 @@ static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
 
 static int fill_geo(DwP& p, const int32_t* d) {
     p.B = d[0]; p.C = d[1]; p.H = d[2]; p.W = d[3]; p.K = d[4]; p.S = d[5]; p.PT = d[6]; p.PL = d[7];
-    p.HO = d[8]; p.WO = d[9]; p.pro = d[10]; p.nrep = 1;
+    p.HO = d[8]; p.WO = d[9]; p.pro = d[10]; p.nrep = 1; p.beta = 0;
     if (p.B <= 0 || p.C <= 0 || p.H <= 0 || p.W <= 0 || (p.K != 3 && p.K != 5) || (p.S != 1 && p.S != 2)) {
         set_error("dwconv: unsupported geometry K=%d S=%d", p.K, p.S);
         return S2K_EINVAL;
     }
+    if ((int64_t)p.B * p.C * p.H * p.W * 4 >= 0x7ffffff0ll) { set_error("dwconv: tensor larger than 2 GiB"); return S2K_EINVAL; }
+    if (p.pro != S2K_PRO_NONE && p.pro != S2K_PRO_SILU) { set_error("dwconv: only the SiLU prologue is on this path"); return S2K_EINVAL; }
     return S2K_OK;
 }
 
-// tiling over OUTPUT rows (fwd, wgrad)
-static size_t tile_out(DwP& p, bool with_w) {
+static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+
+// tiling over rows of the COMPUTED plane (ho x wo); src rows needed per band = irt, src columns = lw
+static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP&), int lw, bool with_w) {
     const int target = 1024;
-    const int hw = p.HO * p.WO;
-    if (hw <= target) { p.PPB = target / hw; if (p.PPB > 16) p.PPB = 16; p.RT = p.HO; }
-    else { p.PPB = 1; p.RT = target / p.WO; if (p.RT < 1) p.RT = 1; }
-    p.bands = cdiv(p.HO, p.RT);
-    p.IRt = (p.RT - 1) * p.S + p.K;
-    p.ICt = (p.WO - 1) * p.S + p.K;
-    p.LW = p.ICt | 1;
+    const int hw = ho * wo;
+    if (hw <= target) { p.PPB = target / hw; if (p.PPB > 16) p.PPB = 16; p.RT = ho; }
+    else { p.PPB = 1; p.RT = target / wo; if (p.RT < 1) p.RT = 1; }
+    p.bands = cdiv(ho, p.RT);
+    p.IRt = irt_for_rt(p.RT, p);
+    p.LW = lw | 1;
+    p.XG = cdiv(wo, 4);
+    const int items = p.RT * p.XG;
+    p.LPP = items >= 64 ? 64 : pow2ceil(items);
+    int l2 = 0;
+    while ((1 << l2) < p.LW && l2 < 6) ++l2;
+    p.lwp_shift = l2;
     return ((size_t)p.PPB * p.IRt * p.LW + (with_w ? p.PPB * p.K * p.K : 0)) * sizeof(float);
+}
+
+static int irt_fwd(int rt, const DwP& p) { return (rt - 1) * p.S + p.K; }
+static int irt_dgrad1(int rt, const DwP& p) { return rt + p.K - 1; }
+static int irt_dgrad2(int rt, const DwP& p) { int v = (rt + p.K - 2) / 2 + 2; return v > p.HO ? p.HO : v; }
+
+template <typename KernT>
+static int launch_dw(KernT kern, const DwP& p, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) { set_error("dwconv: tile too large (%zu B)", lds); return S2K_EINVAL; }
+    const int64_t groups = cdiv64((int64_t)p.B * p.C, p.PPB);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * p.bands)), dim3(NTHREADS), lds, st, p);
+    return S2K_OK;
 }
 
 int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
@@ -310,11 +443,16 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (op.d[S2K_DWCONV_FWD_D_NREP] > 0) p.nrep = op.d[S2K_DWCONV_FWD_D_NREP];
     if (bad(p.x) || bad(p.bnv) || bad(p.w) || bad(p.out) || bad(p.stats)) { set_error("dwconv_fwd: null base"); return S2K_EFAULT; }
     if (!p.x || !p.w || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_fwd: missing tensor"); return S2K_EINVAL; }
-    const size_t lds = tile_out(p, true);
-    if (lds > 64 * 1024) { set_error("dwconv_fwd: tile too large"); return S2K_EINVAL; }
-    const int64_t groups = cdiv64((int64_t)p.B * p.C, p.PPB);
-    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3((unsigned)(groups * p.bands)), dim3(NTHREADS), lds, c.stream, p);
-    return S2K_OK;
+    const int lw = (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
+    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true);
+    const bool silu = p.pro == S2K_PRO_SILU;
+#define DW_FWD(KK, SS) (silu ? launch_dw(dwconv_fwd_kernel<KK, SS, S2K_PRO_SILU>, p, lds, c.stream) \
+                             : launch_dw(dwconv_fwd_kernel<KK, SS, S2K_PRO_NONE>, p, lds, c.stream))
+    if (p.K == 3 && p.S == 1) return DW_FWD(3, 1);
+    if (p.K == 3 && p.S == 2) return DW_FWD(3, 2);
+    if (p.K == 5 && p.S == 1) return DW_FWD(5, 1);
+    return DW_FWD(5, 2);
+#undef DW_FWD
 }
 
 int launch_dwconv_wgrad(const S2kOp& op, const Ctx& c) {
@@ -326,11 +464,16 @@ int launch_dwconv_wgrad(const S2kOp& op, const Ctx& c) {
     p.out = ref_ptr<float>(c, op.t[S2K_DWCONV_WGRAD_T_DW]);
     if (bad(p.x) || bad(p.bnv) || bad(p.dy) || bad(p.out)) { set_error("dwconv_wgrad: null base"); return S2K_EFAULT; }
     if (!p.x || !p.dy || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_wgrad: missing tensor"); return S2K_EINVAL; }
-    const size_t lds = tile_out(p, false);
-    if (lds > 64 * 1024) { set_error("dwconv_wgrad: tile too large"); return S2K_EINVAL; }
-    const int64_t groups = cdiv64((int64_t)p.B * p.C, p.PPB);
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)(groups * p.bands)), dim3(NTHREADS), lds, c.stream, p);
-    return S2K_OK;
+    const int lw = (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
+    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false);
+    const bool silu = p.pro == S2K_PRO_SILU;
+#define DW_WG(KK, SS) (silu ? launch_dw(dwconv_wgrad_kernel<KK, SS, S2K_PRO_SILU>, p, lds, c.stream) \
+                            : launch_dw(dwconv_wgrad_kernel<KK, SS, S2K_PRO_NONE>, p, lds, c.stream))
+    if (p.K == 3 && p.S == 1) return DW_WG(3, 1);
+    if (p.K == 3 && p.S == 2) return DW_WG(3, 2);
+    if (p.K == 5 && p.S == 1) return DW_WG(5, 1);
+    return DW_WG(5, 2);
+#undef DW_WG
 }
 
 int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
@@ -347,21 +490,18 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
     if (bad(p.x) || bad(p.bnv) || bad(p.dy) || bad(p.out) || bad(p.w) || bad(p.stats)) { set_error("dwconv_dgrad: null base"); return S2K_EFAULT; }
     if (!p.dy || !p.w || !p.out || (p.pro != S2K_PRO_NONE && (!p.bnv || !p.x))) { set_error("dwconv_dgrad: missing tensor"); return S2K_EINVAL; }
     if (p.pro == S2K_PRO_NONE) p.stats = nullptr;
-    // tiling over INPUT rows
-    const int target = 1024;
-    const int hw = p.H * p.W;
-    if (hw <= target) { p.PPB = target / hw; if (p.PPB > 16) p.PPB = 16; p.RT = p.H; }
-    else { p.PPB = 1; p.RT = target / p.W; if (p.RT < 1) p.RT = 1; }
-    p.bands = cdiv(p.H, p.RT);
-    p.IRt = (p.RT + p.K - 2) / p.S + 2;   // dY rows a band of RT input rows can touch
-    if (p.IRt > p.HO) p.IRt = p.HO;
-    p.ICt = p.WO;
-    p.LW = p.WO | 1;
-    const size_t lds = ((size_t)p.PPB * p.IRt * p.LW + p.PPB * p.K * p.K) * sizeof(float);
-    if (lds > 64 * 1024) { set_error("dwconv_dgrad: tile too large"); return S2K_EINVAL; }
-    const int64_t groups = cdiv64((int64_t)p.B * p.C, p.PPB);
-    hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3((unsigned)(groups * p.bands)), dim3(NTHREADS), lds, c.stream, p);
-    return S2K_OK;
+    if (p.S == 1) {
+        if (p.HO != p.H || p.WO != p.W) { set_error("dwconv_dgrad: stride-1 geometry mismatch"); return S2K_EINVAL; }
+        const int lw = cdiv(p.W, 4) * 4 + p.K - 1;
+        const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad1, lw, true);
+        const bool silu = p.pro == S2K_PRO_SILU;
+        if (p.K == 3) return silu ? launch_dw(dwconv_dgrad_s1_kernel<3, S2K_PRO_SILU>, p, lds, c.stream)
+                                  : launch_dw(dwconv_dgrad_s1_kernel<3, S2K_PRO_NONE>, p, lds, c.stream);
+        return silu ? launch_dw(dwconv_dgrad_s1_kernel<5, S2K_PRO_SILU>, p, lds, c.stream)
+                    : launch_dw(dwconv_dgrad_s1_kernel<5, S2K_PRO_NONE>, p, lds, c.stream);
+    }
+    const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO, true);
+    return launch_dw(dwconv_dgrad_s2_kernel, p, lds, c.stream);
 }
 
 }  // namespace s2k
