@@ -10,6 +10,8 @@
 // per wave (LPP lanes per plane), so per-plane sums (BN statistics of the output, BN-backward sums of
 // the input gradient, the K*K weight-gradient sums) are log2(LPP) shuffle steps + one atomic per plane.
 // K and S are compile-time.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace s2k {
@@ -166,8 +168,9 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
     // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
     const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
     const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
-    for (int pg = (wave / wpp) * ppw; pg < p.PPB; pg += (4 / wpp) * ppw) {
-        const int pl = pg + lp;
+    float* red = smem + p.PPB * p.IRt * p.LW;   // [4 waves][K*K] cross-wave combine (wpp > 1 only)
+    for (int pgb = 0; pgb < p.PPB; pgb += (4 / wpp) * ppw) {
+        const int pl = pgb + (wave / wpp) * ppw + lp;
         const int64_t plane = pl0 + pl;
         const bool pok = pl < p.PPB && plane < nplanes;
         float acc[K * K];
@@ -196,10 +199,31 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
             }
         }
         const int c = (int)((pok ? plane : 0) % p.C);
+        if (wpp == 1) {
 #pragma unroll
-        for (int i = 0; i < K * K; ++i) {
-            const float v = group_sum(acc[i], lpp);
-            if (li == 0 && pok) atomicAdd(p.out + (int64_t)c * (K * K) + i, v);
+            for (int i = 0; i < K * K; ++i) {
+                const float v = group_sum(acc[i], lpp);
+                if (li == 0 && pok) atomicAdd(p.out + (int64_t)c * (K * K) + i, v);
+            }
+        } else {
+            // one atomic per (plane, tap) per workgroup: same-address atomics serialise at the memory side
+#pragma unroll
+            for (int i = 0; i < K * K; ++i) {
+                const float v = wave_sum(acc[i]);
+                if (lane == 0) red[wave * (K * K) + i] = pok ? v : 0.0f;
+            }
+            __syncthreads();
+            const int nslot = 4 / wpp;
+            if ((int)threadIdx.x < nslot * K * K) {
+                const int slot = threadIdx.x / (K * K), i = threadIdx.x - slot * (K * K);
+                const int64_t pln = pl0 + pgb + slot;
+                if (pgb + slot < p.PPB && pln < nplanes) {
+                    float v = 0.0f;
+                    for (int w = 0; w < wpp; ++w) v += red[(slot * wpp + w) * (K * K) + i];
+                    atomicAdd(p.out + (pln % p.C) * (K * K) + i, v);
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -404,20 +428,26 @@ static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
 // tiling over rows of the COMPUTED plane (ho x wo); src rows needed per band = irt, src columns = lw
 static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP&), int lw, bool with_w) {
-    const int target = 1024;
+    // outputs per workgroup: enough loads in flight per CU to cover HBM latency, LDS small enough for ~6 workgroups / CU
+    static const int target0 = [] { const char* e = getenv("S2K_DW_TARGET"); return e ? atoi(e) : 4096; }();
     const int hw = ho * wo;
-    if (hw <= target) { p.PPB = target / hw; if (p.PPB > 16) p.PPB = 16; p.RT = ho; }
-    else { p.PPB = 1; p.RT = target / wo; if (p.RT < 1) p.RT = 1; }
-    p.bands = cdiv(ho, p.RT);
-    p.IRt = irt_for_rt(p.RT, p);
     p.LW = lw | 1;
     p.XG = cdiv(wo, 4);
+    size_t lds = 0;
+    for (int target = target0;; target >>= 1) {
+        if (hw <= target) { p.PPB = target / hw; if (p.PPB > 32) p.PPB = 32; p.RT = ho; }
+        else { p.PPB = 1; p.RT = target / wo; if (p.RT < 1) p.RT = 1; }
+        p.IRt = irt_for_rt(p.RT, p);
+        lds = ((size_t)p.PPB * p.IRt * p.LW + (with_w ? p.PPB * p.K * p.K : 4 * p.K * p.K)) * sizeof(float);
+        if (lds <= 26 * 1024 || (p.PPB == 1 && p.RT == 1)) break;
+    }
+    p.bands = cdiv(ho, p.RT);
     const int items = p.RT * p.XG;
     p.LPP = items >= 64 ? 64 : pow2ceil(items);
     int l2 = 0;
     while ((1 << l2) < p.LW && l2 < 6) ++l2;
     p.lwp_shift = l2;
-    return ((size_t)p.PPB * p.IRt * p.LW + (with_w ? p.PPB * p.K * p.K : 0)) * sizeof(float);
+    return lds;
 }
 
 static int irt_fwd(int rt, const DwP& p) { return (rt - 1) * p.S + p.K; }

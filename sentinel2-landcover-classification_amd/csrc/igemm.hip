@@ -309,25 +309,57 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         const bool more = ch + 1 < nchunks;
         if (more) fetch((ch + 1) * KCH);
         // ---------------- MFMA over the chunk in LDS --------------------------------------------
-        int tdy = 0, tdx = 0;
+        // Explicit two-set operand pipeline: the LDS reads of stage i+1 are issued before the MFMAs of stage i
+        // (left alone hipcc reads, waits, multiplies, one k-step at a time).  A stage = G k-steps (>= 4 MFMAs
+        // where the tile allows); the last stage of a tap prefetches the first stage of the next tap.
+        {
+            constexpr int KS = KCH / 2;                          // k-steps (pairs of input channels) per tap
+            constexpr int G0 = (WM * WN >= 4) ? 1 : 4 / (WM * WN);
+            constexpr int G = (G0 > KS / 2) ? KS / 2 : G0;       // k-steps per stage
+            constexpr int SPT = KS / G;                          // stages per tap
+            static_assert(KS % G == 0 && SPT % 2 == 0, "stages per tap must be even");
+            auto lds_ops = [&](int tap, int toff, int sg, float (&a)[G][WM], float (&b)[G][WN]) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int k = 2 * (sg * G + g) + lh;
+#pragma unroll
+                    for (int rm = 0; rm < WM; ++rm) a[g][rm] = As[(k * TT + tap) * AS + wm0 + rm * 32 + l31];
+#pragma unroll
+                    for (int rn = 0; rn < WN; ++rn) b[g][rn] = Bs[k * CSB + boff[rn] + toff];
+                }
+            };
+            auto mfmas = [&](const float (&a)[G][WM], const float (&b)[G][WN]) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+                        for (int rn = 0; rn < WN; ++rn)
+                            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][rm], b[g][rn], acc[rm][rn], 0, 0, 0);
+            };
+            float a0[G][WM], b0[G][WN], a1[G][WM], b1[G][WN];
+            int tdy = 0, tdx = 0;
+            lds_ops(0, 0, 0, a0, b0);
 #pragma unroll 1
-        for (int tap = 0; tap < TT; ++tap) {
-            const int toff = (BMODE == BM_PIX) ? 0 : tdy * p.WS + tdx;
+            for (int tap = 0; tap < TT; ++tap) {
+                const int toff = (BMODE == BM_PIX) ? 0 : tdy * p.WS + tdx;
+                if (++tdx == p.KW) { tdx = 0; ++tdy; }
+                const bool last = tap + 1 == TT;
+                const int ntap = last ? tap : tap + 1;           // past the end: re-read (never used)
+                const int ntoff = (BMODE == BM_PIX || last) ? toff : tdy * p.WS + tdx;
 #pragma unroll
-            for (int ks = 0; ks < KCH / 2; ++ks) {
-                const int k = 2 * ks + lh;
-                float a[WM], b[WN];
-#pragma unroll
-                for (int rm = 0; rm < WM; ++rm) a[rm] = As[(k * TT + tap) * AS + wm0 + rm * 32 + l31];
-#pragma unroll
-                for (int rn = 0; rn < WN; ++rn) b[rn] = Bs[k * CSB + boff[rn] + toff];
-#pragma unroll
-                for (int rm = 0; rm < WM; ++rm)
-#pragma unroll
-                    for (int rn = 0; rn < WN; ++rn)
-                        acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], b[rn], acc[rm][rn], 0, 0, 0);
+                for (int sg = 0; sg < SPT; sg += 2) {
+                    lds_ops(tap, toff, sg + 1, a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sg + 2 < SPT) lds_ops(tap, toff, sg + 2, a0, b0);
+                    else lds_ops(ntap, ntoff, 0, a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (++tdx == p.KW) { tdx = 0; ++tdy; }
         }
         __syncthreads();  // every wave is done reading this chunk
         if (more) {

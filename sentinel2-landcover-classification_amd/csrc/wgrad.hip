@@ -248,18 +248,20 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
         const bool more = tile + 1 < tile_end;
         if (more) fetch(tile + 1);
         // ---------------- MFMA over pixel pairs ----------------------------------------------------
-        // SPATIAL: pair s = (row r, column pair xp); walk (r, xp) incrementally, WVK pairs at a time
+        // SPATIAL: pair s = (row r, column pair xp); walk (r, xp) incrementally, WVK pairs at a time.
+        // Two operand sets: the LDS reads of pair s+WVK are issued before the T MFMAs of pair s (hipcc left to
+        // itself re-uses ONE register for every B read and waits for each read in front of its MFMA).
         int r_run = 0, xp_run = wk;
         if (MODE == WG_SPATIAL)
             while (xp_run >= half_xw) { xp_run -= half_xw; ++r_run; }
-        for (int s = wk; s < npairs; s += WVK) {
-            const int n = 2 * s + lh;  // this lane's pixel inside the tile
-            float a[WM];
+        auto lds_operands = [&](int s, float (&a)[WM], float (&bq)[T][WN]) {
+            const bool live = s < npairs;          // past the end: re-read pair 0 (never used), keeps the loop branch-free
+            const int n = live ? 2 * s + lh : lh;  // this lane's pixel inside the tile
 #pragma unroll
             for (int rm = 0; rm < WM; ++rm) a[rm] = Ps[(wm0 + rm * 32 + l31) * p.PSTR + n];
             int qbase;
             if (MODE == WG_SPATIAL) {
-                qbase = (r_run * p.S) * p.WS + (2 * xp_run + lh) * p.S;
+                qbase = live ? (r_run * p.S) * p.WS + (2 * xp_run + lh) * p.S : 0;
                 xp_run += WVK;
                 while (xp_run >= half_xw) { xp_run -= half_xw; ++r_run; }
             } else {
@@ -272,16 +274,32 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 if (MODE == WG_SPATIAL) toff = tdy * p.WS + tdx;
                 else if (MODE == WG_GATHER) toff = t * NPJ;
                 else toff = 0;
-                float bq[WN];
 #pragma unroll
-                for (int rn = 0; rn < WN; ++rn) bq[rn] = Qs[(wc0 + rn * 32 + l31) * p.CSQ + qbase + toff];
+                for (int rn = 0; rn < WN; ++rn) bq[t][rn] = Qs[(wc0 + rn * 32 + l31) * p.CSQ + qbase + toff];
+                if (++tdx == p.KW) { tdx = 0; ++tdy; }
+            }
+        };
+        auto mfmas = [&](const float (&a)[WM], const float (&bq)[T][WN]) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int rm = 0; rm < WM; ++rm)
 #pragma unroll
                     for (int rn = 0; rn < WN; ++rn)
-                        acc[t][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], bq[rn], acc[t][rm][rn], 0, 0, 0);
-                if (++tdx == p.KW) { tdx = 0; ++tdy; }
-            }
+                        acc[t][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], bq[t][rn], acc[t][rm][rn], 0, 0, 0);
+        };
+        float a0[WM], a1[WM], b0[T][WN], b1[T][WN];
+        lds_operands(wk, a0, b0);
+        for (int s = wk; s < npairs; s += 2 * WVK) {
+            lds_operands(s + WVK, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + WVK >= npairs) break;
+            lds_operands(s + 2 * WVK, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (more) {

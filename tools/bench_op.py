@@ -16,20 +16,47 @@ from s2lc_amd.plan.program import Arena, Program  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["wgrad3", "wgrad1", "conv3", "conv1"])
+    ap.add_argument("what", choices=["wgrad3", "wgrad1", "conv3", "conv1", "dwfwd", "dwwgrad", "dwdgrad", "copy"])
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--M", type=int, default=128)
     ap.add_argument("--C", type=int, default=128)
     ap.add_argument("--H", type=int, default=64)
     ap.add_argument("--pro", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--K", type=int, default=3)
+    ap.add_argument("--S", type=int, default=1)
+    ap.add_argument("--nostats", action="store_true")
     a = ap.parse_args()
     B, M, C, H = a.B, a.M, a.C, a.H
     ar = Arena(D.BASE["WS"])
     prog = Program()
     k = 3 if a.what.endswith("3") else 1
     T = k * k
-    if a.what.startswith("wgrad"):
+    if a.what == "copy":
+        x = torch.randn(B, C, H, H, device="cuda"); y = torch.empty_like(x)
+        for _ in range(3): y.copy_(x)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.iters): y.copy_(x)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
+        print(f"copy {x.numel() * 8 / 1e6:.0f} MB: {dt * 1e3:.3f} ms  {x.numel() * 8 / dt / 1e12:.2f} TB/s")
+        return
+    if a.what.startswith("dw"):
+        K, S = a.K, a.S
+        HO = (H + S - 1) // S
+        pad = max((HO - 1) * S + K - H, 0)
+        X = ar.alloc("x", (B, C, H, H)); bnv = ar.alloc("bnv", (4, C)); Wt = ar.alloc("w", (C, K, K)); Y = ar.alloc("y", (B, C, HO, HO))
+        nrep = D.stats_replicas(C)
+        st = ar.alloc("st", (nrep, 2, C), "f64")
+        geo = dict(B=B, C=C, H=H, W=H, K=K, STRIDE=S, PAD_T=pad // 2, PAD_L=pad // 2, HO=HO, WO=HO, PRO=a.pro)
+        if a.what == "dwfwd":
+            prog.add("DWCONV_FWD", X=X, BNV=bnv if a.pro else None, WT=Wt, Y=Y, STATS=None if a.nostats else st, NREP=nrep, **geo)
+        elif a.what == "dwwgrad":
+            prog.add("DWCONV_WGRAD", DY=Y, X=X, BNV=bnv if a.pro else None, DW=Wt, **geo)
+        else:
+            prog.add("DWCONV_DGRAD", DY=Y, WT=Wt, XRAW=X if a.pro else None, BNV=bnv if a.pro else None, G=X if not a.pro else ar.alloc("g", (B, C, H, H)),
+                     STATS2=None if a.nostats or not a.pro else st, BETA=0, NREP=nrep, **geo)
+        flops = 4.0 * B * C * (H * H + HO * HO) * 1000   # "TF/s" column = TB/s of (in + out) bytes
+    elif a.what.startswith("wgrad"):
         P = ar.alloc("p", (B, M, H, H)); Q = ar.alloc("q", (B, C, H, H)); bq = ar.alloc("bnv", (4, C))
         wgs = ar.alloc("wgs", (T, M, C))
         prog.add("WGRAD", P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bq if a.pro else None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C,
