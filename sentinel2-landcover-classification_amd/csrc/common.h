@@ -77,9 +77,50 @@ __device__ __forceinline__ float2 bload2(rsrc_t r, uint32_t byte_off) {
 }
 
 // ---- reductions -------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums run on the DPP data path of the vector ALU (one v_add_f32_dpp per step); the generic
+// __shfl_xor lowers to ds_bpermute_b32 = an LDS round trip + s_waitcnt per step, which made the BatchNorm
+// statistics of a short-K conv cost more than its MFMAs.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_mov0(float v) {   // lanes outside ROW_MASK (or without a source lane) read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <- lane 7-i of its 8-lane half
+constexpr int DPP_MIRROR = 0x140;       // lane i <- lane 15-i of its 16-lane row
+constexpr int DPP_BCAST15 = 0x142;      // lane 15 of every row -> all lanes of the next row
+constexpr int DPP_BCAST31 = 0x143;      // lane 31 -> all lanes of rows 2 and 3
+// every lane ends with the sum of its 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov0<DPP_XOR1>(v);
+    v += dpp_mov0<DPP_XOR2>(v);
+    v += dpp_mov0<DPP_HALF_MIRROR>(v);
+    v += dpp_mov0<DPP_MIRROR>(v);
+    return v;
+}
+// sum over the 32 lanes that share (lane >> 5); valid in lanes 16..31 (resp. 48..63) ONLY
+__device__ __forceinline__ float half_sum_hi(float v) {
+    v = row16_sum(v);
+    v += dpp_mov0<DPP_BCAST15, 0xa>(v);
+    return v;
+}
+// sum over the wave; valid in lanes 48..63 ONLY
+__device__ __forceinline__ float wave_sum_hi(float v) {
+    v = half_sum_hi(v);
+    v += dpp_mov0<DPP_BCAST31, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {   // all lanes (the total comes back through an SGPR)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_hi(v)), 63));
+}
+// sum over aligned groups of lpp lanes (lpp = wave-uniform power of two), all lanes of the group
+__device__ __forceinline__ float group_sum(float v, int lpp) {
+    if (lpp >= 2) v += dpp_mov0<DPP_XOR1>(v);
+    if (lpp >= 4) v += dpp_mov0<DPP_XOR2>(v);
+    if (lpp >= 8) v += dpp_mov0<DPP_HALF_MIRROR>(v);
+    if (lpp >= 16) v += dpp_mov0<DPP_MIRROR>(v);
+    if (lpp >= 32) v += __shfl_xor(v, 16, 64);
+    if (lpp >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -87,7 +128,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// sum over the 32 lanes that share (lane >> 5)
+// sum over the 32 lanes that share (lane >> 5), all lanes
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -28,11 +28,6 @@ struct DwP {
     int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
 };
 
-__device__ __forceinline__ float group_sum(float v, int lpp) {   // sum over aligned groups of lpp lanes
-    for (int o = lpp >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // Stage rows [row0, row0 + nrows) x LW columns of PPB planes of `src` (plane size Hs x Ws) into
 // tile[pl][rr][LW]; element (rr, cc) is src row (row0 + rr), column (col0 + cc), zero outside the image.
 // PRO: prologue applied to in-image values (BatchNorm scale/shift of channel plane % C + activation).

@@ -420,9 +420,9 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 }
             }
             if (p.stats) {
-                s = half_sum(s);
-                q = half_sum(q);
-                if (l31 == 0) {  // each (wave-column, row) slot has exactly one writer
+                s = half_sum_hi(s);
+                q = half_sum_hi(q);
+                if (l31 == 31) {  // each (wave-column, row) slot has exactly one writer
                     srow[(wn_idx * 2 + 0) * BM + row] = rok ? s : 0.0f;
                     srow[(wn_idx * 2 + 1) * BM + row] = rok ? q : 0.0f;
                 }

@@ -66,7 +66,7 @@ def main():
         X = ar.alloc("x", (B, C, H, H)); bnv = ar.alloc("bnv", (4, C)); Y = ar.alloc("y", (B, M, H, H))
         MP, KP = (M + 127) // 128 * 128, (C + 63) // 64 * 64
         W = ar.alloc("w", (KP * T, MP)); st = ar.alloc("st", (D.stats_replicas(M), 2, M), "f64")
-        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=st, B=B, C1=C,
+        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st, B=B, C1=C,
                  C2=0, H=H, W=H, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
         flops = 2.0 * M * C * T * B * H * H
