@@ -63,6 +63,8 @@ def _pro(x, bnv, gate, pro, C):
             x = F.silu(x)
         elif pro == 3:
             x = F.relu(x)
+        elif pro == 4:
+            x = F.gelu(x)
     if gate is not None:
         x = x * gate.view(gate.shape[0], C, 1, 1)
     return x
@@ -74,6 +76,8 @@ def _act_grad(u, act):
         return s * (1 + u * (1 - s))
     if act == 3:
         return (u > 0).to(u.dtype)
+    if act == 4:   # d/du [u * Phi(u)] = Phi(u) + u * phi(u)
+        return 0.5 * (1 + torch.erf(u * 0.7071067811865476)) + u * torch.exp(-0.5 * u * u) * 0.3989422804014327
     return torch.ones_like(u)
 
 
@@ -149,6 +153,8 @@ def op_conv(m: Mem, o):
         st = m.view(o["STATS"], (max(o["NREP"], 1), 2, M), "f64")[0]   # any replica: finalize sums them all
         st[0] += y.double().sum((0, 2, 3))
         st[1] += (y.double() ** 2).sum((0, 2, 3))
+    if o.get("RES", -1) >= 0:
+        y = y + m.view(o["RES"], tuple(dst.shape), strides=tuple(dst.stride()))
     if o["BETA"]:
         dst.add_(y)
     else:
@@ -397,6 +403,184 @@ def op_argmax(m: Mem, o):
     m.view(o["MASK"], (B, HW, 1), "i64").copy_(losses_ref.class_mask(m.view(o["LOGITS"], (B, C, HW, 1))))
 
 
+# ---- Prithvi MAE-ViT / segmentation stages (feature-major [B][C][L] activations) -----------------------
+# arithmetic follows the reference's torch calls: nn.LayerNorm (prithvi.py via timm Block, prithvi_segmentation.py:11-20),
+# softmax attention (timm Attention, parity unpinned), random_masking (prithvi.py:258-283), forward_loss (:333-350)
+def op_chan_ln_fwd(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    x = m.view(o["X"], (B, C, HW))
+    mean = x.mean(1, keepdim=True)
+    var = x.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + o["EPS"])
+    g, b = m.view(o["GAMMA"], (C,)), m.view(o["BETA"], (C,))
+    m.view(o["Y"], (B, C, HW)).copy_((x - mean) * rstd * g.view(1, C, 1) + b.view(1, C, 1))
+    mr = m.view(o["MR"], (B, HW, 2))
+    mr[..., 0] = mean[:, 0]
+    mr[..., 1] = rstd[:, 0]
+
+
+def op_chan_ln_bwd(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    dy, x = m.view(o["DY"], (B, C, HW)), m.view(o["X"], (B, C, HW))
+    mr = m.view(o["MR"], (B, HW, 2))
+    mean, rstd = mr[..., 0].unsqueeze(1), mr[..., 1].unsqueeze(1)
+    xhat = (x - mean) * rstd
+    g = dy * m.view(o["GAMMA"], (C,)).view(1, C, 1)
+    dx = rstd * (g - g.mean(1, keepdim=True) - xhat * (g * xhat).mean(1, keepdim=True))
+    dst = m.view(o["DX"], (B, C, HW))
+    if o["ACCUM"]:
+        dst.add_(dx)
+    else:
+        dst.copy_(dx)
+    if o["DGAMMA"] >= 0:
+        m.view(o["DGAMMA"], (C,)).add_((dy * xhat).double().sum((0, 2)).to(m.fdtype))
+        m.view(o["DBETA"], (C,)).add_(dy.double().sum((0, 2)).to(m.fdtype))
+
+
+def op_act_bwd(m: Mem, o):
+    n = o["COUNT"]
+    g = m.view(o["G"], (n,))
+    g.mul_(_act_grad(m.view(o["X"], (n,)), o["ACT"]))
+
+
+def _split_qkv(t, B, H, HD, L):   # [B][3*H*HD][L] -> q, k, v each [B,H,L,HD]
+    t = t.view(B, 3, H, HD, L).permute(1, 0, 2, 4, 3)
+    return t[0], t[1], t[2]
+
+
+def op_attn_fwd(m: Mem, o):
+    B, H, HD, L = o["B"], o["HEADS"], o["HD"], o["L"]
+    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, L)), B, H, HD, L)
+    p = torch.softmax((q @ k.transpose(-2, -1)) * o["SCALE"], dim=-1)
+    out = p @ v                                              # [B,H,L,HD]
+    m.view(o["O"], (B, H, HD, L)).copy_(out.permute(0, 1, 3, 2))
+
+
+def op_attn_bwd(m: Mem, o):
+    B, H, HD, L = o["B"], o["HEADS"], o["HD"], o["L"]
+    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, L)), B, H, HD, L)
+    do = m.view(o["DO"], (B, H, HD, L)).permute(0, 1, 3, 2)  # [B,H,L,HD]
+    p = torch.softmax((q @ k.transpose(-2, -1)) * o["SCALE"], dim=-1)
+    dv = p.transpose(-2, -1) @ do
+    dp = do @ v.transpose(-2, -1)
+    ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * o["SCALE"]
+    dq = ds @ k
+    dk = ds.transpose(-2, -1) @ q
+    dst = m.view(o["DQKV"], (B, 3, H, HD, L))
+    dst[:, 0].copy_(dq.permute(0, 1, 3, 2))
+    dst[:, 1].copy_(dk.permute(0, 1, 3, 2))
+    dst[:, 2].copy_(dv.permute(0, 1, 3, 2))
+
+
+def op_mae_mask_index(m: Mem, o):
+    B, L, keep = o["B"], o["L"], o["KEEP"]
+    noise = m.view(o["NOISE"], (B, L))
+    ids_shuffle = torch.argsort(noise, dim=1, stable=True)
+    rank = torch.argsort(ids_shuffle, dim=1)
+    m.view(o["IDS_RESTORE"], (B, L), "i64").copy_(rank)
+    m.view(o["MASK"], (B, L)).copy_((rank >= keep).to(m.fdtype))
+    enc = m.view(o["ENC_IDX"], (B, 1 + keep), "i32")
+    enc[:, 0] = -1
+    enc[:, 1:] = ids_shuffle[:, :keep].to(torch.int32)
+    dec = m.view(o["DEC_IDX"], (B, 1 + L), "i32")
+    dec[:, 0] = 0
+    dec[:, 1:] = torch.where(rank < keep, rank + 1, torch.full_like(rank, -1)).to(torch.int32)
+
+
+def op_token_gather(m: Mem, o):
+    B, C, Lin, Lout = o["B"], o["C"], o["LIN"], o["LOUT"]
+    src = m.view(o["IN"], (B, C, Lin))
+    idx = m.view(o["IDX"], (B, Lout), "i32").long()
+    fill = m.view(o["FILL"], (C,))
+    got = torch.gather(src, 2, idx.clamp(min=0).unsqueeze(1).expand(-1, C, -1))
+    if fill is not None:
+        got = torch.where((idx >= 0).unsqueeze(1), got, fill.view(1, C, 1).expand(B, C, Lout))
+    if o["POS"] >= 0:
+        prow = (idx + o["POS_OFF"]) if o["POS_BY_SRC"] else torch.arange(Lout).unsqueeze(0).expand(B, -1)
+        nrows = int(prow.max().item()) + 1
+        pos = m.view(o["POS"], (nrows, C))
+        got = got + pos[prow].permute(0, 2, 1)
+    m.view(o["OUT"], (B, C, Lout)).copy_(got)
+
+
+def op_token_scatter(m: Mem, o):
+    B, C, Lin, Lout = o["B"], o["C"], o["LIN"], o["LOUT"]
+    dout = m.view(o["DOUT"], (B, C, Lout))
+    idx = m.view(o["IDX"], (B, Lout), "i32").long()
+    din = m.view(o["DIN"], (B, C, Lin))
+    din.zero_()
+    valid = idx >= 0
+    for b in range(B):
+        jj = torch.nonzero(valid[b]).flatten()
+        din[b][:, idx[b, jj]] = dout[b][:, jj]
+    if o["DFILL"] >= 0:
+        w = (~valid).to(dout.dtype).unsqueeze(1)
+        m.view(o["DFILL"], (C,)).add_((dout * w).double().sum((0, 2)).to(m.fdtype))
+
+
+def _patch_cols(x, P, TUB, order):
+    """x [B,C,T,H,W] -> [B, F, L]; order 'conv': f = (c,tt,py,px); 'mae': f = (tt,py,px,c)."""
+    B, C, T, H, W = x.shape
+    v = x.reshape(B, C, T // TUB, TUB, H // P, P, W // P, P)          # b c t tt h py w px
+    if order == "conv":
+        v = v.permute(0, 1, 3, 5, 7, 2, 4, 6)                           # b c tt py px t h w
+    else:
+        v = v.permute(0, 3, 5, 7, 1, 2, 4, 6)                           # b tt py px c t h w
+    return v.reshape(B, C * TUB * P * P, (T // TUB) * (H // P) * (W // P))
+
+
+def op_patchify(m: Mem, o):
+    B, C, T, H, W, P, TUB = (o[k] for k in ("B", "C", "T", "H", "W", "P", "TUB"))
+    x = m.view(o["X"], (B, C, T, H, W))
+    cols = _patch_cols(x, P, TUB, "conv")
+    m.view(o["OUT"], tuple(cols.shape)).copy_(cols)
+
+
+def _mae_loss_terms(m: Mem, o):
+    B, C, T, H, W, P, TUB, LP, LO = (o[k] for k in ("B", "C", "T", "H", "W", "P", "TUB", "LP", "L_OFF"))
+    x = m.view(o["IMGS"], (B, C, T, H, W))
+    target = _patch_cols(x, P, TUB, "mae")                               # [B, PD, L]
+    PD, L = target.shape[1], target.shape[2]
+    if o["NORM_PIX"]:
+        mean = target.mean(1, keepdim=True)
+        var = target.var(1, keepdim=True)                                # unbiased, as torch.var default
+        target = (target - mean) / (var + 1.0e-6) ** 0.5
+    pred = m.view(o["PRED"], (B, PD, LP))[:, :, LO:LO + L]
+    mask = m.view(o["MASK"], (B, L))
+    return pred, target, mask, PD, L
+
+
+def op_mae_loss_fwd(m: Mem, o):
+    pred, target, mask, PD, L = _mae_loss_terms(m, o)
+    per = ((pred - target) ** 2).mean(1)
+    acc = m.view(o["ACC"], (2,), "f64")
+    acc[0] = (per * mask).double().sum()
+    acc[1] = mask.double().sum()
+    m.view(o["LOSS"], (1,)).copy_((acc[0] / acc[1]).to(m.fdtype).reshape(1))
+
+
+def op_mae_loss_bwd(m: Mem, o):
+    pred, target, mask, PD, L = _mae_loss_terms(m, o)
+    acc = m.view(o["ACC"], (2,), "f64")
+    go = m.view(o["GOUT"], (1,)) if o["GOUT"] >= 0 else torch.ones(1, dtype=m.fdtype)
+    d = 2.0 * (pred - target) * mask.unsqueeze(1) * (go[0] / (PD * acc[1].to(m.fdtype)))
+    dst = m.view(o["DPRED"], (o["B"], PD, o["LP"]))
+    dst.zero_()
+    dst[:, :, o["L_OFF"]:o["L_OFF"] + L] = d
+
+
+def op_transpose_cl(m: Mem, o):
+    B, C, L, LO, Lout = o["B"], o["C"], o["L"], o["L_OFF"], o["LOUT"]
+    x = m.view(o["X"], (B, C, L))
+    m.view(o["Y"], (B, Lout, C)).copy_(x[:, :, LO:LO + Lout].permute(0, 2, 1))
+
+
+def op_drop_gate(m: Mem, o):
+    n = o["COUNT"]
+    u = m.view(o["U"], (n,))
+    m.view(o["GATE"], (n,)).copy_((u >= o["P"]).to(m.fdtype) / (1.0 - o["P"]))
+
+
 DISPATCH = {
     "MEMSET": op_memset, "AXPY": op_axpy, "WEIGHT_PACK": op_weight_pack, "CONV": op_conv, "WGRAD": op_wgrad, "WGRAD_FINALIZE": op_wgrad_finalize,
     "DWCONV_FWD": op_dwconv_fwd, "DWCONV_DGRAD": op_dwconv_dgrad, "DWCONV_WGRAD": op_dwconv_wgrad,
@@ -404,6 +588,10 @@ DISPATCH = {
     "SE_BWD_REDUCE": op_se_bwd_reduce, "BN_BWD_REDUCE": op_bn_bwd_reduce, "BN_BWD_FINALIZE": op_bn_bwd_finalize,
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
+    "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ATTN_FWD": op_attn_fwd,
+    "ATTN_BWD": op_attn_bwd, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
+    "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
+    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate,
 }
 
 

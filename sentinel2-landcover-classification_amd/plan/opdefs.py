@@ -31,8 +31,8 @@ def stats_replicas(C: int) -> int:
 
 
 # ---- prologue / activation codes -----------------------------------------------------------
-PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU = 0, 1, 2, 3          # v' = act(scale[c]*v + shift[c])
-ACT_NONE, ACT_SILU, ACT_RELU = 0, 2, 3                          # same numbering as PRO_*
+PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU, PRO_GELU = 0, 1, 2, 3, 4   # v' = act(scale[c]*v + shift[c]); GELU = exact erf form
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 2, 3, 4                   # same numbering as PRO_*
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
 
 # kind -> (t slots, n slots, d slots, f slots); positional
@@ -54,7 +54,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # MODE_CONVT_SCATTER: rows m = (co,dy,dx), stored to Y[b][co][2y+dy][2x+dx] (ConvTranspose k2 s2).
     # MODE_GATHER2X2: pseudo-channel k = (co,dy,dx) of X1 reads X1[b][co][2y+dy][2x+dx].
     # STATS (double [2][M]) accumulates sum(Y), sum(Y^2) per row for train-mode BatchNorm.
-    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS"], [],
+    # RES (same layout as Y): added to the result (the transformer's residual stream: x' = x + proj(...)).
+    # A Linear over feature-major tokens [B][C][L] is this stage with H = 1, W = L.
+    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
               "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
     # Weight gradient on f32 MFMA, K = pixels:
@@ -106,6 +108,40 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
                  ["B", "C", "HW", "MODE", "IGNORE", "REDUCE_SUM"], ["GAMMA", "SMOOTH"]),
     # MASK[b][hw] (int64) = argmax_c LOGITS[b][c][hw], first max wins
     "ARGMAX": (["LOGITS", "MASK"], [], ["B", "C", "HW"], []),
+    # ---- Prithvi MAE-ViT / segmentation head (activations are feature-major [B][C][L]: tokens play the role of pixels) ----
+    # LayerNorm over the channel axis of [B][C][HW] (token LayerNorm with HW = L; Norm2d of the neck):
+    #   MR[b][hw] = {mean, rstd};  Y = (X - mean) * rstd * GAMMA[c] + BETA[c]
+    "CHAN_LN_FWD": (["X", "GAMMA", "BETA", "Y", "MR"], [], ["B", "C", "HW"], ["EPS"]),
+    # DX (+)= rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = DY * GAMMA;  DGAMMA[c] += sum DY * xhat;  DBETA[c] += sum DY
+    "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA"], [], ["B", "C", "HW", "ACCUM"], []),
+    # G[i] *= act'(X[i])
+    "ACT_BWD": (["G", "X"], ["COUNT"], ["ACT"], []),
+    # multi-head attention on QKV [B][3*HEADS*HD][L] (rows q | k | v, each (head, d)):
+    #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d]
+    "ATTN_FWD": (["QKV", "O"], [], ["B", "HEADS", "HD", "L"], ["SCALE"]),
+    "ATTN_BWD": (["QKV", "DO", "DQKV"], [], ["B", "HEADS", "HD", "L"], ["SCALE"]),
+    # rank r of NOISE[b][l] in its row (ties: lower index first = a stable argsort): IDS_RESTORE[b][l] = r (int64),
+    # MASK[b][l] = r >= KEEP (f32);  gather tables (int32): ENC_IDX[b] = {-1 (cls), index of rank 0 .. KEEP-1},
+    # DEC_IDX[b] = {0, (r_l < KEEP ? 1 + r_l : -1) for l < L}
+    "MAE_MASK_INDEX": (["NOISE", "IDS_RESTORE", "MASK", "ENC_IDX", "DEC_IDX"], [], ["B", "L", "KEEP"], []),
+    # OUT[b][c][j] = (i = IDX[b][j]) >= 0 ? IN[b][c][i] : FILL[c];  then + POS[(POS_BY_SRC ? i + POS_OFF : j) * C + c]
+    # (POS is token-major, as the reference's pos_embed parameters)
+    "TOKEN_GATHER": (["IN", "IDX", "FILL", "POS", "OUT"], [], ["B", "C", "LIN", "LOUT", "POS_BY_SRC", "POS_OFF"], []),
+    # DIN[b][c][i] = DOUT[b][c][j] for i = IDX[b][j] >= 0 (other DIN entries zero);  DFILL[c] += sum_{b, j: IDX < 0} DOUT[b][c][j]
+    "TOKEN_SCATTER": (["DOUT", "IDX", "DIN", "DFILL"], [], ["B", "C", "LIN", "LOUT"], []),
+    # im2col of non-overlapping patches (PatchEmbed's Conv3d as a GEMM):
+    #   OUT[b][((c*TUB + tt)*P + py)*P + px][(t, h, w)] = X[b][c][t*TUB + tt][h*P + py][w*P + px]
+    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB"], []),
+    # MAE loss (prithvi.py:333-350).  PRED is feature-major [B][PD][LP], token l in column l + L_OFF, feature order
+    # (tt, py, px, c).  LOSS[0] = sum_l MASK * mean_f (PRED - target)^2 / sum MASK;  NORM_PIX: per-patch standardised target
+    "MAE_LOSS_FWD": (["PRED", "IMGS", "MASK", "LOSS", "ACC"], [],
+                     ["B", "C", "T", "H", "W", "P", "TUB", "LP", "L_OFF", "NORM_PIX"], []),
+    "MAE_LOSS_BWD": (["PRED", "IMGS", "MASK", "ACC", "GOUT", "DPRED"], [],
+                     ["B", "C", "T", "H", "W", "P", "TUB", "LP", "L_OFF", "NORM_PIX"], []),
+    # Y[b][j][c] = X[b][c][j + L_OFF], j < LOUT   (feature-major -> the reference's token-major tensors at the API boundary)
+    "TRANSPOSE_CL": (["X", "Y"], [], ["B", "C", "L", "L_OFF", "LOUT"], []),
+    # GATE[i] = (U[i] >= P) / (1 - P)   (Dropout2d: one draw per (sample, channel), applied as a channel gate of the next conv)
+    "DROP_GATE": (["U", "GATE"], ["COUNT"], [], ["P"]),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 

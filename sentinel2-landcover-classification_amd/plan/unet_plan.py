@@ -145,6 +145,25 @@ class _P:
         self.marks: list = []
         self.wpack = Arena(D.BASE["WPACK"])
         self.pack_rows = {"fwd": [], "bwd": []}
+        self.blob: list[int] = []      # int32 words of the CONST base (tables; float constants as their bit patterns)
+
+    def const_table(self, rows, width) -> TRef:
+        off = len(self.blob) * 4
+        for r in rows:
+            assert len(r) == width
+            self.blob.extend(int(v) for v in r)
+        while len(self.blob) % 64:
+            self.blob.append(0)
+        return TRef(D.BASE["CONST"], off, (len(rows), width), "i32")
+
+    def const_floats(self, values, shape) -> TRef:
+        import numpy as np
+
+        off = len(self.blob) * 4
+        self.blob.extend(int(v) for v in np.asarray(values, dtype=np.float32).reshape(-1).view(np.int32))
+        while len(self.blob) % 64:
+            self.blob.append(0)
+        return TRef(D.BASE["CONST"], off, tuple(shape), "f32")
 
     def pack_weight(self, which: str, wname: str, M: int, K: int, T: int, s_m: int, s_k: int, s_t: int, flip: int,
                     src_elem_off: int = 0):
@@ -589,6 +608,45 @@ def _numel(shape) -> int:
     return n
 
 
+def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int):
+    """Common tail of every planner: emit the backward from the tape, zero the accumulators, cut the backward
+    into bucketed segments (+ WGRAD_FINALIZE per bucket) and put the WEIGHT_PACK stages in front."""
+    table = p.const_table
+
+    def pack_op(prog: Program, rows):
+        if not rows:
+            return
+        total = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9]
+        prog.ops.insert(0, ("WEIGHT_PACK", dict(TABLE=table(rows, 12), SRC=TRef(D.BASE["PARAMS"], 0, (layout.n_params,)),
+                                                DST=TRef(D.BASE["WPACK"], 0, (p.wpack.mark() // 4,)), TOTAL=total,
+                                                N_ENTRIES=len(rows))))
+
+    fwd_aux_end = p.aux.mark()
+    if training and fwd_aux_end:
+        p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
+
+    bwd = None
+    segments = []
+    if training:
+        for back in reversed(p.tape):
+            back()
+            p.marks.append(len(p.bwd.ops))
+        bwd_aux_end = p.aux.mark()
+        pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
+        if bwd_aux_end > fwd_aux_end:
+            pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
+                                           BYTES=bwd_aux_end - fwd_aux_end)))
+        p.bwd.ops[0:0] = pre_ops
+        segments = _bucket_backward(p, layout, table, bucket_floats)
+        n_before = len(p.bwd.ops)
+        pack_op(p.bwd, p.pack_rows["bwd"])
+        if len(p.bwd.ops) > n_before:   # WEIGHT_PACK went in front
+            segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]
+        bwd = p.bwd
+    pack_op(p.fwd, p.pack_rows["fwd"])
+    return segments, bwd
+
+
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
               bucket_floats: int = 8 << 20) -> UnetPlan:
     if H % 32 or W % 32:
@@ -648,46 +706,7 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
                   bias=pre + ".3.bias")
     logits = out_conv(p, "out_conv1x1.weight", "out_conv1x1.bias", cur, spec.num_classes)
 
-    # ---- constant tables (int32 blob in the CONST base) ------------------------------------------------
-    blob: list[int] = []
+    segments, bwd = finish_plan(p, layout, training, bucket_floats)
 
-    def table(rows, width):
-        off = len(blob) * 4
-        for r in rows:
-            assert len(r) == width
-            blob.extend(int(v) for v in r)
-        while len(blob) % 4:
-            blob.append(0)
-        return TRef(D.BASE["CONST"], off, (len(rows), width), "i32")
-
-    def pack_op(prog: Program, rows):
-        if not rows:
-            return
-        total = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9]
-        prog.ops.insert(0, ("WEIGHT_PACK", dict(TABLE=table(rows, 12), SRC=TRef(D.BASE["PARAMS"], 0, (layout.n_params,)),
-                                                DST=TRef(D.BASE["WPACK"], 0, (p.wpack.mark() // 4,)), TOTAL=total,
-                                                N_ENTRIES=len(rows))))
-
-    fwd_aux_end = p.aux.mark()
-    if training and fwd_aux_end:
-        p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
-
-    bwd = None
-    if training:
-        for back in reversed(p.tape):
-            back()
-            p.marks.append(len(p.bwd.ops))
-        bwd_aux_end = p.aux.mark()
-        pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
-        if bwd_aux_end > fwd_aux_end:
-            pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
-                                           BYTES=bwd_aux_end - fwd_aux_end)))
-        p.bwd.ops[0:0] = pre_ops
-        segments = _bucket_backward(p, layout, table, bucket_floats)
-        pack_op(p.bwd, p.pack_rows["bwd"])
-        segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]   # WEIGHT_PACK went in front
-        bwd = p.bwd
-    pack_op(p.fwd, p.pack_rows["fwd"])
-
-    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), blob, layout, n,
+    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, n,
                     segments if training else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

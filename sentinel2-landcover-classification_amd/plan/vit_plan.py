@@ -1,0 +1,462 @@
+"""Planner for the Prithvi MAE-ViT path: MaskedAutoencoderViT (pre-training) and PrithviSegmentationNet
+(ViT encoder + ConvTranspose neck + FCN head).  Emits forward / backward stage programs like unet_plan.
+
+Data flow follows /root/reference/src/modules/prithvi.py (forward_encoder :285-305, forward_decoder :307-331,
+forward_loss :333-350) and prithvi_segmentation.py (:23-72, :75-111, :156-162); the transformer block is timm's
+(`Block`: pre-norm attention + MLP, restated in oracle/vit_block_ref.py — parity unpinned at that boundary).
+
+Layout: ViT activations are FEATURE-MAJOR, [B][C][L] — tokens take the place of pixels — so that
+  * every Linear is the 1x1 implicit-GEMM conv stage (tokens on the MFMA lanes, 128-B coalesced rows),
+  * LayerNorm is the same channel-LayerNorm stage the neck's Norm2d needs,
+  * q/k/v rows of one head are [hd][L] tiles that feed the MFMA operands of QK^T and PV without a transpose,
+  * the neck consumes the encoder output as [B][768][14][14] directly.
+The reference's token-major tensors (pred, latent) are produced by a TRANSPOSE_CL stage at the API boundary.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+from . import opdefs as D
+from .program import Program, TRef
+from .unet_plan import Act, ParamLayout, _P, _conv_dgrad_wgrad, _numel, conv_bn, conv_transpose, finish_plan
+
+
+@dataclass
+class MaeSpec:
+    img_size: int = 224
+    patch_size: int = 16
+    num_frames: int = 1
+    tubelet_size: int = 1
+    in_chans: int = 6
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    decoder_embed_dim: int = 512
+    decoder_depth: int = 8
+    decoder_num_heads: int = 16
+    mlp_ratio: float = 4.0
+    norm_pix_loss: bool = False
+    decoder: bool = True
+
+    @property
+    def grid(self):
+        g = self.img_size // self.patch_size
+        return (self.num_frames // self.tubelet_size, g, g)
+
+    @property
+    def num_patches(self) -> int:
+        t, h, w = self.grid
+        return t * h * w
+
+    @property
+    def patch_dim(self) -> int:
+        return self.tubelet_size * self.patch_size * self.patch_size * self.in_chans
+
+
+@dataclass
+class SegSpec:
+    mae: MaeSpec
+    num_classes: int
+    fcn_out_channels: int
+    fcn_num_convs: int
+    fcn_dropout: float
+    frozen_backbone: bool
+
+    @property
+    def embed(self) -> int:
+        return self.mae.embed_dim * self.mae.num_frames
+
+
+@dataclass
+class VitPlan:
+    spec: object
+    B: int
+    training: bool
+    fwd: Program
+    bwd: Program | None
+    ws_bytes: int
+    aux_bytes: int
+    const_table: list
+    layout: ParamLayout
+    bwd_param_marks: list
+    outputs: dict            # name -> TRef in the OUT base
+    out_bytes: int
+    noise: dict              # name -> TRef in the NOISE base (caller-supplied uniforms)
+    noise_bytes: int
+    dout_shape: tuple        # what the caller provides in DOUT (upstream gradient)
+    tensors: dict
+    wpack_bytes: int = 0
+    trainable_lo: int = 0    # flat floats [trainable_lo, n_params) receive gradients (frozen backbone sits in front)
+    x_shape: tuple = ()
+
+
+# ---- layouts (reference registration order) ---------------------------------------------
+def _block_params(L: ParamLayout, prefix: str, dim: int, hidden: int):
+    L.add_param(prefix + ".norm1.weight", (dim,))
+    L.add_param(prefix + ".norm1.bias", (dim,))
+    L.add_param(prefix + ".attn.qkv.weight", (3 * dim, dim))
+    L.add_param(prefix + ".attn.qkv.bias", (3 * dim,))
+    L.add_param(prefix + ".attn.proj.weight", (dim, dim))
+    L.add_param(prefix + ".attn.proj.bias", (dim,))
+    L.add_param(prefix + ".norm2.weight", (dim,))
+    L.add_param(prefix + ".norm2.bias", (dim,))
+    L.add_param(prefix + ".mlp.fc1.weight", (hidden, dim))
+    L.add_param(prefix + ".mlp.fc1.bias", (hidden,))
+    L.add_param(prefix + ".mlp.fc2.weight", (dim, hidden))
+    L.add_param(prefix + ".mlp.fc2.bias", (dim,))
+
+
+def mae_layout(s: MaeSpec, prefix: str = "", L: ParamLayout | None = None) -> ParamLayout:
+    """The fixed sin-cos tables are requires_grad=False parameters in the reference: they live with the buffers
+    here (never touched by the optimiser), and are surfaced under their reference names by state_dict()."""
+    L = L or ParamLayout()
+    Lp, Dm, Dd = s.num_patches, s.embed_dim, s.decoder_embed_dim
+    L.add_param(prefix + "cls_token", (1, 1, Dm))
+    L.add_buf(prefix + "pos_embed", (1, Lp + 1, Dm))
+    if s.decoder:
+        L.add_param(prefix + "mask_token", (1, 1, Dd))
+    L.add_buf(prefix + "decoder_pos_embed", (1, Lp + 1, Dd))
+    L.add_param(prefix + "patch_embed.proj.weight", (Dm, s.in_chans, s.tubelet_size, s.patch_size, s.patch_size))
+    L.add_param(prefix + "patch_embed.proj.bias", (Dm,))
+    for i in range(s.depth):
+        _block_params(L, f"{prefix}blocks.{i}", Dm, int(Dm * s.mlp_ratio))
+    L.add_param(prefix + "norm.weight", (Dm,))
+    L.add_param(prefix + "norm.bias", (Dm,))
+    if s.decoder:
+        L.add_param(prefix + "decoder_embed.weight", (Dd, Dm))
+        L.add_param(prefix + "decoder_embed.bias", (Dd,))
+        for i in range(s.decoder_depth):
+            _block_params(L, f"{prefix}decoder_blocks.{i}", Dd, int(Dd * s.mlp_ratio))
+        L.add_param(prefix + "decoder_norm.weight", (Dd,))
+        L.add_param(prefix + "decoder_norm.bias", (Dd,))
+        L.add_param(prefix + "decoder_pred.weight", (s.patch_dim, Dd))
+        L.add_param(prefix + "decoder_pred.bias", (s.patch_dim,))
+    return L
+
+
+def seg_layout(s: SegSpec) -> ParamLayout:
+    L = mae_layout(s.mae, "backbone.")
+    E = s.embed
+    nk = "neck.feature_pyramid_net."
+    for i in (0, 3, 4, 7):
+        L.add_param(f"{nk}{i}.weight", (E, E, 2, 2))
+        L.add_param(f"{nk}{i}.bias", (E,))
+        if i in (0, 4):
+            L.add_param(f"{nk}{i + 1}.ln.weight", (E,))
+            L.add_param(f"{nk}{i + 1}.ln.bias", (E,))
+    cin, idx = E, 0
+    for _ in range(s.fcn_num_convs):
+        L.add_param(f"head.net.{idx}.weight", (s.fcn_out_channels, cin, 3, 3))
+        L.add_param(f"head.net.{idx}.bias", (s.fcn_out_channels,))
+        bn = f"head.net.{idx + 1}"
+        L.add_param(bn + ".weight", (s.fcn_out_channels,))
+        L.add_param(bn + ".bias", (s.fcn_out_channels,))
+        L.add_buf(bn + ".running_mean", (s.fcn_out_channels,))
+        L.add_buf(bn + ".running_var", (s.fcn_out_channels,))
+        L.nbt.append(bn + ".num_batches_tracked")
+        cin = s.fcn_out_channels
+        idx += 3
+    idx += 1
+    L.add_param(f"head.net.{idx}.weight", (s.num_classes, cin, 1, 1))
+    L.add_param(f"head.net.{idx}.bias", (s.num_classes,))
+    return L
+
+
+# ---- building blocks ----------------------------------------------------------------------------------
+class _V:
+    """ViT emission helpers on top of the shared planner state."""
+
+    def __init__(self, p: _P, trainable):
+        self.p = p
+        self.trainable = trainable     # name -> bool (frozen backbone: no parameter gradients, no wgrad stages)
+        self._ident: dict[int, TRef] = {}
+
+    def ident_bnv(self, C: int) -> TRef:
+        """{scale 1, shift 0, mean 0, invstd 1}[C]: lets a conv apply a bare activation (GELU) as its load prologue."""
+        if C not in self._ident:
+            self._ident[C] = self.p.const_floats([1.0] * C + [0.0] * C + [0.0] * C + [1.0] * C, (4, C))
+        return self._ident[C]
+
+    # Linear over feature-major tokens = 1x1 conv stage.  y[B][M][N] = W[M][K] x + b (+ res)
+    def linear_fwd(self, wname: str, bname: str | None, x: TRef, K: int, M: int, N: int, pro: int = D.PRO_NONE,
+                   res: TRef | None = None, out: TRef | None = None) -> TRef:
+        p, B = self.p, self.p.B
+        y = out if out is not None else p.alloc("y:" + wname, (B, M, N))
+        wp, MP = p.pack_weight("fwd", wname, M, K, 1, K, 1, 1, 0)
+        p.fwd.add("CONV", X1=x, BNV1=self.ident_bnv(K) if pro != D.PRO_NONE else None, GATE1=None, X2=None, BNV2=None, WT=wp,
+                  BIAS=p.param(bname) if bname else None, Y=y, STATS=None, RES=res, B=B, C1=K, C2=0, H=1, W=N, M=M, KH=1, KW=1,
+                  STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N, PRO1=pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0,
+                  BETA=0, YC=M, NREP=1)
+        return y
+
+    def linear_bwd(self, wname: str, bname: str | None, x: TRef, dy: TRef, K: int, M: int, N: int, pro: int = D.PRO_NONE,
+                   dx: TRef | None = None, dx_beta: int = 0) -> None:
+        """weight / bias gradients (when trainable) and, if `dx` is given, the input gradient w.r.t. pro(x)."""
+        p, B = self.p, self.p.B
+        if self.trainable(wname):
+            p.table_entry(wname, M, K, 1)
+            p.bwd.add("WGRAD", P=dy, BNVP=None, GATEP=None, Q=x, BNVQ=self.ident_bnv(K) if pro != D.PRO_NONE else None, GATEQ=None,
+                      WGS=p.wgs(wname), B=B, M=M, C=K, CTOT=K, H=1, W=N, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N,
+                      PROP=D.PRO_NONE, PROQ=pro, MODE=D.MODE_CONV)
+            if bname:
+                p.bwd.add("CHANNEL_SUM", G=dy, OUT=p.pgrad(bname), B=B, C=M, HW=N)
+        if dx is not None:
+            wp, MP = p.pack_weight("bwd", wname, K, M, 1, 1, K, 1, 0)
+            p.bwd.add("CONV", X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=dx, STATS=None, RES=None,
+                      B=B, C1=M, C2=0, H=1, W=N, M=K, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N, PRO1=D.PRO_NONE, PRO2=0,
+                      MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=dx_beta, YC=K, NREP=1)
+
+    def ln_fwd(self, prefix: str, x: TRef, C: int, N: int, eps: float):
+        p, B = self.p, self.p.B
+        y = p.alloc("ln:" + prefix, (B, C, N))
+        mr = p.alloc("mr:" + prefix, (B, N, 2))
+        p.fwd.add("CHAN_LN_FWD", X=x, GAMMA=p.param(prefix + ".weight"), BETA=p.param(prefix + ".bias"), Y=y, MR=mr,
+                  B=B, C=C, HW=N, EPS=eps)
+        return y, mr
+
+    def ln_bwd(self, prefix: str, dy: TRef, x: TRef, mr: TRef, dx: TRef, C: int, N: int, accum: int):
+        p, B = self.p, self.p.B
+        tr = self.trainable(prefix + ".weight")
+        p.bwd.add("CHAN_LN_BWD", DY=dy, X=x, MR=mr, GAMMA=p.param(prefix + ".weight"), DX=dx,
+                  DGAMMA=p.pgrad(prefix + ".weight") if tr else None, DBETA=p.pgrad(prefix + ".bias") if tr else None,
+                  B=B, C=C, HW=N, ACCUM=accum)
+
+    # timm Block on [B][Dm][N] ------------------------------------------------------------------------
+    def block_fwd(self, prefix: str, x: TRef, Dm: int, heads: int, hidden: int, N: int) -> tuple[TRef, dict]:
+        p, B = self.p, self.p.B
+        hd = Dm // heads
+        h1, mr1 = self.ln_fwd(prefix + ".norm1", x, Dm, N, 1e-5)
+        qkv = self.linear_fwd(prefix + ".attn.qkv.weight", prefix + ".attn.qkv.bias", h1, Dm, 3 * Dm, N)
+        o = p.alloc("attn:" + prefix, (B, Dm, N))
+        p.fwd.add("ATTN_FWD", QKV=qkv, O=o, B=B, HEADS=heads, HD=hd, L=N, SCALE=float(hd) ** -0.5)
+        xm = self.linear_fwd(prefix + ".attn.proj.weight", prefix + ".attn.proj.bias", o, Dm, Dm, N, res=x)
+        h2, mr2 = self.ln_fwd(prefix + ".norm2", xm, Dm, N, 1e-5)
+        f1 = self.linear_fwd(prefix + ".mlp.fc1.weight", prefix + ".mlp.fc1.bias", h2, Dm, hidden, N)
+        xo = self.linear_fwd(prefix + ".mlp.fc2.weight", prefix + ".mlp.fc2.bias", f1, hidden, Dm, N, pro=D.PRO_GELU, res=xm)
+        return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, xm=xm, h2=h2, mr2=mr2, f1=f1, Dm=Dm, heads=heads,
+                        hidden=hidden, N=N)
+
+    def block_bwd(self, r: dict, g: TRef) -> None:
+        """g = gradient of the block output, [B][Dm][N]; on return it holds the gradient of the block INPUT (the
+        residual stream's gradient is accumulated in place)."""
+        p, B = self.p, self.p.B
+        pre, Dm, heads, hidden, N = r["prefix"], r["Dm"], r["heads"], r["hidden"], r["N"]
+        g_f1 = p.alloc("g:f1:" + pre, (B, hidden, N))
+        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["f1"], g, hidden, Dm, N, pro=D.PRO_GELU, dx=g_f1)
+        p.bwd.add("ACT_BWD", G=g_f1, X=r["f1"], COUNT=B * hidden * N, ACT=D.ACT_GELU)
+        g_h = p.alloc("g:h:" + pre, (B, Dm, N))       # shared scratch for both LayerNorm output gradients
+        self.linear_bwd(pre + ".mlp.fc1.weight", pre + ".mlp.fc1.bias", r["h2"], g_f1, Dm, hidden, N, dx=g_h)
+        self.ln_bwd(pre + ".norm2", g_h, r["xm"], r["mr2"], g, Dm, N, accum=1)
+        g_o = p.alloc("g:o:" + pre, (B, Dm, N))
+        self.linear_bwd(pre + ".attn.proj.weight", pre + ".attn.proj.bias", r["o"], g, Dm, Dm, N, dx=g_o)
+        g_qkv = p.alloc("g:qkv:" + pre, (B, 3 * Dm, N))
+        p.bwd.add("ATTN_BWD", QKV=r["qkv"], DO=g_o, DQKV=g_qkv, B=B, HEADS=heads, HD=Dm // heads, L=N, SCALE=float(Dm // heads) ** -0.5)
+        self.linear_bwd(pre + ".attn.qkv.weight", pre + ".attn.qkv.bias", r["h1"], g_qkv, Dm, 3 * Dm, N, dx=g_h)
+        self.ln_bwd(pre + ".norm1", g_h, r["x"], r["mr1"], g, Dm, N, accum=1)
+
+
+def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int, outs: dict, need_input_grads: bool):
+    """forward_encoder (prithvi.py:285-305).  Returns (latent [B][Dm][N], N, record for the backward)."""
+    p, B = v.p, v.p.B
+    C, T, Hh, P, tub = s.in_chans, s.num_frames, s.img_size, s.patch_size, s.tubelet_size
+    Lp, Dm = s.num_patches, s.embed_dim
+    Kp = C * tub * P * P
+    cols = p.alloc("cols:" + prefix, (B, Kp, Lp))
+    p.fwd.add("PATCHIFY", X=x_img, OUT=cols, B=B, C=C, T=T, H=Hh, W=Hh, P=P, TUB=tub)
+    pe = v.linear_fwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", cols, Kp, Dm, Lp)
+    enc_idx = p.alloc("enc_idx:" + prefix, (B, 1 + keep), "i32")
+    dec_idx = p.alloc("dec_idx:" + prefix, (B, 1 + Lp), "i32")
+    p.fwd.add("MAE_MASK_INDEX", NOISE=noise, IDS_RESTORE=outs["ids_restore"], MASK=outs["mask"], ENC_IDX=enc_idx, DEC_IDX=dec_idx,
+              B=B, L=Lp, KEEP=keep)
+    N = 1 + keep
+    x0 = p.alloc("x0:" + prefix, (B, Dm, N))
+    p.fwd.add("TOKEN_GATHER", IN=pe, IDX=enc_idx, FILL=p.param(prefix + "cls_token"), POS=p.buf(prefix + "pos_embed"), OUT=x0,
+              B=B, C=Dm, LIN=Lp, LOUT=N, POS_BY_SRC=1, POS_OFF=1)
+    recs = []
+    x = x0
+    for i in range(s.depth):
+        x, r = v.block_fwd(f"{prefix}blocks.{i}", x, Dm, s.num_heads, int(Dm * s.mlp_ratio), N)
+        recs.append(r)
+    latent, mr = v.ln_fwd(prefix + "norm", x, Dm, N, 1e-5)
+    rec = dict(prefix=prefix, cols=cols, pe=pe, enc_idx=enc_idx, dec_idx=dec_idx, x_last=x, mr=mr, blocks=recs, N=N, Kp=Kp, Lp=Lp, Dm=Dm)
+    return latent, N, rec
+
+
+def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef):
+    """g_latent: gradient of the normalised encoder output [B][Dm][N] (consumed)."""
+    p, B = v.p, v.p.B
+    prefix, N, Dm, Lp, Kp = rec["prefix"], rec["N"], rec["Dm"], rec["Lp"], rec["Kp"]
+    g = p.alloc("g:enc:" + prefix, (B, Dm, N))
+    v.ln_bwd(prefix + "norm", g_latent, rec["x_last"], rec["mr"], g, Dm, N, accum=0)
+    for r in reversed(rec["blocks"]):
+        v.block_bwd(r, g)
+    g_pe = p.alloc("g:pe:" + prefix, (B, Dm, Lp))
+    p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token"), B=B, C=Dm, LIN=Lp, LOUT=N)
+    v.linear_bwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", rec["cols"], g_pe, Kp, Dm, Lp)
+
+
+def _out(outs: dict, cursor: list, name: str, shape: tuple, dtype: str = "f32") -> TRef:
+    isz = {"f32": 4, "i64": 8, "i32": 4}[dtype]
+    t = TRef(D.BASE["OUT"], cursor[0], shape, dtype, name)
+    outs[name] = t
+    cursor[0] += (_numel(shape) * isz + 255) // 256 * 256
+    return t
+
+
+def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: ParamLayout | None = None,
+             bucket_floats: int = 8 << 20) -> VitPlan:
+    """MaskedAutoencoderViT.forward(imgs, mask_ratio) -> (loss, pred, mask) (+ latent, ids_restore for forward_encoder)."""
+    assert s.decoder
+    layout = layout or mae_layout(s)
+    p = _P(s, layout, B, s.img_size, s.img_size, training)
+    v = _V(p, lambda name: True)
+    Lp, Dm, Dd, PD = s.num_patches, s.embed_dim, s.decoder_embed_dim, s.patch_dim
+    keep = int(Lp * (1 - mask_ratio))
+    outs: dict = {}
+    cur = [0]
+    x_shape = (B, s.in_chans, s.num_frames, s.img_size, s.img_size)
+    x_img = TRef(D.BASE["X"], 0, x_shape, "f32", "imgs")
+    noise = TRef(D.BASE["NOISE"], 0, (B, Lp), "f32", "noise")
+    _out(outs, cur, "loss", (1,))
+    _out(outs, cur, "pred", (B, Lp, PD))
+    _out(outs, cur, "mask", (B, Lp))
+    _out(outs, cur, "ids_restore", (B, Lp), "i64")
+    latent, N, erec = _encoder(v, s, "", x_img, noise, keep, outs, True)
+    _out(outs, cur, "latent", (B, N, Dm))
+    p.fwd.add("TRANSPOSE_CL", X=latent, Y=outs["latent"], B=B, C=Dm, L=N, L_OFF=0, LOUT=N)
+    # decoder (:307-331)
+    dx = v.linear_fwd("decoder_embed.weight", "decoder_embed.bias", latent, Dm, Dd, N)
+    ND = Lp + 1
+    y0 = p.alloc("y0", (B, Dd, ND))
+    p.fwd.add("TOKEN_GATHER", IN=dx, IDX=erec["dec_idx"], FILL=p.param("mask_token"), POS=p.buf("decoder_pos_embed"), OUT=y0,
+              B=B, C=Dd, LIN=N, LOUT=ND, POS_BY_SRC=0, POS_OFF=0)
+    drecs = []
+    y = y0
+    for i in range(s.decoder_depth):
+        y, r = v.block_fwd(f"decoder_blocks.{i}", y, Dd, s.decoder_num_heads, int(Dd * s.mlp_ratio), ND)
+        drecs.append(r)
+    yn, mrd = v.ln_fwd("decoder_norm", y, Dd, ND, 1e-5)
+    pred_fm = v.linear_fwd("decoder_pred.weight", "decoder_pred.bias", yn, Dd, PD, ND)
+    p.fwd.add("TRANSPOSE_CL", X=pred_fm, Y=outs["pred"], B=B, C=PD, L=ND, L_OFF=1, LOUT=Lp)
+    acc = p.aux.alloc("mae_acc", (2,), "f64")
+    geo = dict(B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size, TUB=s.tubelet_size, LP=ND, L_OFF=1,
+               NORM_PIX=int(s.norm_pix_loss))
+    p.fwd.add("MAE_LOSS_FWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], LOSS=outs["loss"], ACC=acc, **geo)
+
+    def backward():
+        gout = TRef(D.BASE["DOUT"], 0, (1,), "f32", "dloss")
+        g_pred = p.alloc("g:pred", (B, PD, ND))
+        p.bwd.add("MAE_LOSS_BWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], ACC=acc, GOUT=gout, DPRED=g_pred, **geo)
+        g_yn = p.alloc("g:yn", (B, Dd, ND))
+        v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, ND, dx=g_yn)
+        g = p.alloc("g:dec", (B, Dd, ND))
+        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, ND, accum=0)
+        for r in reversed(drecs):
+            v.block_bwd(r, g)
+        g_dx = p.alloc("g:dx", (B, Dd, N))
+        p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=erec["dec_idx"], DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND)
+        g_lat = p.alloc("g:latent", (B, Dm, N))
+        v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, N, dx=g_lat)
+        _encoder_bwd(v, s, erec, g_lat)
+
+    p.tape.append(backward)
+    segments, bwd = finish_plan(p, layout, training, bucket_floats)
+    return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
+                   {"noise": noise}, B * Lp * 4, (1,), p.tensors, p.wpack.mark(), 0, x_shape)
+
+
+def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20) -> VitPlan:
+    """PrithviSegmentationNet.forward (prithvi_segmentation.py:156-162)."""
+    m = s.mae
+    assert not m.decoder
+    if m.img_size // m.patch_size * 16 != m.img_size:
+        raise ValueError("the neck upsamples the patch grid x16: img_size must be 16 * (img_size // patch_size)")
+    layout = layout or seg_layout(s)
+    p = _P(s, layout, B, m.img_size, m.img_size, training)
+    frozen = s.frozen_backbone
+    v = _V(p, lambda name: not (frozen and name.startswith("backbone.")))
+    Lp, Dm, E = m.num_patches, m.embed_dim, s.embed
+    g = m.img_size // m.patch_size
+    if m.num_frames != 1 or Lp != g * g:
+        raise ValueError("PrithviSegmentationNet lays out L tokens as a (patch_height x patch_width) map: num_frames must be 1")
+    x_shape = (B, m.in_chans, m.num_frames, m.img_size, m.img_size)
+    x_img = TRef(D.BASE["X"], 0, x_shape, "f32", "imgs")
+    noise = TRef(D.BASE["NOISE"], 0, (B, Lp), "f32", "noise")
+    drop_off = (B * Lp * 4 + 255) // 256 * 256
+    drop_u = TRef(D.BASE["NOISE"], drop_off, (B, s.fcn_out_channels), "f32", "drop_u")
+    outs: dict = {}
+    cur = [0]
+    _out(outs, cur, "logits", (B, s.num_classes, m.img_size, m.img_size))
+    _out(outs, cur, "mask", (B, Lp))
+    _out(outs, cur, "ids_restore", (B, Lp), "i64")
+    latent, N, erec = _encoder(v, m, "backbone.", x_img, noise, Lp, outs, not frozen)   # mask_ratio 0: a pure shuffle
+    # neck (:66-72): drop cls, tokens -> [B][E][g][g]
+    drop_idx = p.const_table([[j + 1 for j in range(Lp)] for _ in range(B)], Lp)
+    t0 = p.alloc("neck_in", (B, Dm, Lp))
+    p.fwd.add("TOKEN_GATHER", IN=latent, IDX=drop_idx, FILL=None, POS=None, OUT=t0, B=B, C=Dm, LIN=N, LOUT=Lp, POS_BY_SRC=0, POS_OFF=0)
+    a0 = Act(t0, Dm, g, g, needs_grad=(training and not frozen))
+    nk = "neck.feature_pyramid_net."
+
+    def norm2d_gelu(prefix: str, src: Act) -> Act:
+        """Norm2d (LayerNorm over channels, eps 1e-6) -> GELU; the GELU is the next ConvTranspose's load prologue."""
+        C, HW = src.C, src.H * src.W
+        y, mr = v.ln_fwd(prefix, src.raw, C, HW, 1e-6)
+        out = Act(y, C, src.H, src.W, v.ident_bnv(C), D.PRO_GELU)
+
+        def backward():
+            gq = out.grad                                           # w.r.t. gelu(y)
+            p.bwd.add("ACT_BWD", G=gq, X=y, COUNT=B * C * HW, ACT=D.ACT_GELU)
+            gx = p.grad_of(src, prefix + ".src")
+            v.ln_bwd(prefix, gq, src.raw, mr, gx, C, HW, accum=int(src.grad_init))
+            src.grad_init = True
+
+        p.tape.append(backward)
+        return out
+
+    def encoder_tail_backward():
+        if not (training and not frozen):
+            return
+        g_lat = p.alloc("g:latent", (B, Dm, N))
+        p.bwd.add("TOKEN_SCATTER", DOUT=a0.grad, IDX=drop_idx, DIN=g_lat, DFILL=None, B=B, C=Dm, LIN=N, LOUT=Lp)
+        _encoder_bwd(v, m, erec, g_lat)
+
+    p.tape.append(encoder_tail_backward)
+    a = conv_transpose(p, nk + "0.weight", nk + "0.bias", a0, E)
+    a = norm2d_gelu(nk + "1.ln", a)
+    a = conv_transpose(p, nk + "3.weight", nk + "3.bias", a, E)
+    a = conv_transpose(p, nk + "4.weight", nk + "4.bias", a, E)
+    a = norm2d_gelu(nk + "5.ln", a)
+    a = conv_transpose(p, nk + "7.weight", nk + "7.bias", a, E)
+    # head (:90-111)
+    idx = 0
+    for _ in range(s.fcn_num_convs):
+        a = conv_bn(p, f"head.net.{idx}.weight", f"head.net.{idx + 1}", [a], s.fcn_out_channels, 3, 1, False, D.PRO_RELU, 1e-5, 0.1,
+                    bias=f"head.net.{idx}.bias")
+        idx += 3
+    idx += 1
+    Cf, Hh = a.C, m.img_size
+    gate = None
+    if training and s.fcn_dropout > 0:
+        gate = p.alloc("drop_gate", (B, Cf))
+        p.fwd.add("DROP_GATE", U=drop_u, GATE=gate, COUNT=B * Cf, P=s.fcn_dropout)
+        a.gate = gate
+        a.mulbc = gate         # the BatchNorm backward of the producer multiplies the incoming gradient by the gate
+    wname, bname = f"head.net.{idx}.weight", f"head.net.{idx}.bias"
+    wp, MP = p.pack_weight("fwd", wname, s.num_classes, Cf, 1, Cf, 1, 1, 0)
+    p.fwd.add("CONV", X1=a.raw, BNV1=a.bnv, GATE1=gate, X2=None, BNV2=None, WT=wp, BIAS=p.param(bname), Y=outs["logits"], STATS=None,
+              RES=None, B=B, C1=Cf, C2=0, H=Hh, W=Hh, M=s.num_classes, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=Hh, WO=Hh,
+              PRO1=a.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=s.num_classes, NREP=1)
+    head_in = a
+
+    def out_backward():
+        dY = TRef(D.BASE["DOUT"], 0, (B, s.num_classes, Hh, Hh), "f32", "dlogits")
+        _conv_dgrad_wgrad(p, wname, dY, [head_in], s.num_classes, 1, 1, 0, 0, Hh, Hh, bname)
+
+    p.tape.append(out_backward)
+    segments, bwd = finish_plan(p, layout, training, bucket_floats)
+    lo = 0
+    if frozen:
+        lo = min(off for name, (off, _) in layout.params.items() if not name.startswith("backbone."))
+    noise_bytes = drop_off + B * s.fcn_out_channels * 4
+    return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
+                   {"noise": noise, "drop_u": drop_u}, noise_bytes, (B, s.num_classes, Hh, Hh), p.tensors, p.wpack.mark(), lo, x_shape)
