@@ -19,11 +19,15 @@ constexpr int NTHREADS = 256;
 // v_exp_f32 + v_rcp_f32 (~1 ulp each): far inside the 1e-3 logits bar, 3x fewer VALU ops than a true division
 __device__ __forceinline__ float silu_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
 
+// exact (erf) GELU, as nn.GELU() / F.gelu default (timm Mlp, prithvi_segmentation.py:58,62)
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+
 __device__ __forceinline__ float apply_pro(float v, int pro, float scale, float shift) {
     if (pro != S2K_PRO_NONE) {
         v = fmaf(v, scale, shift);
         if (pro == S2K_PRO_SILU) v = silu_f(v);
         else if (pro == S2K_PRO_RELU) v = fmaxf(v, 0.0f);
+        else if (pro == S2K_PRO_GELU) v = gelu_f(v);
     }
     return v;
 }
@@ -36,6 +40,7 @@ __device__ __forceinline__ float apply_pro_c(float v, float scale, float shift) 
     const float u = fmaf(v, scale, shift);
     if (PRO == S2K_PRO_SILU) return silu_f(u);
     if (PRO == S2K_PRO_RELU) return fmaxf(u, 0.0f);
+    if (PRO == S2K_PRO_GELU) return gelu_f(u);
     return u;
 }
 // call f(std::integral_constant<int, pro>) for the runtime value `pro`
@@ -44,6 +49,7 @@ __device__ __forceinline__ void dispatch_pro(int pro, F&& f) {
     if (pro == S2K_PRO_NONE) f(std::integral_constant<int, S2K_PRO_NONE>{});
     else if (pro == S2K_PRO_SILU) f(std::integral_constant<int, S2K_PRO_SILU>{});
     else if (pro == S2K_PRO_RELU) f(std::integral_constant<int, S2K_PRO_RELU>{});
+    else if (pro == S2K_PRO_GELU) f(std::integral_constant<int, S2K_PRO_GELU>{});
     else f(std::integral_constant<int, S2K_PRO_AFFINE>{});
 }
 
@@ -54,6 +60,7 @@ __device__ __forceinline__ float act_grad(float u, int act) {
         return s * (1.0f + u * (1.0f - s));
     }
     if (act == S2K_PRO_RELU) return u > 0.0f ? 1.0f : 0.0f;
+    if (act == S2K_PRO_GELU) return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * __expf(-0.5f * u * u) * 0.39894228040143268f;
     return 1.0f;
 }
 

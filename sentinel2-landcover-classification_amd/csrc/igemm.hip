@@ -26,7 +26,7 @@ namespace s2k {
 enum { BM_PIX = 0, BM_SPATIAL = 1 };
 
 struct ConvP {
-    const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias;
+    const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
     float* y;
     double* stats;
     int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 float v = acc[rm][rn][reg] + bs;
                 if (rok && cval[rn]) {
                     float* dst = p.y + ycol[rn] + (int64_t)gm * HWo;
+                    if (p.res) v += p.res[ycol[rn] + (int64_t)gm * HWo];
                     if (p.beta) v += *dst;
                     *dst = v;
                     s += v;
@@ -521,7 +522,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.bias = ref_ptr<const float>(c, op.t[S2K_CONV_T_BIAS]);
     p.y = ref_ptr<float>(c, op.t[S2K_CONV_T_Y]);
     p.stats = ref_ptr<double>(c, op.t[S2K_CONV_T_STATS]);
-    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats};
+    p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
+    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res};
     for (const void* q : ptrs)
         if (q == reinterpret_cast<const void*>(1)) { set_error("conv: tensor references a null base"); return S2K_EFAULT; }
     const int32_t* d = op.d;
@@ -556,8 +558,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         if (T != 1 || p.S != 1 || p.C2 != 0 || p.HO != p.H || p.WO != p.W) {
             set_error("conv: scatter/gather modes are 1x1 over the low-resolution grid"); return S2K_EINVAL;
         }
-        if (p.mode == S2K_MODE_CONVT_SCATTER && ((p.M & 3) || p.beta || p.stats)) {
-            set_error("conv: scatter needs M = 4*Cout, beta = 0, no stats"); return S2K_EINVAL;
+        if (p.mode == S2K_MODE_CONVT_SCATTER && ((p.M & 3) || p.beta || p.stats || p.res)) {
+            set_error("conv: scatter needs M = 4*Cout, beta = 0, no stats, no residual"); return S2K_EINVAL;
         }
         if (p.mode == S2K_MODE_GATHER2X2 && ((p.C1 & 3) || p.pro1 != S2K_PRO_NONE || p.gate1)) {
             set_error("conv: gather needs C1 = 4*Cout and no prologue"); return S2K_EINVAL;

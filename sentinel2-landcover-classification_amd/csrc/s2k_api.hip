@@ -41,6 +41,19 @@ int launch_channel_sum(const S2kOp&, const Ctx&);
 int launch_loss_fwd(const S2kOp&, const Ctx&);
 int launch_loss_bwd(const S2kOp&, const Ctx&);
 int launch_argmax(const S2kOp&, const Ctx&);
+int launch_chan_ln_fwd(const S2kOp&, const Ctx&);
+int launch_chan_ln_bwd(const S2kOp&, const Ctx&);
+int launch_act_bwd(const S2kOp&, const Ctx&);
+int launch_attn_fwd(const S2kOp&, const Ctx&);
+int launch_attn_bwd(const S2kOp&, const Ctx&);
+int launch_mae_mask_index(const S2kOp&, const Ctx&);
+int launch_token_gather(const S2kOp&, const Ctx&);
+int launch_token_scatter(const S2kOp&, const Ctx&);
+int launch_patchify(const S2kOp&, const Ctx&);
+int launch_mae_loss_fwd(const S2kOp&, const Ctx&);
+int launch_mae_loss_bwd(const S2kOp&, const Ctx&);
+int launch_transpose_cl(const S2kOp&, const Ctx&);
+int launch_drop_gate(const S2kOp&, const Ctx&);
 int launch_adam(float*, const float*, float*, float*, int64_t, float, float, float, float, float, int, hipStream_t);
 int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
 
@@ -58,7 +71,8 @@ static int launch_memset(const S2kOp& op, const Ctx& c) {
 static const char* const kNames[S2K_N_KINDS + 1] = {
     nullptr, "MEMSET", "AXPY", "WEIGHT_PACK", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
     "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
-    "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX"};
+    "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX",
+    "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "DROP_GATE"};
 
 static int dispatch(const S2kOp& op, const Ctx& c) {
     switch (op.kind) {
@@ -84,6 +98,19 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_LOSS_FWD: return launch_loss_fwd(op, c);
         case S2K_OP_LOSS_BWD: return launch_loss_bwd(op, c);
         case S2K_OP_ARGMAX: return launch_argmax(op, c);
+        case S2K_OP_CHAN_LN_FWD: return launch_chan_ln_fwd(op, c);
+        case S2K_OP_CHAN_LN_BWD: return launch_chan_ln_bwd(op, c);
+        case S2K_OP_ACT_BWD: return launch_act_bwd(op, c);
+        case S2K_OP_ATTN_FWD: return launch_attn_fwd(op, c);
+        case S2K_OP_ATTN_BWD: return launch_attn_bwd(op, c);
+        case S2K_OP_MAE_MASK_INDEX: return launch_mae_mask_index(op, c);
+        case S2K_OP_TOKEN_GATHER: return launch_token_gather(op, c);
+        case S2K_OP_TOKEN_SCATTER: return launch_token_scatter(op, c);
+        case S2K_OP_PATCHIFY: return launch_patchify(op, c);
+        case S2K_OP_MAE_LOSS_FWD: return launch_mae_loss_fwd(op, c);
+        case S2K_OP_MAE_LOSS_BWD: return launch_mae_loss_bwd(op, c);
+        case S2K_OP_TRANSPOSE_CL: return launch_transpose_cl(op, c);
+        case S2K_OP_DROP_GATE: return launch_drop_gate(op, c);
         default: set_error("unknown stage kind %d", op.kind); return S2K_ENOSYS;
     }
 }

@@ -1,0 +1,521 @@
+// HBM-bound stages of the Prithvi MAE-ViT path on feature-major [B][C][L] activations:
+// channel LayerNorm (token LayerNorm of timm's Block and the neck's Norm2d, prithvi_segmentation.py:11-20),
+// GELU backward, random masking (prithvi.py:258-283) as a rank kernel + token gather / scatter, the patch
+// im2col of PatchEmbed (:84-127), the MAE reconstruction loss (:333-350), the layout change at the API
+// boundary and the Dropout2d keep-gate of the FCN head (prithvi_segmentation.py:106).
+// Lanes always run along the contiguous token / pixel axis (coalesced 256-B wave rows).
+#include "common.h"
+
+namespace s2k {
+
+template <typename T>
+static T* ref_ptr(const Ctx& c, int64_t ref) {
+    if (ref < 0) return nullptr;
+    const int base = (int)(ref >> 56);
+    const int64_t off = ref & ((1ll << 56) - 1);
+    if (base >= c.n_bases || c.bases[base] == nullptr) return reinterpret_cast<T*>(1);
+    return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
+}
+static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
+#define CHECK_PTRS(name, ...)                                                                         \
+    do {                                                                                              \
+        const void* _ps[] = {__VA_ARGS__};                                                            \
+        for (const void* _q : _ps)                                                                    \
+            if (bad(_q)) { set_error(name ": tensor references a null base"); return S2K_EFAULT; }    \
+    } while (0)
+
+// ---------------- channel LayerNorm ---------------------------------------------------------------------
+// One workgroup = 64 consecutive positions (lanes) of one sample x all C channels; the four waves split the
+// channels, combine their per-position sums through LDS, then each normalises its own channels.
+struct LnP {
+    const float *x, *gamma, *beta, *dy, *mr_in;
+    float *y, *mr, *dx, *dgamma, *dbeta;
+    int B, C, HW, tiles_per_b, accum;
+    float eps;
+};
+
+__global__ void __launch_bounds__(NTHREADS) chan_ln_fwd_kernel(const LnP p) {
+    __shared__ double red[4][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / p.tiles_per_b);
+        const int hw = (int)(tile - (int64_t)b * p.tiles_per_b) * 64 + lane;
+        const bool ok = hw < p.HW;
+        const float* xb = p.x + (int64_t)b * p.C * p.HW + (ok ? hw : 0);
+        double s = 0.0, q = 0.0;
+        for (int c = wave; c < p.C; c += 4) {
+            const float v = ok ? xb[(int64_t)c * p.HW] : 0.0f;
+            s += v;
+            q += (double)v * v;
+        }
+        red[wave][lane][0] = s;
+        red[wave][lane][1] = q;
+        __syncthreads();
+        s = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
+        q = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+        const double mean = s / p.C;
+        double var = q / p.C - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float mf = (float)mean;
+        if (ok && wave == 0) {
+            float* mr = p.mr + ((int64_t)b * p.HW + hw) * 2;
+            mr[0] = mf;
+            mr[1] = rstd;
+        }
+        float* yb = p.y + (int64_t)b * p.C * p.HW + (ok ? hw : 0);
+        for (int c = wave; c < p.C; c += 4) {
+            if (ok) yb[(int64_t)c * p.HW] = fmaf((xb[(int64_t)c * p.HW] - mf) * rstd, p.gamma[c], p.beta[c]);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_chan_ln_fwd(const S2kOp& op, const Ctx& c) {
+    LnP p{};
+    p.x = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_FWD_T_X]);
+    p.gamma = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_FWD_T_GAMMA]);
+    p.beta = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_FWD_T_BETA]);
+    p.y = ref_ptr<float>(c, op.t[S2K_CHAN_LN_FWD_T_Y]);
+    p.mr = ref_ptr<float>(c, op.t[S2K_CHAN_LN_FWD_T_MR]);
+    CHECK_PTRS("chan_ln_fwd", p.x, p.gamma, p.beta, p.y, p.mr);
+    p.B = op.d[S2K_CHAN_LN_FWD_D_B]; p.C = op.d[S2K_CHAN_LN_FWD_D_C]; p.HW = op.d[S2K_CHAN_LN_FWD_D_HW];
+    p.eps = op.f[S2K_CHAN_LN_FWD_F_EPS];
+    if (!p.x || !p.gamma || !p.beta || !p.y || !p.mr || p.B <= 0 || p.C <= 0 || p.HW <= 0) { set_error("chan_ln_fwd: bad args"); return S2K_EINVAL; }
+    p.tiles_per_b = cdiv(p.HW, 64);
+    const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(NTHREADS), 0, c.stream, p);
+    return S2K_OK;
+}
+
+// backward: dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma; the per-channel parameter
+// sums of a workgroup's tiles are collected in LDS (each wave owns its channels) and flushed once at the end
+__global__ void __launch_bounds__(NTHREADS) chan_ln_bwd_kernel(const LnP p) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* pg = lsm;              // [C] dgamma partial
+    float* pb = lsm + p.C;        // [C] dbeta partial
+    float(*red)[64][2] = reinterpret_cast<float(*)[64][2]>(lsm + 2 * p.C);   // [4][64][2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool want_p = p.dgamma != nullptr;
+    for (int c = threadIdx.x; c < 2 * p.C; c += NTHREADS) lsm[c] = 0.0f;
+    __syncthreads();
+    const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
+    const float invC = 1.0f / p.C;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / p.tiles_per_b);
+        const int hw = (int)(tile - (int64_t)b * p.tiles_per_b) * 64 + lane;
+        const bool ok = hw < p.HW;
+        const int64_t base = (int64_t)b * p.C * p.HW + (ok ? hw : 0);
+        float mean = 0.0f, rstd = 0.0f;
+        if (ok) {
+            const float* mr = p.mr_in + ((int64_t)b * p.HW + hw) * 2;
+            mean = mr[0];
+            rstd = mr[1];
+        }
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int c = wave; c < p.C; c += 4) {
+            const float dyv = ok ? p.dy[base + (int64_t)c * p.HW] : 0.0f;
+            const float xh = ok ? (p.x[base + (int64_t)c * p.HW] - mean) * rstd : 0.0f;
+            const float g = dyv * p.gamma[c];
+            s1 += g;
+            s2 = fmaf(g, xh, s2);
+        }
+        red[wave][lane][0] = s1;
+        red[wave][lane][1] = s2;
+        __syncthreads();
+        s1 = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
+        s2 = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+        const float m1 = s1 * invC, m2 = s2 * invC;
+        for (int c = wave; c < p.C; c += 4) {
+            const float dyv = ok ? p.dy[base + (int64_t)c * p.HW] : 0.0f;
+            const float xh = ok ? (p.x[base + (int64_t)c * p.HW] - mean) * rstd : 0.0f;
+            const float g = dyv * p.gamma[c];
+            float d = rstd * (g - m1 - xh * m2);
+            if (ok) {
+                float* dst = p.dx + base + (int64_t)c * p.HW;
+                if (p.accum) d += *dst;
+                *dst = d;
+            }
+            if (want_p) {
+                const float a = wave_sum_hi(dyv * xh), bb = wave_sum_hi(dyv);
+                if (lane == 63) { pg[c] += a; pb[c] += bb; }
+            }
+        }
+        __syncthreads();
+    }
+    if (want_p) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += NTHREADS) {
+            atomicAdd(p.dgamma + c, pg[c]);
+            atomicAdd(p.dbeta + c, pb[c]);
+        }
+    }
+}
+
+int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
+    LnP p{};
+    p.dy = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_DY]);
+    p.x = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_X]);
+    p.mr_in = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_MR]);
+    p.gamma = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_GAMMA]);
+    p.dx = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DX]);
+    p.dgamma = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DGAMMA]);
+    p.dbeta = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DBETA]);
+    CHECK_PTRS("chan_ln_bwd", p.dy, p.x, p.mr_in, p.gamma, p.dx, p.dgamma, p.dbeta);
+    p.B = op.d[S2K_CHAN_LN_BWD_D_B]; p.C = op.d[S2K_CHAN_LN_BWD_D_C]; p.HW = op.d[S2K_CHAN_LN_BWD_D_HW];
+    p.accum = op.d[S2K_CHAN_LN_BWD_D_ACCUM];
+    if (!p.dy || !p.x || !p.mr_in || !p.gamma || !p.dx || p.B <= 0 || p.C <= 0 || p.HW <= 0 || (!p.dgamma != !p.dbeta)) {
+        set_error("chan_ln_bwd: bad args"); return S2K_EINVAL;
+    }
+    p.tiles_per_b = cdiv(p.HW, 64);
+    const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
+    const size_t lds = (2 * (size_t)p.C + 4 * 64 * 2) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("chan_ln_bwd: C too large"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(NTHREADS), lds, c.stream, p);
+    return S2K_OK;
+}
+
+// ---------------- G *= act'(X) ---------------------------------------------------------------------------
+__global__ void act_bwd_kernel(float* g, const float* x, int64_t n, int act) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= act_grad(x[i], act);
+}
+
+int launch_act_bwd(const S2kOp& op, const Ctx& c) {
+    float* g = ref_ptr<float>(c, op.t[S2K_ACT_BWD_T_G]);
+    const float* x = ref_ptr<const float>(c, op.t[S2K_ACT_BWD_T_X]);
+    CHECK_PTRS("act_bwd", g, x);
+    const int64_t n = op.n[S2K_ACT_BWD_N_COUNT];
+    const int act = op.d[S2K_ACT_BWD_D_ACT];
+    if (!g || !x || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU)) { set_error("act_bwd: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, g, x, n, act);
+    return S2K_OK;
+}
+
+// ---------------- Dropout2d keep gate --------------------------------------------------------------------
+__global__ void drop_gate_kernel(const float* u, float* gate, int64_t n, float prob) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gate[i] = u[i] >= prob ? 1.0f / (1.0f - prob) : 0.0f;
+}
+
+int launch_drop_gate(const S2kOp& op, const Ctx& c) {
+    const float* u = ref_ptr<const float>(c, op.t[S2K_DROP_GATE_T_U]);
+    float* gate = ref_ptr<float>(c, op.t[S2K_DROP_GATE_T_GATE]);
+    CHECK_PTRS("drop_gate", u, gate);
+    const int64_t n = op.n[S2K_DROP_GATE_N_COUNT];
+    const float prob = op.f[S2K_DROP_GATE_F_P];
+    if (!u || !gate || n <= 0 || !(prob >= 0.0f && prob < 1.0f)) { set_error("drop_gate: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(drop_gate_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, c.stream, u, gate, n, prob);
+    return S2K_OK;
+}
+
+// ---------------- rank of the masking noise -> ids_restore, mask, gather tables ------------------------------
+// one workgroup per sample; rank[i] = #{j : n[j] < n[i] or (n[j] == n[i] and j < i)}  (= a stable argsort)
+__global__ void __launch_bounds__(NTHREADS) mae_mask_index_kernel(const float* noise, int64_t* ids_restore, float* mask, int* enc_idx,
+                                                                    int* dec_idx, int L, int keep) {
+    extern __shared__ __attribute__((aligned(16))) float ns[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < L; i += NTHREADS) ns[i] = noise[(int64_t)b * L + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        enc_idx[(int64_t)b * (1 + keep)] = -1;
+        dec_idx[(int64_t)b * (1 + L)] = 0;
+    }
+    for (int i = threadIdx.x; i < L; i += NTHREADS) {
+        const float v = ns[i];
+        int r = 0;
+        for (int j = 0; j < L; ++j) {
+            const float w = ns[j];
+            r += (w < v || (w == v && j < i)) ? 1 : 0;
+        }
+        ids_restore[(int64_t)b * L + i] = r;
+        mask[(int64_t)b * L + i] = r >= keep ? 1.0f : 0.0f;
+        if (r < keep) enc_idx[(int64_t)b * (1 + keep) + 1 + r] = i;
+        dec_idx[(int64_t)b * (1 + L) + 1 + i] = r < keep ? 1 + r : -1;
+    }
+}
+
+int launch_mae_mask_index(const S2kOp& op, const Ctx& c) {
+    const float* noise = ref_ptr<const float>(c, op.t[S2K_MAE_MASK_INDEX_T_NOISE]);
+    int64_t* ids = ref_ptr<int64_t>(c, op.t[S2K_MAE_MASK_INDEX_T_IDS_RESTORE]);
+    float* mask = ref_ptr<float>(c, op.t[S2K_MAE_MASK_INDEX_T_MASK]);
+    int* enc = ref_ptr<int>(c, op.t[S2K_MAE_MASK_INDEX_T_ENC_IDX]);
+    int* dec = ref_ptr<int>(c, op.t[S2K_MAE_MASK_INDEX_T_DEC_IDX]);
+    CHECK_PTRS("mae_mask_index", noise, ids, mask, enc, dec);
+    const int B = op.d[S2K_MAE_MASK_INDEX_D_B], L = op.d[S2K_MAE_MASK_INDEX_D_L], keep = op.d[S2K_MAE_MASK_INDEX_D_KEEP];
+    if (!noise || !ids || !mask || !enc || !dec || B <= 0 || L <= 0 || keep < 0 || keep > L || L > 12288) { set_error("mae_mask_index: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(mae_mask_index_kernel, dim3(B), dim3(NTHREADS), (size_t)L * sizeof(float), c.stream, noise, ids, mask, enc, dec, L, keep);
+    return S2K_OK;
+}
+
+// ---------------- token gather / scatter --------------------------------------------------------------------
+struct TokP {
+    const float *in, *fill, *pos, *dout;
+    const int* idx;
+    float *out, *din, *dfill;
+    int B, C, Lin, Lout, pos_by_src, pos_off;
+};
+
+__global__ void token_gather_kernel(const TokP p) {
+    const int64_t n = (int64_t)p.B * p.C * p.Lout;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int j = (int)(i % p.Lout);
+        const int64_t bc = i / p.Lout;
+        const int cc = (int)(bc % p.C), b = (int)(bc / p.C);
+        const int src = p.idx[(int64_t)b * p.Lout + j];
+        float v = src >= 0 ? p.in[bc * p.Lin + src] : (p.fill ? p.fill[cc] : 0.0f);
+        if (p.pos) v += p.pos[(int64_t)(p.pos_by_src ? src + p.pos_off : j) * p.C + cc];
+        p.out[i] = v;
+    }
+}
+
+int launch_token_gather(const S2kOp& op, const Ctx& c) {
+    TokP p{};
+    p.in = ref_ptr<const float>(c, op.t[S2K_TOKEN_GATHER_T_IN]);
+    p.idx = ref_ptr<const int>(c, op.t[S2K_TOKEN_GATHER_T_IDX]);
+    p.fill = ref_ptr<const float>(c, op.t[S2K_TOKEN_GATHER_T_FILL]);
+    p.pos = ref_ptr<const float>(c, op.t[S2K_TOKEN_GATHER_T_POS]);
+    p.out = ref_ptr<float>(c, op.t[S2K_TOKEN_GATHER_T_OUT]);
+    CHECK_PTRS("token_gather", p.in, p.idx, p.fill, p.pos, p.out);
+    p.B = op.d[S2K_TOKEN_GATHER_D_B]; p.C = op.d[S2K_TOKEN_GATHER_D_C]; p.Lin = op.d[S2K_TOKEN_GATHER_D_LIN];
+    p.Lout = op.d[S2K_TOKEN_GATHER_D_LOUT]; p.pos_by_src = op.d[S2K_TOKEN_GATHER_D_POS_BY_SRC]; p.pos_off = op.d[S2K_TOKEN_GATHER_D_POS_OFF];
+    if (!p.in || !p.idx || !p.out || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0) { set_error("token_gather: bad args"); return S2K_EINVAL; }
+    const int64_t n = (int64_t)p.B * p.C * p.Lout;
+    hipLaunchKernelGGL(token_gather_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, p);
+    return S2K_OK;
+}
+
+// one wave per (b, c) row: the row of DIN is assembled in LDS (zero, scatter, copy out), the gradient of the fill
+// token is a wave sum + one atomic per row
+__global__ void __launch_bounds__(NTHREADS) token_scatter_kernel(const TokP p) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [4][Lin]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* row = rows + (size_t)wave * p.Lin;
+    const int64_t nrows = (int64_t)p.B * p.C;
+    for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < nrows; r0 += (int64_t)gridDim.x * 4) {
+        const int64_t r = r0 + wave;
+        const bool ok = r < nrows;
+        const int b = ok ? (int)(r / p.C) : 0, cc = ok ? (int)(r % p.C) : 0;
+        for (int i = lane; i < p.Lin; i += 64) row[i] = 0.0f;
+        __syncthreads();
+        float acc = 0.0f;
+        if (ok)
+            for (int j = lane; j < p.Lout; j += 64) {
+                const int dst = p.idx[(int64_t)b * p.Lout + j];
+                const float v = p.dout[r * p.Lout + j];
+                if (dst >= 0) row[dst] = v;
+                else acc += v;
+            }
+        __syncthreads();
+        if (ok)
+            for (int i = lane; i < p.Lin; i += 64) p.din[r * p.Lin + i] = row[i];
+        if (p.dfill) {
+            acc = wave_sum_hi(acc);
+            if (ok && lane == 63) atomicAdd(p.dfill + cc, acc);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_token_scatter(const S2kOp& op, const Ctx& c) {
+    TokP p{};
+    p.dout = ref_ptr<const float>(c, op.t[S2K_TOKEN_SCATTER_T_DOUT]);
+    p.idx = ref_ptr<const int>(c, op.t[S2K_TOKEN_SCATTER_T_IDX]);
+    p.din = ref_ptr<float>(c, op.t[S2K_TOKEN_SCATTER_T_DIN]);
+    p.dfill = ref_ptr<float>(c, op.t[S2K_TOKEN_SCATTER_T_DFILL]);
+    CHECK_PTRS("token_scatter", p.dout, p.idx, p.din, p.dfill);
+    p.B = op.d[S2K_TOKEN_SCATTER_D_B]; p.C = op.d[S2K_TOKEN_SCATTER_D_C]; p.Lin = op.d[S2K_TOKEN_SCATTER_D_LIN]; p.Lout = op.d[S2K_TOKEN_SCATTER_D_LOUT];
+    if (!p.dout || !p.idx || !p.din || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0 || p.Lin > 4096) { set_error("token_scatter: bad args"); return S2K_EINVAL; }
+    const int64_t nrows = (int64_t)p.B * p.C;
+    hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nrows, 4), 4096)), dim3(NTHREADS), (size_t)4 * p.Lin * sizeof(float), c.stream, p);
+    return S2K_OK;
+}
+
+// ---------------- patch geometry shared by PATCHIFY and the MAE loss -----------------------------------------
+struct PatchP {
+    const float *x, *pred, *mask, *gout;
+    float *out, *loss, *dpred;
+    double* acc;
+    int B, C, T, H, W, P, TUB, LP, L_OFF, norm_pix;
+    int gt, gh, gw, L, PD;
+};
+
+static int fill_patch(PatchP& p, const int32_t* d) {
+    p.B = d[0]; p.C = d[1]; p.T = d[2]; p.H = d[3]; p.W = d[4]; p.P = d[5]; p.TUB = d[6];
+    if (p.B <= 0 || p.C <= 0 || p.T <= 0 || p.H <= 0 || p.W <= 0 || p.P <= 0 || p.TUB <= 0 || p.T % p.TUB || p.H % p.P || p.W % p.P) {
+        set_error("patch geometry: bad dims"); return S2K_EINVAL;
+    }
+    p.gt = p.T / p.TUB; p.gh = p.H / p.P; p.gw = p.W / p.P;
+    p.L = p.gt * p.gh * p.gw;
+    p.PD = p.TUB * p.P * p.P * p.C;
+    return S2K_OK;
+}
+
+// OUT[b][((c*TUB + tt)*P + py)*P + px][l] ; lanes along l
+__global__ void patchify_kernel(const PatchP p) {
+    const int64_t n = (int64_t)p.B * p.PD * p.L;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int l = (int)(i % p.L);
+        const int64_t bk = i / p.L;
+        const int k = (int)(bk % p.PD), b = (int)(bk / p.PD);
+        const int px = k % p.P, py = (k / p.P) % p.P, tt = (k / (p.P * p.P)) % p.TUB, cc = k / (p.P * p.P * p.TUB);
+        const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
+        p.out[i] = p.x[((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px];
+    }
+}
+
+int launch_patchify(const S2kOp& op, const Ctx& c) {
+    PatchP p{};
+    if (int e = fill_patch(p, op.d)) return e;
+    p.x = ref_ptr<const float>(c, op.t[S2K_PATCHIFY_T_X]);
+    p.out = ref_ptr<float>(c, op.t[S2K_PATCHIFY_T_OUT]);
+    CHECK_PTRS("patchify", p.x, p.out);
+    if (!p.x || !p.out) { set_error("patchify: missing tensor"); return S2K_EINVAL; }
+    const int64_t n = (int64_t)p.B * p.PD * p.L;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 16384)), dim3(256), 0, c.stream, p);
+    return S2K_OK;
+}
+
+// target value f = ((tt*P + py)*P + px)*C + c of patch l of sample b (prithvi.py:236-245)
+__device__ __forceinline__ float patch_target(const PatchP& p, int b, int l, int f) {
+    const int cc = f % p.C, px = (f / p.C) % p.P, py = (f / (p.C * p.P)) % p.P, tt = f / (p.C * p.P * p.P);
+    const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
+    return p.x[((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px];
+}
+
+__device__ __forceinline__ void patch_norm(const PatchP& p, int b, int l, float& mean, float& inv) {
+    mean = 0.0f;
+    inv = 1.0f;
+    if (!p.norm_pix) return;
+    double s = 0.0, q = 0.0;
+    for (int f = 0; f < p.PD; ++f) {
+        const float v = patch_target(p, b, l, f);
+        s += v;
+        q += (double)v * v;
+    }
+    const double m = s / p.PD;
+    const double var = (q - p.PD * m * m) / (p.PD - 1);   // unbiased, torch.var default (prithvi.py:343)
+    mean = (float)m;
+    inv = (float)(1.0 / sqrt(var + 1.0e-6));
+}
+
+// one thread per (b, l): lanes along l read PRED coalesced
+__global__ void __launch_bounds__(NTHREADS) mae_loss_fwd_kernel(const PatchP p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double num = 0.0, den = 0.0;
+    if (i < (int64_t)p.B * p.L) {
+        const int b = (int)(i / p.L), l = (int)(i % p.L);
+        const float mk = p.mask[i];
+        den = mk;
+        if (mk != 0.0f) {
+            float mean, inv;
+            patch_norm(p, b, l, mean, inv);
+            const float* pr = p.pred + (int64_t)b * p.PD * p.LP + l + p.L_OFF;
+            float s = 0.0f;
+            for (int f = 0; f < p.PD; ++f) {
+                const float d = pr[(int64_t)f * p.LP] - (patch_target(p, b, l, f) - mean) * inv;
+                s = fmaf(d, d, s);
+            }
+            num = (double)(s / p.PD) * mk;
+        }
+    }
+    num = wave_sum_d(num);
+    den = wave_sum_d(den);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_add_d(p.acc, num);
+        atomic_add_d(p.acc + 1, den);
+    }
+}
+
+__global__ void mae_loss_finish_kernel(const PatchP p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) p.loss[0] = (float)(p.acc[0] / p.acc[1]);   // 0/0 -> NaN at mask_ratio 0, as the reference
+}
+
+__global__ void __launch_bounds__(NTHREADS) mae_loss_bwd_kernel(const PatchP p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, column of DPRED)
+    if (i >= (int64_t)p.B * p.LP) return;
+    const int b = (int)(i / p.LP), col = (int)(i % p.LP);
+    float* dst = p.dpred + (int64_t)b * p.PD * p.LP + col;
+    const int l = col - p.L_OFF;
+    const float mk = (l >= 0 && l < p.L) ? p.mask[(int64_t)b * p.L + l] : 0.0f;
+    if (mk == 0.0f) {
+        for (int f = 0; f < p.PD; ++f) dst[(int64_t)f * p.LP] = 0.0f;
+        return;
+    }
+    float mean, inv;
+    patch_norm(p, b, l, mean, inv);
+    const float go = p.gout ? p.gout[0] : 1.0f;
+    const float k = 2.0f * mk * go / ((float)p.PD * (float)p.acc[1]);
+    const float* pr = p.pred + (int64_t)b * p.PD * p.LP + col;
+    for (int f = 0; f < p.PD; ++f) dst[(int64_t)f * p.LP] = k * (pr[(int64_t)f * p.LP] - (patch_target(p, b, l, f) - mean) * inv);
+}
+
+static int mae_loss_common(PatchP& p, const S2kOp& op) {
+    if (int e = fill_patch(p, op.d)) return e;
+    p.LP = op.d[7]; p.L_OFF = op.d[8]; p.norm_pix = op.d[9];
+    if (p.LP < p.L + p.L_OFF || p.L_OFF < 0) { set_error("mae_loss: LP/L_OFF inconsistent with the patch grid"); return S2K_EINVAL; }
+    return S2K_OK;
+}
+
+int launch_mae_loss_fwd(const S2kOp& op, const Ctx& c) {
+    PatchP p{};
+    if (int e = mae_loss_common(p, op)) return e;
+    p.pred = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_FWD_T_PRED]);
+    p.x = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_FWD_T_IMGS]);
+    p.mask = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_FWD_T_MASK]);
+    p.loss = ref_ptr<float>(c, op.t[S2K_MAE_LOSS_FWD_T_LOSS]);
+    p.acc = ref_ptr<double>(c, op.t[S2K_MAE_LOSS_FWD_T_ACC]);
+    CHECK_PTRS("mae_loss_fwd", p.pred, p.x, p.mask, p.loss, p.acc);
+    if (!p.pred || !p.x || !p.mask || !p.loss || !p.acc) { set_error("mae_loss_fwd: missing tensor"); return S2K_EINVAL; }
+    (void)hipMemsetAsync(p.acc, 0, 2 * sizeof(double), c.stream);
+    hipLaunchKernelGGL(mae_loss_fwd_kernel, dim3((unsigned)cdiv64((int64_t)p.B * p.L, NTHREADS)), dim3(NTHREADS), 0, c.stream, p);
+    hipLaunchKernelGGL(mae_loss_finish_kernel, dim3(1), dim3(64), 0, c.stream, p);
+    return S2K_OK;
+}
+
+int launch_mae_loss_bwd(const S2kOp& op, const Ctx& c) {
+    PatchP p{};
+    if (int e = mae_loss_common(p, op)) return e;
+    p.pred = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_BWD_T_PRED]);
+    p.x = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_BWD_T_IMGS]);
+    p.mask = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_BWD_T_MASK]);
+    p.acc = ref_ptr<double>(c, op.t[S2K_MAE_LOSS_BWD_T_ACC]);
+    p.gout = ref_ptr<const float>(c, op.t[S2K_MAE_LOSS_BWD_T_GOUT]);
+    p.dpred = ref_ptr<float>(c, op.t[S2K_MAE_LOSS_BWD_T_DPRED]);
+    CHECK_PTRS("mae_loss_bwd", p.pred, p.x, p.mask, p.acc, p.gout, p.dpred);
+    if (!p.pred || !p.x || !p.mask || !p.acc || !p.dpred) { set_error("mae_loss_bwd: missing tensor"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3((unsigned)cdiv64((int64_t)p.B * p.LP, NTHREADS)), dim3(NTHREADS), 0, c.stream, p);
+    return S2K_OK;
+}
+
+// ---------------- [B][C][L] -> [B][LOUT][C] through a 64x64 LDS tile -------------------------------------------
+__global__ void __launch_bounds__(NTHREADS) transpose_cl_kernel(const float* x, float* y, int B, int C, int L, int l_off, int Lout) {
+    __shared__ float tile[64][65];
+    const int ct = blockIdx.x, lt = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < 64; r += 4) {   // r = channel inside the tile, lanes along tokens
+        const int cc = ct * 64 + r, j = lt * 64 + lane;
+        tile[r][lane] = (cc < C && j < Lout) ? x[((int64_t)b * C + cc) * L + j + l_off] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {   // r = token inside the tile, lanes along channels
+        const int j = lt * 64 + r, cc = ct * 64 + lane;
+        if (j < Lout && cc < C) y[((int64_t)b * Lout + j) * C + cc] = tile[lane][r];
+    }
+}
+
+int launch_transpose_cl(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_TRANSPOSE_CL_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_TRANSPOSE_CL_T_Y]);
+    CHECK_PTRS("transpose_cl", x, y);
+    const int B = op.d[S2K_TRANSPOSE_CL_D_B], C = op.d[S2K_TRANSPOSE_CL_D_C], L = op.d[S2K_TRANSPOSE_CL_D_L];
+    const int l_off = op.d[S2K_TRANSPOSE_CL_D_L_OFF], Lout = op.d[S2K_TRANSPOSE_CL_D_LOUT];
+    if (!x || !y || B <= 0 || C <= 0 || L <= 0 || l_off < 0 || Lout <= 0 || l_off + Lout > L || B > 65535) { set_error("transpose_cl: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(transpose_cl_kernel, dim3(cdiv(C, 64), cdiv(Lout, 64), B), dim3(NTHREADS), 0, c.stream, x, y, B, C, L, l_off, Lout);
+    return S2K_OK;
+}
+
+}  // namespace s2k

@@ -373,11 +373,14 @@ static int launch_wg(WgradP& p, hipStream_t st) {
         if (pq == S2K_PRO_NONE && pp == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
         if (pq == S2K_PRO_NONE && pp == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_SILU, S2K_PRO_NONE>(p, st);
         if (pq == S2K_PRO_NONE && pp == S2K_PRO_NONE) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+        if (pq == S2K_PRO_NONE && pp == S2K_PRO_GELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_GELU, S2K_PRO_NONE>(p, st);
     } else {
         if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
         if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
         if constexpr (MODE == WG_PIX)
             if (pp == S2K_PRO_NONE && pq == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_SILU>(p, st);
+        if constexpr (MODE == WG_PIX)
+            if (pp == S2K_PRO_NONE && pq == S2K_PRO_GELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_GELU>(p, st);
     }
     set_error("wgrad: prologue combination (P %d, Q %d) is not instantiated for this mode", pp, pq);
     return S2K_EINVAL;
