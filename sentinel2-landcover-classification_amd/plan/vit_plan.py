@@ -107,15 +107,20 @@ def _block_params(L: ParamLayout, prefix: str, dim: int, hidden: int):
 
 
 def mae_layout(s: MaeSpec, prefix: str = "", L: ParamLayout | None = None) -> ParamLayout:
-    """The fixed sin-cos tables are requires_grad=False parameters in the reference: they live with the buffers
-    here (never touched by the optimiser), and are surfaced under their reference names by state_dict()."""
+    """The fixed sin-cos tables are requires_grad=False nn.Parameters in the reference (prithvi.py:155-157,173-175): they keep
+    their place in the flat parameter buffer (same state_dict order) and are listed in `L.frozen`, which the optimiser and
+    the gradient publication skip."""
     L = L or ParamLayout()
+    if not hasattr(L, "frozen"):
+        L.frozen = set()
     Lp, Dm, Dd = s.num_patches, s.embed_dim, s.decoder_embed_dim
     L.add_param(prefix + "cls_token", (1, 1, Dm))
-    L.add_buf(prefix + "pos_embed", (1, Lp + 1, Dm))
+    L.add_param(prefix + "pos_embed", (1, Lp + 1, Dm))
+    L.frozen.add(prefix + "pos_embed")
     if s.decoder:
         L.add_param(prefix + "mask_token", (1, 1, Dd))
-    L.add_buf(prefix + "decoder_pos_embed", (1, Lp + 1, Dd))
+    L.add_param(prefix + "decoder_pos_embed", (1, Lp + 1, Dd))
+    L.frozen.add(prefix + "decoder_pos_embed")
     L.add_param(prefix + "patch_embed.proj.weight", (Dm, s.in_chans, s.tubelet_size, s.patch_size, s.patch_size))
     L.add_param(prefix + "patch_embed.proj.bias", (Dm,))
     for i in range(s.depth):
@@ -270,7 +275,7 @@ def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int
               B=B, L=Lp, KEEP=keep)
     N = 1 + keep
     x0 = p.alloc("x0:" + prefix, (B, Dm, N))
-    p.fwd.add("TOKEN_GATHER", IN=pe, IDX=enc_idx, FILL=p.param(prefix + "cls_token"), POS=p.buf(prefix + "pos_embed"), OUT=x0,
+    p.fwd.add("TOKEN_GATHER", IN=pe, IDX=enc_idx, FILL=p.param(prefix + "cls_token"), POS=p.param(prefix + "pos_embed"), OUT=x0,
               B=B, C=Dm, LIN=Lp, LOUT=N, POS_BY_SRC=1, POS_OFF=1)
     recs = []
     x = x0
@@ -328,7 +333,7 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
     dx = v.linear_fwd("decoder_embed.weight", "decoder_embed.bias", latent, Dm, Dd, N)
     ND = Lp + 1
     y0 = p.alloc("y0", (B, Dd, ND))
-    p.fwd.add("TOKEN_GATHER", IN=dx, IDX=erec["dec_idx"], FILL=p.param("mask_token"), POS=p.buf("decoder_pos_embed"), OUT=y0,
+    p.fwd.add("TOKEN_GATHER", IN=dx, IDX=erec["dec_idx"], FILL=p.param("mask_token"), POS=p.param("decoder_pos_embed"), OUT=y0,
               B=B, C=Dd, LIN=N, LOUT=ND, POS_BY_SRC=0, POS_OFF=0)
     drecs = []
     y = y0

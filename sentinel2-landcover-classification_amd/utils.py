@@ -15,3 +15,48 @@ def initialize_classification_layer_bias(layer: nn.Linear | nn.Conv2d, class_dis
             layer.bias.fill_((dist[1] / dist[0]).log())
         else:
             layer.bias.copy_(dist.log())
+
+
+# ---- Prithvi loaders (reference utils.py:52-96) -------------------------------------------------------------
+def _prithvi_model_args(num_frames: int) -> dict:
+    from pathlib import Path
+
+    import yaml
+
+    with (Path(__file__).resolve().parent / "configs" / "prithvi_config.yaml").open("r") as f:
+        args = dict(yaml.safe_load(f)["model_args"])
+    args["num_frames"] = num_frames
+    return args
+
+
+def load_untrained_prithvi(num_frames: int, _flat: bool = True):
+    from .modules.prithvi import MaskedAutoencoderViT
+
+    return MaskedAutoencoderViT(**_prithvi_model_args(num_frames), _flat=_flat)
+
+
+def load_prithvi(num_frames: int, no_decoder: bool = True, weights: str | None = None, _flat: bool = True):
+    """Pre-trained Prithvi-100M: pos tables are dropped from the checkpoint and re-initialised, the decoder is removed
+    when `no_decoder` (reference utils.py:62-96).  `weights` defaults to $S2LC_PRITHVI_WEIGHTS or weights/Prithvi_100M.pt."""
+    import os
+    from pathlib import Path
+
+    from .modules.prithvi import MaskedAutoencoderViT
+
+    path = Path(weights or os.environ.get("S2LC_PRITHVI_WEIGHTS", "weights/Prithvi_100M.pt"))
+    if not path.exists():
+        raise FileNotFoundError(f"{path}: the Prithvi-100M checkpoint is not part of this repository "
+                                "(use load_untrained_prithvi for random initialisation)")
+    model = MaskedAutoencoderViT(**_prithvi_model_args(num_frames), _decoder=not no_decoder, _flat=False)
+    state = torch.load(path, map_location="cpu")
+    drop = ["pos_embed", "decoder_pos_embed"]
+    if no_decoder:
+        drop += ["decoder_embed", "mask_token", "decoder_blocks", "decoder_norm", "decoder_pred"]
+    state = {k: v for k, v in state.items() if not any(k.startswith(p) for p in drop)}
+    model.load_state_dict(state, strict=False)
+    model.reinitialize_pos_embed()
+    if _flat:
+        from .plan.vit_plan import mae_layout
+
+        model._init_flat(mae_layout(model.spec))
+    return model

@@ -1,0 +1,146 @@
+"""Runtime glue for the Prithvi modules (MaskedAutoencoderViT, PrithviSegmentationNet): device buffers of a planned
+network + one autograd node around its two stage programs.  Mirrors engine.py (the U-Net's); PyTorch supplies device
+memory, the HIP stream and the autograd edge only."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
+
+
+class VitEngine:
+    def __init__(self, module, B: int, training: bool, mask_ratio: float, device: torch.device):
+        plan = module._make_plan(B, training, mask_ratio)
+        self.plan = plan
+        self.fwd = plan.fwd.pack()
+        self.bwd = plan.bwd.pack() if plan.bwd is not None else None
+        pad = 256
+        self.ws = torch.empty(plan.ws_bytes + pad, dtype=torch.uint8, device=device)
+        self.aux = torch.zeros(max(plan.aux_bytes, 8) + pad, dtype=torch.uint8, device=device)
+        self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
+        self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)
+        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
+        self.bwd_marks = plan.bwd_param_marks
+
+    def bases(self, module, x, out, noise, dout=None, grads=None) -> _lib.Bases:
+        b = _lib.Bases()
+        b.set("WS", self.ws).set("AUX", self.aux).set("CONST", self.const).set("WPACK", self.wpack)
+        b.set("PARAMS", module._flat_params).set("BUFS", module._flat_bufs)
+        b.set("X", x).set("OUT", out).set("NOISE", noise)
+        if self.wgs is not None:
+            b.set("WGS", self.wgs)
+        if dout is not None:
+            b.set("DOUT", dout)
+        if grads is not None:
+            b.set("GRADS", grads)
+        return b
+
+    def views(self, out: torch.Tensor) -> dict:
+        res = {}
+        for name, t in self.plan.outputs.items():
+            res[name] = out[t.off:t.off + t.nbytes].view(_TORCH_DT[t.dtype]).view(t.shape)
+        return res
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _VitFunction(torch.autograd.Function):
+    """Whole-network autograd node; parameter gradients go straight into the module's flat gradient buffer.
+    Only the primary output (loss for the MAE, logits for the segmentation net) carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, module, eng, noise, primary):
+        out = torch.empty(eng.plan.out_bytes + 256, dtype=torch.uint8, device=x.device)
+        _lib.run(eng.fwd, eng.bases(module, x, out, noise), _stream(x.device))
+        v = eng.views(out)
+        names = [primary] + [n for n in v if n != primary]
+        ctx.module, ctx.eng, ctx.noise, ctx.names, ctx.out = module, eng, noise, names, out
+        ctx.save_for_backward(x)
+        outs = tuple(v[n] for n in names)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dprimary, *unused):
+        module, eng = ctx.module, ctx.eng
+        (x,) = ctx.saved_tensors
+        dout = dprimary.contiguous().reshape(eng.plan.dout_shape).to(torch.float32)
+        scale = getattr(module, "_grad_scale", 1.0)
+        if scale != 1.0:
+            dout = dout * scale
+        live = module._grads_live()
+        accumulate = live and not getattr(module, "_overwrite_next", False)
+        module._overwrite_next = False
+        grads = module._grad_buffer() if not accumulate else module._grad_scratch()
+        grads.zero_()
+        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads)
+        hook = getattr(module, "_bwd_segment_hook", None)
+        st = _stream(x.device)
+        if hook is None:
+            _lib.run(eng.bwd, bases, st)
+        else:
+            if accumulate:
+                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+            lo_min = eng.plan.trainable_lo
+            for (a, b, lo, hi) in eng.bwd_marks:
+                _lib.run(eng.bwd, bases, st, a, b)
+                hook(max(lo, lo_min), hi, grads)
+        if accumulate:
+            module._grad_buffer().add_(grads)
+        if not live:
+            module._publish_grads(module._no_grad_params)
+        return None, None, None, None, None, None
+
+
+def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = None) -> dict:
+    """Runs the module's forward program; returns {output name: tensor}.  `injected`: noise name -> tensor or None."""
+    if not x.is_cuda:
+        raise RuntimeError(f"{type(module).__name__} runs on the HIP engine only: move the module and the input to the GPU "
+                           "(there is no CPU fallback; the CPU restatement lives under oracle/ for tests)")
+    _lib.lib()
+    if x.dtype != torch.float32:
+        raise TypeError("the parity path computes in fp32; got " + str(x.dtype))
+    if module._flat_params.device != x.device:
+        raise RuntimeError("module and input are on different devices")
+    x = x.contiguous()
+    B = x.shape[0]
+    trainable = any(p.requires_grad for p in module.parameters())
+    is_seg = mask_ratio is None
+    # the segmentation head has BatchNorm / Dropout2d: its plan follows module.training; the MAE has neither, so a
+    # "training" plan (one that also carries the backward program) is only needed when a gradient is wanted
+    want_grad = torch.is_grad_enabled() and trainable and (module.training or not is_seg)
+    training = module.training if is_seg else want_grad
+    mr = 0.0 if is_seg else float(mask_ratio)
+    key = (tuple(x.shape), training, mr, x.device)
+    eng = module._engines.get(key)
+    if eng is None:
+        eng = VitEngine(module, B, training, mr, x.device)
+        module._engines[key] = eng
+    plan = eng.plan
+    noise = torch.empty(max(plan.noise_bytes // 4, 1), dtype=torch.float32, device=x.device)
+    for name, t in plan.noise.items():
+        n = int(np.prod(t.shape))
+        dst = noise[t.off // 4:t.off // 4 + n]
+        src = injected.get(name)
+        if src is None:
+            dst.uniform_(0.0, 1.0)     # torch.rand semantics: U[0, 1)
+        else:
+            if tuple(src.shape) != tuple(t.shape):
+                raise ValueError(f"{name} must have shape {tuple(t.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src.to(device=x.device, dtype=torch.float32).reshape(-1))
+    if is_seg and training:
+        module._flat_nbt += 1
+    primary = "logits" if is_seg else "loss"
+    if want_grad and (training or not is_seg):
+        anchor = module._anchor(x.device)
+        outs = _VitFunction.apply(x, anchor, module, eng, noise, primary)
+        names = [primary] + [n for n in plan.outputs if n != primary]
+        return dict(zip(names, outs))
+    out = torch.empty(plan.out_bytes + 256, dtype=torch.uint8, device=x.device)
+    _lib.run(eng.fwd, eng.bases(module, x, out, noise), _stream(x.device))
+    return eng.views(out)
