@@ -27,6 +27,9 @@ static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
 // ---------------- channel LayerNorm ---------------------------------------------------------------------
 // One workgroup = 64 consecutive positions (lanes) of one sample x all C channels; the four waves split the
 // channels, combine their per-position sums through LDS, then each normalises its own channels.
+constexpr int LN_U = 8;
+constexpr int LN_NW = 16;   // waves per workgroup: the channel loop of a tile is split 16 ways (latency-bound at ViT sizes)
+
 struct LnP {
     const float *x, *gamma, *beta, *dy, *mr_in;
     float *y, *mr, *dx, *dgamma, *dbeta;
@@ -34,8 +37,8 @@ struct LnP {
     float eps;
 };
 
-__global__ void __launch_bounds__(NTHREADS) chan_ln_fwd_kernel(const LnP p) {
-    __shared__ double red[4][64][2];
+__global__ void __launch_bounds__(64 * LN_NW) chan_ln_fwd_kernel(const LnP p) {
+    __shared__ double red[LN_NW][64][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -44,16 +47,20 @@ __global__ void __launch_bounds__(NTHREADS) chan_ln_fwd_kernel(const LnP p) {
         const bool ok = hw < p.HW;
         const float* xb = p.x + (int64_t)b * p.C * p.HW + (ok ? hw : 0);
         double s = 0.0, q = 0.0;
-        for (int c = wave; c < p.C; c += 4) {
-            const float v = ok ? xb[(int64_t)c * p.HW] : 0.0f;
-            s += v;
-            q += (double)v * v;
+        for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {     // LN_U independent loads in flight per lane
+            float v[LN_U];
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? xb[(int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) { s += v[u]; q += (double)v[u] * v[u]; }
         }
         red[wave][lane][0] = s;
         red[wave][lane][1] = q;
         __syncthreads();
-        s = red[0][lane][0] + red[1][lane][0] + red[2][lane][0] + red[3][lane][0];
-        q = red[0][lane][1] + red[1][lane][1] + red[2][lane][1] + red[3][lane][1];
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int w = 0; w < LN_NW; ++w) { s += red[w][lane][0]; q += red[w][lane][1]; }
         const double mean = s / p.C;
         double var = q / p.C - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -65,8 +72,15 @@ __global__ void __launch_bounds__(NTHREADS) chan_ln_fwd_kernel(const LnP p) {
             mr[1] = rstd;
         }
         float* yb = p.y + (int64_t)b * p.C * p.HW + (ok ? hw : 0);
-        for (int c = wave; c < p.C; c += 4) {
-            if (ok) yb[(int64_t)c * p.HW] = fmaf((xb[(int64_t)c * p.HW] - mf) * rstd, p.gamma[c], p.beta[c]);
+        for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {
+            float v[LN_U];
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? xb[(int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                const int c = c0 + LN_NW * u;
+                if (ok && c < p.C) yb[(int64_t)c * p.HW] = fmaf((v[u] - mf) * rstd, p.gamma[c], p.beta[c]);
+            }
         }
         __syncthreads();
     }
@@ -85,20 +99,20 @@ int launch_chan_ln_fwd(const S2kOp& op, const Ctx& c) {
     if (!p.x || !p.gamma || !p.beta || !p.y || !p.mr || p.B <= 0 || p.C <= 0 || p.HW <= 0) { set_error("chan_ln_fwd: bad args"); return S2K_EINVAL; }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
-    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(NTHREADS), 0, c.stream, p);
+    hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(64 * LN_NW), 0, c.stream, p);
     return S2K_OK;
 }
 
 // backward: dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = dy * gamma; the per-channel parameter
 // sums of a workgroup's tiles are collected in LDS (each wave owns its channels) and flushed once at the end
-__global__ void __launch_bounds__(NTHREADS) chan_ln_bwd_kernel(const LnP p) {
+__global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     float* pg = lsm;              // [C] dgamma partial
     float* pb = lsm + p.C;        // [C] dbeta partial
-    float(*red)[64][2] = reinterpret_cast<float(*)[64][2]>(lsm + 2 * p.C);   // [4][64][2]
+    float(*red)[64][2] = reinterpret_cast<float(*)[64][2]>(lsm + 2 * p.C);   // [LN_NW][64][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool want_p = p.dgamma != nullptr;
-    for (int c = threadIdx.x; c < 2 * p.C; c += NTHREADS) lsm[c] = 0.0f;
+    for (int c = threadIdx.x; c < 2 * p.C; c += 64 * LN_NW) lsm[c] = 0.0f;
     __syncthreads();
     const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
     const float invC = 1.0f / p.C;
@@ -114,39 +128,58 @@ __global__ void __launch_bounds__(NTHREADS) chan_ln_bwd_kernel(const LnP p) {
             rstd = mr[1];
         }
         float s1 = 0.0f, s2 = 0.0f;
-        for (int c = wave; c < p.C; c += 4) {
-            const float dyv = ok ? p.dy[base + (int64_t)c * p.HW] : 0.0f;
-            const float xh = ok ? (p.x[base + (int64_t)c * p.HW] - mean) * rstd : 0.0f;
-            const float g = dyv * p.gamma[c];
-            s1 += g;
-            s2 = fmaf(g, xh, s2);
+        for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {
+            float dv[LN_U], xv[LN_U];
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                const bool on = ok && c0 + LN_NW * u < p.C;
+                dv[u] = on ? p.dy[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+                xv[u] = on ? p.x[base + (int64_t)(c0 + LN_NW * u) * p.HW] : mean;
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                const int c = c0 + LN_NW * u;
+                const float g = dv[u] * (c < p.C ? p.gamma[c] : 0.0f);
+                s1 += g;
+                s2 = fmaf(g, (xv[u] - mean) * rstd, s2);
+            }
         }
         red[wave][lane][0] = s1;
         red[wave][lane][1] = s2;
         __syncthreads();
-        s1 = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
-        s2 = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
+        s1 = 0.0f;
+        s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LN_NW; ++w) { s1 += red[w][lane][0]; s2 += red[w][lane][1]; }
         const float m1 = s1 * invC, m2 = s2 * invC;
-        for (int c = wave; c < p.C; c += 4) {
-            const float dyv = ok ? p.dy[base + (int64_t)c * p.HW] : 0.0f;
-            const float xh = ok ? (p.x[base + (int64_t)c * p.HW] - mean) * rstd : 0.0f;
-            const float g = dyv * p.gamma[c];
-            float d = rstd * (g - m1 - xh * m2);
-            if (ok) {
-                float* dst = p.dx + base + (int64_t)c * p.HW;
-                if (p.accum) d += *dst;
-                *dst = d;
+        for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {
+            float dv[LN_U], xv[LN_U], ov[LN_U];
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                const bool on = ok && c0 + LN_NW * u < p.C;
+                dv[u] = on ? p.dy[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+                xv[u] = on ? p.x[base + (int64_t)(c0 + LN_NW * u) * p.HW] : mean;
+                ov[u] = (on && p.accum) ? p.dx[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
             }
-            if (want_p) {
-                const float a = wave_sum_hi(dyv * xh), bb = wave_sum_hi(dyv);
-                if (lane == 63) { pg[c] += a; pb[c] += bb; }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
+                const int c = c0 + LN_NW * u;
+                if (c < p.C) {      // wave-uniform
+                    const float xh = (xv[u] - mean) * rstd;
+                    const float g = dv[u] * p.gamma[c];
+                    if (ok) p.dx[base + (int64_t)c * p.HW] = rstd * (g - m1 - xh * m2) + ov[u];
+                    if (want_p) {
+                        const float a = wave_sum_hi(dv[u] * xh), bb = wave_sum_hi(dv[u]);
+                        if (lane == 63) { pg[c] += a; pb[c] += bb; }
+                    }
+                }
             }
         }
         __syncthreads();
     }
     if (want_p) {
         __syncthreads();
-        for (int c = threadIdx.x; c < p.C; c += NTHREADS) {
+        for (int c = threadIdx.x; c < p.C; c += 64 * LN_NW) {
             atomicAdd(p.dgamma + c, pg[c]);
             atomicAdd(p.dbeta + c, pb[c]);
         }
@@ -170,9 +203,9 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
-    const size_t lds = (2 * (size_t)p.C + 4 * 64 * 2) * sizeof(float);
+    const size_t lds = (2 * (size_t)p.C + LN_NW * 64 * 2) * sizeof(float);
     if (lds > 64 * 1024) { set_error("chan_ln_bwd: C too large"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(NTHREADS), lds, c.stream, p);
+    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(64 * LN_NW), lds, c.stream, p);
     return S2K_OK;
 }
 
