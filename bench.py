@@ -47,6 +47,37 @@ def conv_flops(packed, D) -> dict:
     return out
 
 
+def conv_bytes(packed, D) -> dict:
+    """Algorithmic HBM bytes per launch family: every conv-like stage reads its input(s) + weights once and writes its
+    output once (SURVEY §8d convention), from the stage records."""
+    names = {v: k for k, v in D.KIND.items()}
+    out = {}
+    for rec in packed:
+        kind = names[int(rec["kind"])]
+        d = rec["d"]
+        if kind == "CONV":
+            B, C1, C2, H, W, M, KH, KW, HO, WO, mode = (int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "H", "W", "M", "KH", "KW", "HO", "WO", "MODE"))
+            by = 4.0 * (B * (C1 + C2) * H * W + B * M * HO * WO + M * (C1 + C2) * KH * KW)
+        elif kind == "WGRAD":
+            B, M, C, H, W, KH, KW, HO, WO = (int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "H", "W", "KH", "KW", "HO", "WO"))
+            by = 4.0 * (B * M * HO * WO + B * C * H * W + M * C * KH * KW)
+        else:
+            continue
+        out[kind] = out.get(kind, 0.0) + by
+    return out
+
+
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC run (profiles/*_hbm_traffic.json, newest), or None."""
+    files = sorted((ROOT / "profiles").glob("*_hbm_traffic.json"))
+    if not files:
+        return None
+    try:
+        return json.loads(files[-1].read_text())["kernels"][kernel]["hbm_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(version, C, H, ncls, budget_s=20.0):
     """The CPU oracle (a port of the reference's torch CPU path, validated against the reference via
     tests/golden) timed on this host: forward + backward of the same step at a small batch."""
@@ -193,8 +224,13 @@ def main() -> None:
             dom, dms, dfl = ("conv_igemm_kernel", conv_ms, conv_fl) if conv_ms >= wg_ms else ("wgrad_kernel", wg_ms, wg_fl)
             n_l = kernels["CONV" if dom == "conv_igemm_kernel" else "WGRAD"]["launches"]
             ach = dfl / (dms * 1e-3) / 1e12
+            by_f, by_b = conv_bytes(eng.fwd, D), conv_bytes(eng.bwd, D)
+            dkind = "CONV" if dom == "conv_igemm_kernel" else "WGRAD"
+            alg_bytes = (by_f.get(dkind, 0.0) + by_b.get(dkind, 0.0)) / n_l
             roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        # HBM bytes per launch from the PMC counters (committed run, see profiles/); algorithmic bytes beside it
+                        "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": round(alg_bytes),
                         "launches": n_l, "avg_launch_ms": round(dms / n_l, 4),
                         "flops_per_step": dfl, "all_mfma_tflops": round((conv_fl + wg_fl) / ((conv_ms + wg_ms) * 1e-3) / 1e12, 2)}
         if world == 1 and not args.no_cpu_baseline:
