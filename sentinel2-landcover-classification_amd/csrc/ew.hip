@@ -142,26 +142,34 @@ int launch_weight_pack(const S2kOp& op, const Ctx& c) {
 }
 
 // ---------------- BN_FINALIZE ----------------------------------------------------------------------
+// One wave per channel: the (up to 64) statistics replicas are read by the lanes in parallel and summed with a wave
+// reduction (a thread-per-channel loop over the replicas was 64 dependent L2 round trips: 12 us per launch, 252 launches a step)
 __global__ void bn_finalize_kernel(const double* stats, const float* gamma, const float* beta, float* rm, float* rv,
                                    float* bnv, int C, int train, double count, float eps, float mom, int nrep) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     float mean, invstd;
     if (train) {
         double s = 0.0, q = 0.0;
-        for (int r = 0; r < nrep; ++r) { s += stats[(int64_t)r * 2 * C + c]; q += stats[(int64_t)r * 2 * C + C + c]; }
+        for (int r = lane; r < nrep; r += 64) { s += stats[(int64_t)r * 2 * C + c]; q += stats[(int64_t)r * 2 * C + C + c]; }
+        s = wave_sum_d(s);
+        q = wave_sum_d(q);
         const double m = s / count;
         double var = q / count - m * m;
         if (var < 0.0) var = 0.0;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
         mean = (float)m;
         const double unbiased = var * (count / fmax(count - 1.0, 1.0));
-        rm[c] = (1.0f - mom) * rm[c] + mom * mean;
-        rv[c] = (1.0f - mom) * rv[c] + mom * (float)unbiased;
+        if (lane == 0) {
+            rm[c] = (1.0f - mom) * rm[c] + mom * mean;
+            rv[c] = (1.0f - mom) * rv[c] + mom * (float)unbiased;
+        }
     } else {
         mean = rm[c];
         invstd = 1.0f / sqrtf(rv[c] + eps);
     }
+    if (lane != 0) return;
     const float scale = gamma[c] * invstd;
     bnv[c] = scale;
     bnv[C + c] = beta[c] - mean * scale;
@@ -179,7 +187,7 @@ int launch_bn_finalize(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("bn_finalize", stats, gamma, beta, rm, rv, bnv);
     const int C = op.d[S2K_BN_FINALIZE_D_C], train = op.d[S2K_BN_FINALIZE_D_TRAIN];
     if (!gamma || !beta || !rm || !rv || !bnv || C <= 0 || (train && !stats)) { set_error("bn_finalize: bad args"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, stats, gamma, beta, rm, rv, bnv, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, c.stream, stats, gamma, beta, rm, rv, bnv, C,
                        train, (double)op.n[S2K_BN_FINALIZE_N_COUNT], op.f[S2K_BN_FINALIZE_F_EPS], op.f[S2K_BN_FINALIZE_F_MOM],
                        op.d[S2K_BN_FINALIZE_D_NREP] > 0 ? op.d[S2K_BN_FINALIZE_D_NREP] : 1);
     return S2K_OK;
@@ -539,10 +547,14 @@ int launch_bn_bwd_reduce(const S2kOp& op, const Ctx& c) {
 
 __global__ void bn_bwd_finalize_kernel(const double* st2, const float* gamma, const float* bnv, float* dgamma, float* dbeta,
                                        float* coef, int C, double count, int nrep) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrep; ++r) { s1 += st2[(int64_t)r * 2 * C + c]; s2 += st2[(int64_t)r * 2 * C + C + c]; }
+    for (int r = lane; r < nrep; r += 64) { s1 += st2[(int64_t)r * 2 * C + c]; s2 += st2[(int64_t)r * 2 * C + C + c]; }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     dgamma[c] += (float)s2;
     dbeta[c] += (float)s1;
     const double a = (double)gamma[c] * (double)bnv[3 * C + c];
@@ -561,7 +573,7 @@ int launch_bn_bwd_finalize(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("bn_bwd_finalize", st2, gamma, bnv, dgamma, dbeta, coef);
     const int C = op.d[S2K_BN_BWD_FINALIZE_D_C];
     if (!st2 || !gamma || !bnv || !dgamma || !dbeta || !coef || C <= 0) { set_error("bn_bwd_finalize: bad args"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, c.stream, st2, gamma, bnv, dgamma, dbeta, coef, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, c.stream, st2, gamma, bnv, dgamma, dbeta, coef, C,
                        (double)op.n[S2K_BN_BWD_FINALIZE_N_COUNT], op.d[S2K_BN_BWD_FINALIZE_D_NREP] > 0 ? op.d[S2K_BN_BWD_FINALIZE_D_NREP] : 1);
     return S2K_OK;
 }

@@ -28,6 +28,9 @@ enum { BM_PIX = 0, BM_SPATIAL = 1 };
 struct ConvP {
     const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
     float* y;
+    float* scratch;      // split-K partial tiles [splits][Y layout] (deep, short-N layers), or null
+    int splits, chunks_per_split;
+    int64_t y_elems;
     double* stats;
     int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
     int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC, nrep;
@@ -67,6 +70,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     const int wm0 = (wave / WVN) * (WM * 32);
     const int wn0 = (wave % WVN) * (WN * 32);
     const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int ksplit = blockIdx.y;   // split-K: this workgroup reduces chunks [ch_begin, ch_end) only
     const int mt = tile % p.n_mtiles;
     const int nt = tile / p.n_mtiles;
     const int m0 = mt * BM;
@@ -300,13 +304,15 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         }
     };
 
+    const int ch_begin = ksplit * p.chunks_per_split;
+    const int ch_end = min(nchunks, ch_begin + p.chunks_per_split);
     __syncthreads();  // ssc / ssh staged
-    fetch(0);
-    commit(0);
+    fetch(ch_begin * KCH);
+    commit(ch_begin * KCH);
     __syncthreads();
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const bool more = ch + 1 < ch_end;
         if (more) fetch((ch + 1) * KCH);
         // ---------------- MFMA over the chunk in LDS --------------------------------------------
         // Explicit two-set operand pipeline: the LDS reads of stage i+1 are issued before the MFMAs of stage i
@@ -369,6 +375,19 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     }
 
     // ---------------- epilogue ---------------------------------------------------------------------
+    if (p.splits > 1) {   // partial tile -> scratch; bias / residual / statistics are applied by splitk_reduce_kernel
+        float* part = p.scratch + (int64_t)ksplit * p.y_elems;
+#pragma unroll
+        for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn)
+                    if (gm < p.M && cval[rn]) part[ycol[rn] + (int64_t)gm * HWo] = acc[rm][rn][reg];
+            }
+        return;
+    }
     if (scatter) {
         // rows m = (co,dy,dx): registers 4q..4q+3 of a lane are the 2x2 output patch of one co
         const int64_t plane = 4 * (int64_t)p.HW;
@@ -467,8 +486,39 @@ static int pick_bm(int M) {
     return best;
 }
 
+// Split-K tail: Y[b][m][hw] (+)= sum_s part[s][b][m][hw] + bias[m] + res, partials added in a FIXED order (reproducible),
+// BatchNorm statistics of the finished rows.  One wave per (b, m) plane.
+__global__ void __launch_bounds__(NTHREADS) splitk_reduce_kernel(const ConvP p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HWo = p.HO * p.WO;
+    if (plane >= (int64_t)p.B * p.M) return;
+    const int b = (int)(plane / p.M), m = (int)(plane % p.M);
+    const int64_t base = ((int64_t)b * p.YC + m) * HWo;
+    const float bs = p.bias ? p.bias[m] : 0.0f;
+    float s = 0.0f, q = 0.0f;
+    for (int i = lane; i < HWo; i += 64) {
+        float v = bs;
+        for (int k = 0; k < p.splits; ++k) v += p.scratch[(int64_t)k * p.y_elems + base + i];
+        if (p.res) v += p.res[base + i];
+        if (p.beta) v += p.y[base + i];
+        p.y[base + i] = v;
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    if (p.stats) {
+        s = wave_sum_hi(s);
+        q = wave_sum_hi(q);
+        if (lane == 63) {
+            double* st = p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.M;
+            atomic_add_d(st + m, (double)s);
+            atomic_add_d(st + p.M + m, (double)q);
+        }
+    }
+}
+
 template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW = 2>
-static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st) {
+static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk = false) {
     constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;
     constexpr int A_FLOATS = (KCH * TT * BM + 3) & ~3;
     p.n_mtiles = cdiv(p.M, BM);
@@ -487,7 +537,23 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st) {
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
     p.n_tiles = (int)blocks;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NTHREADS), lds, st, p);
+    const int nchunks = cdiv(p.Ctot, KCH);
+    p.splits = 1;
+    p.chunks_per_split = nchunks;
+    p.y_elems = (int64_t)p.B * p.YC * p.HO * p.WO;
+    if (allow_splitk && p.scratch && p.mode == S2K_MODE_CONV && blocks <= 512 && nchunks >= 4) {
+        // too few tiles to fill 256 CUs and a long reduction: cut K so that ~4 workgroups per CU hide each other's latency
+        int splits = (int)cdiv64(1024, blocks);
+        if (splits > 8) splits = 8;
+        if (splits > nchunks / 2) splits = nchunks / 2;
+        if (splits > 1) {
+            p.chunks_per_split = cdiv(nchunks, splits);
+            p.splits = cdiv(nchunks, p.chunks_per_split);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splits), dim3(NTHREADS), lds, st, p);
+    if (p.splits > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64((int64_t)p.B * p.M, 4)), dim3(NTHREADS), 0, st, p);
     return S2K_OK;
 }
 
@@ -523,7 +589,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.y = ref_ptr<float>(c, op.t[S2K_CONV_T_Y]);
     p.stats = ref_ptr<double>(c, op.t[S2K_CONV_T_STATS]);
     p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
-    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res};
+    p.scratch = ref_ptr<float>(c, op.t[S2K_CONV_T_SCRATCH]);
+    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch};
     for (const void* q : ptrs)
         if (q == reinterpret_cast<const void*>(1)) { set_error("conv: tensor references a null base"); return S2K_EFAULT; }
     const int32_t* d = op.d;
@@ -575,7 +642,7 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
-        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st);
+        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st, true);
         if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 64, 1>(p, cdiv(p.Ntot, 128), st);
         if (bm == 64) return launch_cfg<BM_PIX, 1, 2, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
         return launch_cfg<BM_PIX, 1, 1, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);

@@ -56,7 +56,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # STATS (double [2][M]) accumulates sum(Y), sum(Y^2) per row for train-mode BatchNorm.
     # RES (same layout as Y): added to the result (the transformer's residual stream: x' = x + proj(...)).
     # A Linear over feature-major tokens [B][C][L] is this stage with H = 1, W = L.
-    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES"], [],
+    # SCRATCH (optional, >= 8 * B*YC*HO*WO floats): lets the kernel cut a long reduction over few output tiles into
+    # split-K partials that a tail kernel adds in a fixed order (deep 8x8 / 16x16 layers: 160 tiles cannot fill 256 CUs).
+    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
               "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
     # Weight gradient on f32 MFMA, K = pixels:

@@ -621,6 +621,20 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
                                                 DST=TRef(D.BASE["WPACK"], 0, (p.wpack.mark() // 4,)), TOTAL=total,
                                                 N_ENTRIES=len(rows))))
 
+    def attach_splitk_scratch():
+        """One shared scratch region (stages run in stream order) for the 1x1 convs with few output pixels and a long
+        reduction: the kernel may then cut K into partial tiles (csrc/igemm.hip, splitk_reduce_kernel)."""
+        want = []
+        for prog in (p.fwd, p.bwd):
+            for kind, f in prog.ops:
+                if kind == "CONV" and f["KH"] == 1 and f["KW"] == 1 and f["MODE"] == D.MODE_CONV \
+                        and f["B"] * f["HO"] * f["WO"] <= 8192 and f["C1"] + f["C2"] >= 256:
+                    want.append((f, 8 * f["B"] * f["YC"] * f["HO"] * f["WO"]))
+        if want:
+            scratch = p.ws.alloc("splitk_scratch", (max(n for _, n in want),))
+            for f, _ in want:
+                f["SCRATCH"] = scratch
+
     fwd_aux_end = p.aux.mark()
     if training and fwd_aux_end:
         p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
@@ -644,6 +658,7 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
             segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]
         bwd = p.bwd
     pack_op(p.fwd, p.pack_rows["fwd"])
+    attach_splitk_scratch()
     return segments, bwd
 
 
