@@ -19,6 +19,8 @@
 // latency hides under 64..288 MFMAs per wave; all index arithmetic of the stagers is incremental
 // or compile-time (no runtime divisions in the K loop).  Workgroup ids are remapped so that the
 // m-tiles sharing one activation tile run on the same XCD (shared L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace s2k {
@@ -642,7 +644,10 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
-        if (bm >= 64 && tiles_big < 160) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st, true);
+        static const int small_max = [] { const char* e = getenv("S2K_PIX_SMALL_TILES"); return e ? atoi(e) : 400; }();
+        if (bm >= 64 && tiles_big < small_max) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st, true);
+        static const int k16_max = [] { const char* e = getenv("S2K_PIX_K16_MAX"); return e ? atoi(e) : 192; }();
+        if (bm == 128 && p.Ctot <= k16_max) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 16, 1>(p, cdiv(p.Ntot, 128), st);   // short-K expand convs
         if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 64, 1>(p, cdiv(p.Ntot, 128), st);
         if (bm == 64) return launch_cfg<BM_PIX, 1, 2, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
         return launch_cfg<BM_PIX, 1, 1, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
@@ -666,6 +671,9 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         return launch_cfg<BM_SPATIAL, 9, 1, 1, 2, 2, 8, 2>(p, (int)tiles, st);
     }
     // thin layers (M <= 32, full-resolution maps): 32 x 1024 tiles amortise the halo (6 rows per 4)
+    static const int thin_mode = [] { const char* e = getenv("S2K_THIN"); return e ? atoi(e) : 1; }();
+    if (thin_mode == 1 && p.S == 1 && cdiv64(out_px, 512) >= 200 && geom(512, 5 * NTHREADS))
+        return launch_cfg<BM_SPATIAL, 9, 1, 4, 1, 4, 8, 5>(p, (int)tiles, st);
     if (p.S == 1 && cdiv64(out_px, 1024) >= 200 && geom(1024, 7 * NTHREADS))
         return launch_cfg<BM_SPATIAL, 9, 1, 8, 1, 4, 8, 7, 1>(p, (int)tiles, st);
     if (!geom(256, 4 * NTHREADS)) { set_error("conv: halo tile does not fit"); return S2K_EINVAL; }
