@@ -80,6 +80,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
 __device__ __forceinline__ float bload(rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
+__device__ __forceinline__ f32x4 bload4(rsrc_t r, uint32_t byte_off) {   // 16-byte aligned offsets only
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
 __device__ __forceinline__ float2 bload2(rsrc_t r, uint32_t byte_off) {
     auto v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
     return make_float2(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]));

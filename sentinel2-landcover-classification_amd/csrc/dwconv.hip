@@ -26,11 +26,11 @@ struct DwP {
     int B, C, H, W, K, S, PT, PL, HO, WO, pro, beta, nrep;
     int PPB, RT, bands, IRt, LW;     // tiling: planes per workgroup, rows per band, LDS rows / row stride
     int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
+    int vps_shift;                   // log2(pow2ceil(LW / 4)) capped at 6 (vector stager)
 };
 
-// Stage rows [row0, row0 + nrows) x LW columns of PPB planes of `src` (plane size Hs x Ws) into
+// Scalar stager (any width / column origin): rows [row0, row0 + nrows) x LW columns of PPB planes of `src` into
 // tile[pl][rr][LW]; element (rr, cc) is src row (row0 + rr), column (col0 + cc), zero outside the image.
-// PRO: prologue applied to in-image values (BatchNorm scale/shift of channel plane % C + activation).
 template <int PRO>
 __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int Hs, int Ws, float* tile, int64_t pl0,
                                            int64_t nplanes, int nrows, int row0, int col0) {
@@ -64,10 +64,76 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
     }
 }
 
+// Vector stager of the register-blocked kernels: LW % 4 == 0 and tile column cc holds source column cc - 4, so that
+// source column 0 sits on a 16-byte boundary: a lane moves one aligned float4 HBM -> LDS (ds_write_b128); the 4-column
+// halo on the left and the columns past the row end are zeros (or real data where the source row is wider).
+template <int PRO>
+__device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, int Hs, int Ws, float* tile, int64_t pl0,
+                                              int64_t nplanes, int nrows, int row0) {
+    const rsrc_t rs = make_rsrc(src, nplanes * Hs * Ws * 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int VPR = p.LW >> 2;                          // float4 slots per tile row
+    const int vshift = p.vps_shift;                     // log2(pow2 >= VPR), capped at 6
+    const int vps = 1 << vshift, rpw = 64 >> vshift;
+    const int sub = lane >> vshift, v0 = lane & (vps - 1);
+    const int total_rows = p.PPB * nrows;
+    const bool vec = (Ws & 3) == 0;
+    for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
+        const int row = rbase + sub;
+        const int pl = row / nrows, rr = row - pl * nrows;
+        const int64_t plane = pl0 + pl;
+        const bool rok = row < total_rows && plane < nplanes;
+        const int iy = row0 + rr;
+        const bool yok = rok && iy >= 0 && iy < Hs;
+        float sc = 1.0f, sh = 0.0f;
+        if (PRO != S2K_PRO_NONE) {
+            const int c = (int)((rok ? plane : 0) % p.C);
+            sc = p.bnv[c];
+            sh = p.bnv[p.C + c];
+        }
+        const uint32_t rowoff = (uint32_t)((plane * Hs + iy) * Ws) * 4u;
+        for (int vi = v0; vi < VPR; vi += vps) {
+            const int ix = 4 * vi - 4;
+            f32x4 v;
+            if (vec) {
+                const bool ok = yok && ix >= 0 && ix < Ws;
+                v = bload4(rs, ok ? rowoff + (uint32_t)ix * 4u : BUF_OOB);
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = ok ? apply_pro_c<PRO>(v[j], sc, sh) : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = yok && ix + j >= 0 && ix + j < Ws;
+                    float e = bload(rs, ok ? rowoff + (uint32_t)(ix + j) * 4u : BUF_OOB);
+                    if (PRO != S2K_PRO_NONE) e = ok ? apply_pro_c<PRO>(e, sc, sh) : 0.0f;
+                    v[j] = e;
+                }
+            }
+            if (row < total_rows) *reinterpret_cast<f32x4*>(tile + (pl * nrows + rr) * p.LW + 4 * vi) = v;
+        }
+    }
+}
+
+// one row window of an item: NV aligned float4 LDS reads (ds_read_b128) -> v[4 * NV]
+template <int NV>
+__device__ __forceinline__ void read_window(const float* t, float* v) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(t + 4 * i);
+        v[4 * i + 0] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+}
+
 // ---- forward -------------------------------------------------------------------------------------
-template <int K, int S, int PRO>
+// PL = left padding (compile time: the column window of an item then starts at the constant offset 4 - PL of an aligned
+// float4 group, so every LDS operand index below is a constant)
+template <int K, int S, int PL, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
-    constexpr int NX = 3 * S + K;   // LDS values of one row needed for 4 outputs
+    constexpr int NX = 3 * S + K;         // values of one row needed for 4 outputs
+    constexpr int O0 = 4 - PL;            // first of them inside the aligned window
+    constexpr int NV = (O0 + NX + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                               // [PPB][IRt][LW]
     float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K]
@@ -77,7 +143,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    stage_band<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT, -p.PL);
+    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT);
     for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
         const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
@@ -109,13 +175,12 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < K; ++ky) {
-                    float v[NX];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) v[i] = t0[ky * p.LW + i];
+                    float v[4 * NV];
+                    read_window<NV>(t0 + ky * p.LW, v);
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], v[j * S + kx], o[j]);
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], v[O0 + j * S + kx], o[j]);
                 }
                 const int xo = xg * 4;
                 float* dst = p.out + plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo;
@@ -143,9 +208,11 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------
-template <int K, int S, int PRO>
+template <int K, int S, int PL, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
     constexpr int NX = 3 * S + K;
+    constexpr int O0 = 4 - PL;
+    constexpr int NV = (O0 + NX + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;  // [PPB][IRt][LW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,12 +221,13 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    stage_band<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT, -p.PL);
+    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT);
     __syncthreads();
     const rsrc_t rdy = make_rsrc(p.dy, nplanes * p.HO * p.WO * 4);
     const int items = rows * p.XG;
     const int lpp = p.LPP, ppw = 64 / lpp;
     const int li = lane & (lpp - 1), lp = lane / lpp;
+    const bool vec4 = (p.WO & 3) == 0;
     // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
     const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
     const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
@@ -178,18 +246,22 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
                 const int xo = xg * 4;
                 const uint32_t goff = (uint32_t)(plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo) * 4u;
                 float g[4];
+                if (vec4) {
+                    const f32x4 gv = bload4(rdy, goff);
+                    g[0] = gv[0]; g[1] = gv[1]; g[2] = gv[2]; g[3] = gv[3];
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = bload(rdy, xo + j < p.WO ? goff + 4u * j : BUF_OOB);
+                    for (int j = 0; j < 4; ++j) g[j] = bload(rdy, xo + j < p.WO ? goff + 4u * j : BUF_OOB);
+                }
                 const float* t0 = tp + (r * S) * p.LW + xo * S;
 #pragma unroll
                 for (int ky = 0; ky < K; ++ky) {
-                    float v[NX];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) v[i] = t0[ky * p.LW + i];
+                    float v[4 * NV];
+                    read_window<NV>(t0 + ky * p.LW, v);
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(g[j], v[j * S + kx], acc[ky * K + kx]);
+                        for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(g[j], v[O0 + j * S + kx], acc[ky * K + kx]);
                 }
             }
         }
@@ -224,11 +296,14 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
 }
 
 // ---- data gradient, stride 1 (the common case): a correlation with the flipped kernel ------------------
-// G[iy][ix] = sum_{ky,kx} w[ky][kx] * dY[iy + PT - ky][ix + PL - kx]; LDS band holds dY rows
-// [iy0 + PT - (K-1), ...) and columns [PL - (K-1), ...): tile(r + a, x + b) with a = K-1-ky, b = K-1-kx.
-template <int K, int PRO>
+// G[iy][ix] = sum_{ky,kx} w[ky][kx] * dY[iy + PT - ky][ix + PL - kx]; the LDS band holds dY rows
+// [iy0 + PT - (K-1), ...); with a = K-1-ky, b = K-1-kx the window of 4 outputs starts at column 4*xg + (PL - (K-1)),
+// i.e. at offset 4 - (K-1-PL) of the aligned group (PR = K-1-PL = the right padding of the forward).
+template <int K, int PR, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) {
     constexpr int NX = 3 + K;
+    constexpr int O0 = 4 - PR;
+    constexpr int NV = (O0 + NX + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                               // [PPB][IRt][LW]
     float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K] flipped
@@ -238,7 +313,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
     const int band = blockIdx.x % p.bands;
     const int iy0 = band * p.RT;
     const int rows = min(p.RT, p.H - iy0);
-    stage_band<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, iy0 + p.PT - (K - 1), p.PL - (K - 1));
+    stage_band_v4<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, iy0 + p.PT - (K - 1));
     for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
         const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
@@ -272,31 +347,38 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
                 const int r = it / p.XG, xg = it - r * p.XG;
                 const int ix = xg * 4;
                 const float* t0 = tp + r * p.LW + ix;
+                const int64_t off = plane * p.H * p.W + (int64_t)(iy0 + r) * p.W + ix;
+                const uint32_t boff = (uint32_t)off * 4u;
+                float xr[4] = {0.f, 0.f, 0.f, 0.f}, ob[4] = {0.f, 0.f, 0.f, 0.f};
+                if (vec4) {       // issue the global loads before the LDS work
+                    if (PRO != S2K_PRO_NONE) { const f32x4 t = bload4(rxr, boff); xr[0] = t[0]; xr[1] = t[1]; xr[2] = t[2]; xr[3] = t[3]; }
+                    if (p.beta) { const f32x4 t = bload4(rout, boff); ob[0] = t[0]; ob[1] = t[1]; ob[2] = t[2]; ob[3] = t[3]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (PRO != S2K_PRO_NONE) xr[j] = bload(rxr, ix + j < p.W ? boff + 4u * j : BUF_OOB);
+                        if (p.beta) ob[j] = bload(rout, ix + j < p.W ? boff + 4u * j : BUF_OOB);
+                    }
+                }
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < K; ++a) {
-                    float v[NX];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) v[i] = t0[a * p.LW + i];
+                    float v[4 * NV];
+                    read_window<NV>(t0 + a * p.LW, v);
 #pragma unroll
                     for (int b = 0; b < K; ++b)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], v[j + b], o[j]);
+                        for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], v[O0 + j + b], o[j]);
                 }
-                const int64_t off = plane * p.H * p.W + (int64_t)(iy0 + r) * p.W + ix;
-                const uint32_t boff = (uint32_t)off * 4u;
                 if (PRO != S2K_PRO_NONE) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float xr = bload(rxr, ix + j < p.W ? boff + 4u * j : BUF_OOB);
-                        o[j] *= act_grad(fmaf(xr, scale, shift), PRO);
-                        if (ix + j < p.W) { s1 += o[j]; s2 = fmaf(o[j], (xr - mean) * invstd, s2); }
+                        o[j] *= act_grad(fmaf(xr[j], scale, shift), PRO);
+                        if (ix + j < p.W) { s1 += o[j]; s2 = fmaf(o[j], (xr[j] - mean) * invstd, s2); }
                     }
                 }
-                if (p.beta) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += bload(rout, ix + j < p.W ? boff + 4u * j : BUF_OOB);
-                }
+                for (int j = 0; j < 4; ++j) o[j] += ob[j];
                 float* dst = p.out + off;
                 if (vec4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -422,11 +504,11 @@ static int fill_geo(DwP& p, const int32_t* d) {
 static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 
 // tiling over rows of the COMPUTED plane (ho x wo); src rows needed per band = irt, src columns = lw
-static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP&), int lw, bool with_w) {
+static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP&), int lw, bool with_w, bool vec) {
     // outputs per workgroup: enough loads in flight per CU to cover HBM latency, LDS small enough for ~6 workgroups / CU
     static const int target0 = [] { const char* e = getenv("S2K_DW_TARGET"); return e ? atoi(e) : 4096; }();
     const int hw = ho * wo;
-    p.LW = lw | 1;
+    p.LW = vec ? (lw + 3) & ~3 : lw | 1;     // vector layout: float4 rows; scalar layout: odd stride
     p.XG = cdiv(wo, 4);
     size_t lds = 0;
     for (int target = target0;; target >>= 1) {
@@ -442,6 +524,9 @@ static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP
     int l2 = 0;
     while ((1 << l2) < p.LW && l2 < 6) ++l2;
     p.lwp_shift = l2;
+    l2 = 0;
+    while ((1 << l2) < (p.LW >> 2) && l2 < 6) ++l2;
+    p.vps_shift = l2;
     return lds;
 }
 
@@ -468,15 +553,19 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (op.d[S2K_DWCONV_FWD_D_NREP] > 0) p.nrep = op.d[S2K_DWCONV_FWD_D_NREP];
     if (bad(p.x) || bad(p.bnv) || bad(p.w) || bad(p.out) || bad(p.stats)) { set_error("dwconv_fwd: null base"); return S2K_EFAULT; }
     if (!p.x || !p.w || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_fwd: missing tensor"); return S2K_EINVAL; }
-    const int lw = (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
-    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true);
+    // tile columns: source column cc - 4; the widest window ends at 4 - PL + (4*XG - 1)*S + K - 1
+    const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
+    if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
+    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true, true);
     const bool silu = p.pro == S2K_PRO_SILU;
-#define DW_FWD(KK, SS) (silu ? launch_dw(dwconv_fwd_kernel<KK, SS, S2K_PRO_SILU>, p, lds, c.stream) \
-                             : launch_dw(dwconv_fwd_kernel<KK, SS, S2K_PRO_NONE>, p, lds, c.stream))
-    if (p.K == 3 && p.S == 1) return DW_FWD(3, 1);
-    if (p.K == 3 && p.S == 2) return DW_FWD(3, 2);
-    if (p.K == 5 && p.S == 1) return DW_FWD(5, 1);
-    return DW_FWD(5, 2);
+#define DW_FWD(KK, SS, PP) (silu ? launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_SILU>, p, lds, c.stream) \
+                                 : launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_NONE>, p, lds, c.stream))
+#define DW_FWD_PL(KK, SS) (p.PL == 0 ? DW_FWD(KK, SS, 0) : p.PL == 1 ? DW_FWD(KK, SS, 1) : DW_FWD(KK, SS, 2))
+    if (p.K == 3 && p.S == 1) return DW_FWD_PL(3, 1);
+    if (p.K == 3 && p.S == 2) return DW_FWD_PL(3, 2);
+    if (p.K == 5 && p.S == 1) return DW_FWD_PL(5, 1);
+    return DW_FWD_PL(5, 2);
+#undef DW_FWD_PL
 #undef DW_FWD
 }
 
@@ -489,15 +578,18 @@ int launch_dwconv_wgrad(const S2kOp& op, const Ctx& c) {
     p.out = ref_ptr<float>(c, op.t[S2K_DWCONV_WGRAD_T_DW]);
     if (bad(p.x) || bad(p.bnv) || bad(p.dy) || bad(p.out)) { set_error("dwconv_wgrad: null base"); return S2K_EFAULT; }
     if (!p.x || !p.dy || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_wgrad: missing tensor"); return S2K_EINVAL; }
-    const int lw = (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
-    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false);
+    const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
+    if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
+    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false, true);
     const bool silu = p.pro == S2K_PRO_SILU;
-#define DW_WG(KK, SS) (silu ? launch_dw(dwconv_wgrad_kernel<KK, SS, S2K_PRO_SILU>, p, lds, c.stream) \
-                            : launch_dw(dwconv_wgrad_kernel<KK, SS, S2K_PRO_NONE>, p, lds, c.stream))
-    if (p.K == 3 && p.S == 1) return DW_WG(3, 1);
-    if (p.K == 3 && p.S == 2) return DW_WG(3, 2);
-    if (p.K == 5 && p.S == 1) return DW_WG(5, 1);
-    return DW_WG(5, 2);
+#define DW_WG(KK, SS, PP) (silu ? launch_dw(dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_SILU>, p, lds, c.stream) \
+                                : launch_dw(dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_NONE>, p, lds, c.stream))
+#define DW_WG_PL(KK, SS) (p.PL == 0 ? DW_WG(KK, SS, 0) : p.PL == 1 ? DW_WG(KK, SS, 1) : DW_WG(KK, SS, 2))
+    if (p.K == 3 && p.S == 1) return DW_WG_PL(3, 1);
+    if (p.K == 3 && p.S == 2) return DW_WG_PL(3, 2);
+    if (p.K == 5 && p.S == 1) return DW_WG_PL(5, 1);
+    return DW_WG_PL(5, 2);
+#undef DW_WG_PL
 #undef DW_WG
 }
 
@@ -517,15 +609,18 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
     if (p.pro == S2K_PRO_NONE) p.stats = nullptr;
     if (p.S == 1) {
         if (p.HO != p.H || p.WO != p.W) { set_error("dwconv_dgrad: stride-1 geometry mismatch"); return S2K_EINVAL; }
-        const int lw = cdiv(p.W, 4) * 4 + p.K - 1;
-        const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad1, lw, true);
+        const int pr = p.K - 1 - p.PL;       // right padding of the forward = left reach of the correlation
+        if (pr < 0 || pr > 2) { set_error("dwconv_dgrad: padding %d is not on this path", p.PL); return S2K_EINVAL; }
+        const int lw = 4 - pr + cdiv(p.W, 4) * 4 + p.K - 1;
+        const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad1, lw, true, true);
         const bool silu = p.pro == S2K_PRO_SILU;
-        if (p.K == 3) return silu ? launch_dw(dwconv_dgrad_s1_kernel<3, S2K_PRO_SILU>, p, lds, c.stream)
-                                  : launch_dw(dwconv_dgrad_s1_kernel<3, S2K_PRO_NONE>, p, lds, c.stream);
-        return silu ? launch_dw(dwconv_dgrad_s1_kernel<5, S2K_PRO_SILU>, p, lds, c.stream)
-                    : launch_dw(dwconv_dgrad_s1_kernel<5, S2K_PRO_NONE>, p, lds, c.stream);
+#define DW_DG(KK, PP) (silu ? launch_dw(dwconv_dgrad_s1_kernel<KK, PP, S2K_PRO_SILU>, p, lds, c.stream) \
+                            : launch_dw(dwconv_dgrad_s1_kernel<KK, PP, S2K_PRO_NONE>, p, lds, c.stream))
+        if (p.K == 3) return pr == 0 ? DW_DG(3, 0) : pr == 1 ? DW_DG(3, 1) : DW_DG(3, 2);
+        return pr == 0 ? DW_DG(5, 0) : pr == 1 ? DW_DG(5, 1) : DW_DG(5, 2);
+#undef DW_DG
     }
-    const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO, true);
+    const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO, true, false);
     return launch_dw(dwconv_dgrad_s2_kernel, p, lds, c.stream);
 }
 
