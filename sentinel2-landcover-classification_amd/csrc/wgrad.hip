@@ -10,6 +10,8 @@
 // activations are re-normalised/activated on load (same prologue as the forward), never stored.
 // Partial sums of the pixel splits are combined with float atomics into a [T][M][C] scratch whose
 // rows are contiguous along c (128-B segments per half-wave: the full-rate atomic shape).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace s2k {
@@ -353,7 +355,10 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     }
     // pixel splits: aim at ~3 workgroups per CU, at least 4 tiles per split to amortise the combine
     const int mc = p.n_mtiles * p.n_ctiles;
-    int splits = cdiv(768, mc);
+    // the 9-tap kernels hold 144 accumulator registers (one workgroup per CU): one pixel split per CU keeps the atomic
+    // combine (144 adds per lane) and the pipeline fill at 1/32 of the work; the 1x1 / 2x2 kernels run 2-3 per CU
+    const int target_blocks = (T == 9) ? 256 : 768;
+    int splits = cdiv(target_blocks, mc);
     const int max_splits = cdiv(p.ntiles, 4);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -439,8 +444,9 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     if (p.T != 9) { set_error("wgrad: only 1x1, 3x3 and 2x2-transpose kernels are on this path"); return S2K_EINVAL; }
     // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles; thin layers (few
     // channels, huge maps) take 128-pixel tiles, the rest 64 (two workgroups per CU by LDS)
+    static const int wide = [] { const char* e = getenv("S2K_WG_WIDE"); return e ? atoi(e) : 0; }();
     const bool thin = (p.M <= 32);
-    const int NPX = thin ? 128 : 64;
+    const int NPX = (thin || wide) ? 128 : 64;
     int XW = p.WO <= NPX ? p.WO : NPX;
     int R = NPX / ((XW + 1) & ~1);
     if (R > p.HO) R = p.HO;
@@ -464,6 +470,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.NP = 0;
     if (thin && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4, 128, 2>(p, st);
     if (thin) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2, 128, 2>(p, st);
+    if (wide) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 128, 2>(p, st);
     if (p.IR * p.WS <= NTHREADS) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1>(p, st);
     return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 2>(p, st);
 }
