@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace s2k {
@@ -142,13 +144,63 @@ size_t s2k_op_size(void) { return sizeof(S2kOp); }
 const char* s2k_last_error(void) { return g_err; }
 const char* s2k_kind_name(int kind) { return (kind > 0 && kind <= S2K_N_KINDS) ? kNames[kind] : nullptr; }
 
+// Side stream for stages flagged S2K_FLAG_SIDE (weight gradients: nothing downstream in the backward chain reads them
+// until the bucket's WGRAD_FINALIZE): they run concurrently with the main chain, so an MFMA-bound wgrad overlaps the
+// HBM-bound BatchNorm / depthwise stages of the layers below.  Fork = event on the caller's stream the side stream waits
+// for (re-armed whenever main-stream work was issued since the last fork); join = the reverse, in front of every stage
+// flagged S2K_FLAG_JOIN and at the end of the call, so on return all work is ordered on the caller's stream again.
+struct SideQueue {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+};
+static SideQueue& side_queue() {
+    static SideQueue q = [] {
+        SideQueue s;
+        const char* e = getenv("S2K_NO_SIDE_STREAM");
+        if (e && e[0] == '1') return s;
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return s;
+        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return s;
+        if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return s;
+        s.ok = true;
+        return s;
+    }();
+    return q;
+}
+
 int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream) {
     if (!ops || !bases || begin < 0 || end < begin) { set_error("program_run: bad arguments"); return S2K_EINVAL; }
-    Ctx c{bases, n_bases, static_cast<hipStream_t>(stream)};
+    hipStream_t main_st = static_cast<hipStream_t>(stream);
+    Ctx c{bases, n_bases, main_st};
+    SideQueue& sq = side_queue();
+    bool side_busy = false;      // side work issued and not yet joined
+    bool main_dirty = true;      // main-stream work issued since the last fork
+    auto join = [&]() {
+        if (!side_busy) return;
+        (void)hipEventRecord(sq.join, sq.stream);
+        (void)hipStreamWaitEvent(main_st, sq.join, 0);
+        side_busy = false;
+    };
     for (int i = begin; i < end; ++i) {
-        const int rc = check_launch(dispatch(ops[i], c), ops[i], i);
-        if (rc != S2K_OK) return rc;
+        const S2kOp& op = ops[i];
+        int rc;
+        if ((op.flags & S2K_FLAG_SIDE) && sq.ok) {
+            if (main_dirty) {
+                (void)hipEventRecord(sq.fork, main_st);
+                (void)hipStreamWaitEvent(sq.stream, sq.fork, 0);
+                main_dirty = false;
+            }
+            Ctx cs{bases, n_bases, sq.stream};
+            rc = check_launch(dispatch(op, cs), op, i);
+            side_busy = true;
+        } else {
+            if (op.flags & S2K_FLAG_JOIN) join();
+            rc = check_launch(dispatch(op, c), op, i);
+            main_dirty = true;
+        }
+        if (rc != S2K_OK) { join(); return rc; }
     }
+    join();
     return S2K_OK;
 }
 

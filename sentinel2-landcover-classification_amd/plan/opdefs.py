@@ -34,6 +34,7 @@ def stats_replicas(C: int) -> int:
 PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU, PRO_GELU = 0, 1, 2, 3, 4   # v' = act(scale[c]*v + shift[c]); GELU = exact erf form
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 2, 3, 4                   # same numbering as PRO_*
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
+FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream fork / join)
 
 # kind -> (t slots, n slots, d slots, f slots); positional
 OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {

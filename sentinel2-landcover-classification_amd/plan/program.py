@@ -75,8 +75,9 @@ class Program:
         self.ops: list[tuple[str, dict]] = []
 
     def add(self, kind: str, **fields) -> None:
+        """`_flags` (optional): S2kOp.flags bits (opdefs.FLAG_*)."""
         t, n, d, f = D.OPS[kind]
-        known = set(t) | set(n) | set(d) | set(f)
+        known = set(t) | set(n) | set(d) | set(f) | {"_flags"}
         bad = set(fields) - known
         if bad:
             raise KeyError(f"{kind}: unknown fields {sorted(bad)}")
@@ -91,6 +92,9 @@ class Program:
         for i, (kind, fields) in enumerate(self.ops):
             arr[i]["kind"] = D.KIND[kind]
             for k, v in fields.items():
+                if k == "_flags":
+                    arr[i]["flags"] = int(v)
+                    continue
                 a, j = D.slot(kind, k)
                 if a == "t":
                     arr[i]["t"][j] = NULL if v is None else (v.ref if isinstance(v, TRef) else int(v))

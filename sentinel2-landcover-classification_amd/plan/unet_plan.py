@@ -652,6 +652,13 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
                                            BYTES=bwd_aux_end - fwd_aux_end)))
         p.bwd.ops[0:0] = pre_ops
         segments = _bucket_backward(p, layout, table, bucket_floats)
+        # weight / bias gradients feed nothing in the backward chain until the bucket's WGRAD_FINALIZE: the executor may run
+        # them on its side stream, concurrently with the (mostly HBM-bound) BatchNorm / depthwise stages of the layers below
+        for kind, f in p.bwd.ops:
+            if kind in ("WGRAD", "DWCONV_WGRAD", "CHANNEL_SUM"):
+                f["_flags"] = D.FLAG_SIDE
+            elif kind == "WGRAD_FINALIZE":
+                f["_flags"] = D.FLAG_JOIN
         n_before = len(p.bwd.ops)
         pack_op(p.bwd, p.pack_rows["bwd"])
         if len(p.bwd.ops) > n_before:   # WEIGHT_PACK went in front
