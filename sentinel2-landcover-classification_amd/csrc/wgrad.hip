@@ -12,6 +12,8 @@
 // rows are contiguous along c (128-B segments per half-wave: the full-rate atomic shape).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace s2k {
@@ -353,16 +355,22 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    // pixel splits: aim at ~3 workgroups per CU, at least 4 tiles per split to amortise the combine
+    // Pixel splits.  The 9-tap kernels hold 144 accumulator registers (one workgroup per CU), the 1x1 / 2x2 kernels run
+    // ~3 per CU: pick the split count whose workgroup count fills whole rounds of those slots (288 workgroups on 256
+    // slots take two rounds: 1.8x the time of 256), preferring fewer splits (each ends in an atomic combine of its tile).
     const int mc = p.n_mtiles * p.n_ctiles;
-    // the 9-tap kernels hold 144 accumulator registers (one workgroup per CU): one pixel split per CU keeps the atomic
-    // combine (144 adds per lane) and the pipeline fill at 1/32 of the work; the 1x1 / 2x2 kernels run 2-3 per CU
-    const int target_blocks = (T == 9) ? 256 : 768;
-    int splits = cdiv(target_blocks, mc);
-    const int max_splits = cdiv(p.ntiles, 4);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
+    const int slots = (T == 9) ? 256 : 768;
+    int max_splits = cdiv(p.ntiles, 4);          // at least 4 pixel tiles per split
+    if (max_splits > 65535) max_splits = 65535;
+    if (max_splits < 1) max_splits = 1;
+    int splits = 1;
+    double best = 1e30;
+    const int s_hi = std::min(max_splits, std::max(1, 4 * slots / mc));
+    for (int sp = 1; sp <= s_hi; ++sp) {
+        const double rounds = (double)cdiv(mc * sp, slots);
+        const double cost = rounds * ((double)cdiv(p.ntiles, sp) + (T == 9 ? 1.5 : 0.5));   // tiles + the combine, in tile times
+        if (cost < best * 0.999) { best = cost; splits = sp; }
+    }
     p.tiles_per_split = cdiv(p.ntiles, splits);
     splits = cdiv(p.ntiles, p.tiles_per_split);
     hipLaunchKernelGGL(kern, dim3(mc, splits), dim3(NTHREADS), lds, st, p);

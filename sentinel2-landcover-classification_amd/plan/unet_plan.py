@@ -654,7 +654,11 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         segments = _bucket_backward(p, layout, table, bucket_floats)
         # weight / bias gradients feed nothing in the backward chain until the bucket's WGRAD_FINALIZE: the executor may run
         # them on its side stream, concurrently with the (mostly HBM-bound) BatchNorm / depthwise stages of the layers below
+        import os
+        side_max = float(os.environ.get("S2K_SIDE_MAX_GFLOP", "1e9")) * 1e9
         for kind, f in p.bwd.ops:
+            if kind == "WGRAD" and 2.0 * f["M"] * f["C"] * f["KH"] * f["KW"] * f["B"] * f["HO"] * f["WO"] > side_max:
+                continue      # two large MFMA-bound kernels side by side only fight for the same units
             if kind in ("WGRAD", "DWCONV_WGRAD", "CHANNEL_SUM"):
                 f["_flags"] = D.FLAG_SIDE
             elif kind == "WGRAD_FINALIZE":
