@@ -47,7 +47,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW>
+// BVEC (1x1 stager only): a lane moves 4 consecutive pixels of one channel (one 16-byte load, one ds_write_b128, one
+// gate load) instead of one: the per-element address / validity / LDS-store work of the prologue-heavy 1x1 convs drops 4x.
+// Needs H*W % 4 == 0 (a group of 4 never straddles two images) and contiguous pixels (not the 2x2 gather mode).
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW, bool BVEC = false>
 __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BN = WN * WVN * 32;
@@ -58,6 +61,11 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     constexpr int NB = (BMODE == BM_PIX) ? KCH * BN / NTHREADS : KCH * EPT;  // B elements per thread per chunk
     constexpr int A_FLOATS = (KT * AS + 3) & ~3;
     static_assert(WVM * WVN == 4, "4 waves per workgroup");
+    static_assert(!BVEC || BMODE == BM_PIX, "vector stager is for the 1x1 path");
+    constexpr int LPR = BVEC ? BN / 4 : BN;                   // stager lanes per B row
+    constexpr int KSTEPV = (NTHREADS >= LPR) ? NTHREADS / LPR : 1;
+    constexpr int NBV = BVEC ? KCH / KSTEPV : 1;              // float4 pieces per thread per chunk
+    static_assert(!BVEC || (KCH % KSTEPV == 0 && NTHREADS % LPR == 0), "vector stager shape");
     static_assert(BMODE != BM_PIX || (NTHREADS % BN == 0 || BN % NTHREADS == 0), "pixel tile vs threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 ycol[rn] = (int64_t)b * p.YC * HWo + pp;
             }
         }
-        const int j = tid % BN;
+        const int j = BVEC ? 4 * (tid % LPR) : tid % BN;
         const int n = n0 + j;
         st_valid = n < p.Ntot;
         const int nn = st_valid ? n : 0;
@@ -173,8 +181,10 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     const int used_sp = p.IR * p.WS;
 
     f32x4 areg[NA];
-    float breg[NB];
-    float greg[(BMODE == BM_PIX) ? NB : 1];   // SE gate of the fetched elements (1x1 project conv only)
+    float breg[BVEC ? 1 : NB];
+    float greg[(BMODE == BM_PIX && !BVEC) ? NB : 1];   // SE gate of the fetched elements (1x1 project conv only)
+    f32x4 bvec[BVEC ? NBV : 1];
+    float gvec[BVEC ? NBV : 1];
     if (has_pro) {
         for (int c = tid; c < p.Ctot; c += NTHREADS) {
             float sc = 1.0f, sh = 0.0f;
@@ -198,7 +208,17 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         // B: raw values (prologue applied at LDS-store time) through bounds-checked buffer loads: invalid
         // elements are an out-of-range OFFSET (hardware returns 0), so every load is unconditional and all
         // of a chunk's loads are in flight together
-        if (BMODE == BM_PIX) {
+        if constexpr (BVEC) {
+            const int kc0 = tid / LPR;
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) {
+                const int c = c0 + kc0 + i * KSTEPV;
+                const bool ok = st_valid && c < p.Ctot;
+                const uint32_t off = (c < p.C1) ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
+                bvec[i] = bload4(c < p.C1 ? rx1 : rx2, ok ? off : BUF_OOB);
+                gvec[i] = bload(rgt, (ok && c < p.C1) ? (uint32_t)(st_gate + c) * 4u : BUF_OOB);
+            }
+        } else if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
             const int kc0 = __builtin_amdgcn_readfirstlane(tid / BN);
 #pragma unroll
@@ -241,7 +261,27 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         const int pro_u = (p.C2 > 0 && p.pro2 != p.pro1) ? -1 : p.pro1;
         auto body = [&](auto tag) {
             constexpr int PRO = decltype(tag)::value;
-            if (BMODE == BM_PIX) {
+            if constexpr (BVEC) {
+                const int j4 = tid % LPR, kc0 = tid / LPR;
+#pragma unroll
+                for (int i = 0; i < NBV; ++i) {
+                    const int kc = kc0 + i * KSTEPV;
+                    const int c = c0 + kc;
+                    const bool ok = st_valid && c < p.Ctot;
+                    const int cc = c < p.Ctot ? c : p.Ctot - 1;
+                    float sc = 1.0f, sh = 0.0f;
+                    if (PRO != S2K_PRO_NONE) { sc = ssc[cc]; sh = ssh[cc]; }
+                    const float gm = p.gate1 ? gvec[i] : 1.0f;
+                    f32x4 v = bvec[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e];
+                        if (PRO != S2K_PRO_NONE) t = apply_pro_c<PRO>(t, sc, sh);
+                        v[e] = ok ? t * gm : 0.0f;
+                    }
+                    *reinterpret_cast<f32x4*>(Bs + kc * BN + 4 * j4) = v;
+                }
+            } else if (BMODE == BM_PIX) {
                 constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
                 const int j = tid % BN;
                 const int kc0 = __builtin_amdgcn_readfirstlane(tid / BN);   // wave-uniform (BN >= 64)
@@ -277,7 +317,21 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         if (pro_u >= 0) {
             dispatch_pro(pro_u, body);
         } else {  // mixed concat (not produced by the planner today): generic per-element form
-            if (BMODE == BM_PIX) {
+            if constexpr (BVEC) {
+                const int j4 = tid % LPR, kc0 = tid / LPR;
+#pragma unroll
+                for (int i = 0; i < NBV; ++i) {
+                    const int kc = kc0 + i * KSTEPV;
+                    const int c = c0 + kc;
+                    const bool ok = st_valid && c < p.Ctot;
+                    const int cc = c < p.Ctot ? c : p.Ctot - 1;
+                    const float gm = p.gate1 ? gvec[i] : 1.0f;
+                    f32x4 v = bvec[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? apply_pro(v[e], cc < p.C1 ? p.pro1 : p.pro2, ssc[cc], ssh[cc]) * gm : 0.0f;
+                    *reinterpret_cast<f32x4*>(Bs + kc * BN + 4 * j4) = v;
+                }
+            } else if (BMODE == BM_PIX) {
                 constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
                 const int j = tid % BN;
 #pragma unroll
@@ -519,7 +573,7 @@ __global__ void __launch_bounds__(NTHREADS) splitk_reduce_kernel(const ConvP p) 
     }
 }
 
-template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW = 2>
+template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW = 2, bool BVEC = false>
 static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk = false) {
     constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;
     constexpr int A_FLOATS = (KCH * TT * BM + 3) & ~3;
@@ -528,7 +582,7 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     p.b_floats = (int)b_floats;
     const size_t lds = (A_FLOATS + b_floats + 2 * (size_t)p.Ctot) * sizeof(float);
     if (BMODE == BM_SPATIAL && p.gate1) { set_error("conv: SE gate is only supported on 1x1 convs"); return S2K_EINVAL; }
-    auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW>;
+    auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW, BVEC>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -645,12 +699,18 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
         static const int small_max = [] { const char* e = getenv("S2K_PIX_SMALL_TILES"); return e ? atoi(e) : 400; }();
-        if (bm >= 64 && tiles_big < small_max) return launch_cfg<BM_PIX, 1, 1, 1, 2, 2, 64, 1>(p, cdiv(p.Ntot, 64), st, true);
         static const int k16_max = [] { const char* e = getenv("S2K_PIX_K16_MAX"); return e ? atoi(e) : 192; }();
-        if (bm == 128 && p.Ctot <= k16_max) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 16, 1>(p, cdiv(p.Ntot, 128), st);   // short-K expand convs
-        if (bm == 128) return launch_cfg<BM_PIX, 1, 2, 2, 2, 2, 64, 1>(p, cdiv(p.Ntot, 128), st);
-        if (bm == 64) return launch_cfg<BM_PIX, 1, 2, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
-        return launch_cfg<BM_PIX, 1, 1, 2, 1, 4, 16, 1>(p, cdiv(p.Ntot, 256), st);
+        static const int novec = [] { const char* e = getenv("S2K_PIX_NOVEC"); return e ? atoi(e) : 0; }();
+        const bool bvec = !novec && p.mode != S2K_MODE_GATHER2X2 && (p.HW & 3) == 0;
+#define PIX_CFG(WMv, WNv, WVMv, WVNv, KCHv, ntl, sk) \
+    (bvec ? launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, true>(p, ntl, st, sk) \
+          : launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, false>(p, ntl, st, sk))
+        if (bm >= 64 && tiles_big < small_max) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
+        if (bm == 128 && p.Ctot <= k16_max) return PIX_CFG(2, 2, 2, 2, 16, cdiv(p.Ntot, 128), false);   // short-K expand convs
+        if (bm == 128) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), false);
+        if (bm == 64) return PIX_CFG(2, 2, 1, 4, 16, cdiv(p.Ntot, 256), false);
+        return PIX_CFG(1, 2, 1, 4, 16, cdiv(p.Ntot, 256), false);
+#undef PIX_CFG
     }
     if (T != 9 || p.S > 2) { set_error("conv: unsupported kernel %dx%d stride %d", p.KH, p.KW, p.S); return S2K_EINVAL; }
     int64_t tiles = 0;
