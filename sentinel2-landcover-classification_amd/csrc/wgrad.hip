@@ -293,18 +293,29 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                         acc[t][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rm], bq[t][rn], acc[t][rm][rn], 0, 0, 0);
         };
         float a0[WM], a1[WM], b0[T][WN], b1[T][WN];
+        // issue order inside one half-iteration: MFMA, then a slice of the NEXT pair's address arithmetic and LDS reads,
+        // MFMA, ... — the 64-cycle MFMA leaves its SIMD's issue port free for ~48 cycles, which is where that work goes
+        auto interleave = [&]() {
+#pragma unroll
+            for (int t = 0; t < T * WM * WN; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // <= 2 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // <= 4 VALU / SALU
+            }
+        };
         lds_operands(wk, a0, b0);
         for (int s = wk; s < npairs; s += 2 * WVK) {
-            lds_operands(s + WVK, a1, b1);
             __builtin_amdgcn_sched_barrier(0);
+            lds_operands(s + WVK, a1, b1);
             mfmas(a0, b0);
+            interleave();
             __builtin_amdgcn_sched_barrier(0);
             if (s + WVK >= npairs) break;
             lds_operands(s + 2 * WVK, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
             mfmas(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            interleave();
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         if (more) {
             commit();
