@@ -80,6 +80,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
 __device__ __forceinline__ float bload(rsrc_t r, uint32_t byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
+// vector offset (range-checked: BUF_OOB -> 0) + scalar offset (NOT range-checked: keep base + soff inside the tensor)
+__device__ __forceinline__ float bload_s(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, uint32_t byte_off) {   // 16-byte aligned offsets only
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }

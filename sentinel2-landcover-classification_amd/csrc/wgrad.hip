@@ -54,10 +54,16 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     constexpr int NQR = (MODE == WG_SPATIAL) ? BC * EPT : (MODE == WG_GATHER ? 4 * (BC / RSTEP) : BC / RSTEP);
     static_assert(WVM * WVN * WVK == 4, "4 waves per workgroup");
     static_assert(NTHREADS % NPJ == 0 && BM % RSTEP == 0 && BC % RSTEP == 0, "pixel slots vs threads");
+    // SPATIAL: compile-time LDS row strides (tap / channel offsets of the operand reads and of the stager's stores fold
+    // into instruction immediates instead of vector adds — the f32 MFMA holds the SIMD's vector issue port, so every
+    // VALU instruction costs MFMA time)
+    constexpr int PSTR_C = NPJ + 1, CSQ_C = NTHREADS * EPT + 1;
+    const int PSTR = (MODE == WG_SPATIAL) ? PSTR_C : p.PSTR;
+    const int CSQ = (MODE == WG_SPATIAL) ? CSQ_C : p.CSQ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [BM][PSTR]
-    float* Qs = smem + BM * p.PSTR;      // [BC][CSQ]
-    float* psc = Qs + BC * p.CSQ;        // BatchNorm scale/shift of this workgroup's P rows / Q columns,
+    float* Qs = smem + BM * PSTR;        // [BC][CSQ]
+    float* psc = Qs + BC * CSQ;          // BatchNorm scale/shift of this workgroup's P rows / Q columns,
     float* psh = psc + BM;               // staged once so that the commit step has no loads behind branches
     float* qsc = psh + BM;
     float* qsh = qsc + BC;
@@ -138,10 +144,15 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int yo = y0 + pr, xo = x0 + pxx;
             f_b = b;
             f_pok = pj < np_sp && pxx < p.XW && yo < p.HO && xo < p.WO;
-            const uint32_t pbase = (uint32_t)(((int64_t)b * p.M + m0 + prow) * p.HWp + (f_pok ? yo * p.WO + xo : 0)) * 4u;
+            // per-lane part (pixel, or out of range) in the vector offset, per-row part in the SCALAR offset: no vector
+            // arithmetic per load.  Rows / channels past the tensor are clamped (their products land in discarded outputs).
+            const uint32_t pvoff = f_pok ? (uint32_t)(yo * p.WO + xo) * 4u : BUF_OOB;
+            const int prow_u = __builtin_amdgcn_readfirstlane(prow);   // NPJ >= 64: one P row per wave and pass
 #pragma unroll
-            for (int i = 0; i < NPR; ++i)
-                preg[i] = bload(rp, (f_pok && m0 + prow + i * RSTEP < p.M) ? pbase + i * p_rstride : BUF_OOB);
+            for (int i = 0; i < NPR; ++i) {
+                const int row = min(m0 + prow_u + i * RSTEP, p.M - 1);
+                preg[i] = bload_s(rp, pvoff, (uint32_t)((b * p.M + row) * p.HWp) * 4u);
+            }
             const int iy0 = y0 * p.S - p.PT, ix0 = x0 * p.S - p.PL;
             uint32_t goff[EPT];
             f_qok = 0;
@@ -152,13 +163,12 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 goff[i] = ok ? (uint32_t)(iy * p.W + ix) * 4u : BUF_OOB;
                 f_qok |= ok ? (1u << i) : 0u;
             }
-            const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0) * p.HWq) * 4u;
-            const uint32_t cstride = (uint32_t)p.HWq * 4u;
 #pragma unroll
-            for (int c = 0; c < BC; ++c)
+            for (int c = 0; c < BC; ++c) {
+                const uint32_t soff = (uint32_t)((b * p.C + min(c0 + c, p.C - 1)) * p.HWq) * 4u;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i)   // BUF_OOB + anything below 2^31 stays out of range -> 0
-                    qreg[c * EPT + i] = bload(rq, (c0 + c < p.C && goff[i] != BUF_OOB) ? qbase + c * cstride + goff[i] : BUF_OOB);
+                for (int i = 0; i < EPT; ++i) qreg[c * EPT + i] = bload_s(rq, goff[i], soff);
+            }
         } else {
             const int64_t ntot = (int64_t)p.B * p.HWp;
             const int64_t n = (int64_t)tile * NPJ + pj;
@@ -197,19 +207,25 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     // ---------------- registers -> LDS (prologues applied here; zero padding stays zero) ----------------
     // branch-free per element: parameters from LDS, validity as a final select
     auto commit = [&]() {
-        if (MODE != WG_SPATIAL || pj < np_sp) {
+        if (MODE == WG_SPATIAL) {        // out-of-image pixels were loaded as 0 (no prologue on this operand)
+            static_assert(MODE != WG_SPATIAL || PROP == S2K_PRO_NONE, "3x3 wgrad: P (= dY) carries no prologue");
+            if (pj < np_sp) {
+#pragma unroll
+                for (int i = 0; i < NPR; ++i) Ps[(prow + i * RSTEP) * PSTR + pj] = preg[i];
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
                 const int m = prow + i * RSTEP;
                 float v = preg[i];
                 if (PROP != S2K_PRO_NONE) v = apply_pro_c<PROP>(v, psc[m], psh[m]);
-                Ps[m * p.PSTR + pj] = (f_pok && m0 + m < p.M) ? v : 0.0f;
+                Ps[m * PSTR + pj] = (f_pok && m0 + m < p.M) ? v : 0.0f;
             }
         }
         if (MODE == WG_GATHER) {
 #pragma unroll
             for (int i = 0; i < BC / RSTEP; ++i) {
-                float* dst = Qs + (prow + i * RSTEP) * p.CSQ + pj;
+                float* dst = Qs + (prow + i * RSTEP) * CSQ + pj;
                 dst[0] = qreg[4 * i + 0];
                 dst[NPJ] = qreg[4 * i + 1];
                 dst[2 * NPJ] = qreg[4 * i + 2];
@@ -223,10 +239,9 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) {
                     const int e = tid + NTHREADS * i;
-                    float v = qreg[c * EPT + i];
-                    if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, sc, sh);
-                    v = (c0 + c < p.C && ((f_qok >> i) & 1u)) ? v : 0.0f;
-                    if (e < used_sp) Qs[c * p.CSQ + e] = v;
+                    float v = qreg[c * EPT + i];       // padding / out-of-tile slots were loaded as 0
+                    if (PROQ != S2K_PRO_NONE) v = ((f_qok >> i) & 1u) ? apply_pro_c<PROQ>(v, sc, sh) : 0.0f;
+                    if (e < used_sp) Qs[c * CSQ + e] = v;
                 }
             }
         } else {
@@ -236,7 +251,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 float v = qreg[i];
                 if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, qsc[c], qsh[c]);
                 if (p.gateq) v *= qgate[(MODE == WG_PIX) ? i : 0];
-                Qs[c * p.CSQ + pj] = (f_pok && c0 + c < p.C) ? v : 0.0f;
+                Qs[c * CSQ + pj] = (f_pok && c0 + c < p.C) ? v : 0.0f;
             }
         }
     };
@@ -262,7 +277,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const bool live = s < npairs;          // past the end: re-read pair 0 (never used), keeps the loop branch-free
             const int n = live ? 2 * s + lh : lh;  // this lane's pixel inside the tile
 #pragma unroll
-            for (int rm = 0; rm < WM; ++rm) a[rm] = Ps[(wm0 + rm * 32 + l31) * p.PSTR + n];
+            for (int rm = 0; rm < WM; ++rm) a[rm] = Ps[(wm0 + rm * 32 + l31) * PSTR + n];
             int qbase;
             if (MODE == WG_SPATIAL) {
                 qbase = live ? (r_run * p.S) * p.WS + (2 * xp_run + lh) * p.S : 0;
@@ -279,7 +294,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 else if (MODE == WG_GATHER) toff = t * NPJ;
                 else toff = 0;
 #pragma unroll
-                for (int rn = 0; rn < WN; ++rn) bq[t][rn] = Qs[(wc0 + rn * 32 + l31) * p.CSQ + qbase + toff];
+                for (int rn = 0; rn < WN; ++rn) bq[t][rn] = Qs[(wc0 + rn * 32 + l31) * CSQ + qbase + toff];
                 if (++tdx == p.KW) { tdx = 0; ++tdy; }
             }
         };
@@ -355,6 +370,10 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
+    if (MODE == WG_SPATIAL) { p.PSTR = NPJ + 1; p.CSQ = NTHREADS * EPT + 1; }   // compile-time strides in the kernel
+    if ((int64_t)p.B * p.M * p.HWp * 4 >= 0x7ffffff0ll || (int64_t)p.B * p.C * p.HWq * 4 >= 0x7ffffff0ll) {
+        set_error("wgrad: tensor larger than 2 GiB"); return S2K_EINVAL;
+    }
     const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ + 2 * (BM + BC)) * sizeof(float);
     if (p.gatep || (p.gateq && MODE != WG_PIX)) { set_error("wgrad: SE gate is only supported on the Q operand of 1x1 convs"); return S2K_EINVAL; }
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
