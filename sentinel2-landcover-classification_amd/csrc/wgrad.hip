@@ -232,15 +232,23 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 dst[3 * NPJ] = qreg[4 * i + 3];
             }
         } else if (MODE == WG_SPATIAL) {
+            // branch-free and address-arithmetic-free: the scale/shift table is read through ONE laundered LDS base
+            // register + immediates, padding slots are zeroed by a 0/1 multiplier (hipcc turns `ok ? pro(v) : 0` into a
+            // branch per element and re-materialises every constant LDS address with a v_mov)
+            const float* qtab = qsc;
+            asm volatile("" : "+v"(qtab));
+            float keepf[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) keepf[i] = ((f_qok >> i) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
             for (int c = 0; c < BC; ++c) {
                 float sc = 1.0f, sh = 0.0f;
-                if (PROQ != S2K_PRO_NONE) { sc = qsc[c]; sh = qsh[c]; }
+                if (PROQ != S2K_PRO_NONE) { sc = qtab[c]; sh = qtab[BC + c]; }
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) {
                     const int e = tid + NTHREADS * i;
                     float v = qreg[c * EPT + i];       // padding / out-of-tile slots were loaded as 0
-                    if (PROQ != S2K_PRO_NONE) v = ((f_qok >> i) & 1u) ? apply_pro_c<PROQ>(v, sc, sh) : 0.0f;
+                    if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, sc, sh) * keepf[i];
                     if (e < used_sp) Qs[c * CSQ + e] = v;
                 }
             }
