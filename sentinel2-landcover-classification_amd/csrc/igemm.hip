@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int CSB = (BMODE == BM_PIX) ? BN : p.CS;
+    // compile-time B row stride (3x3: the halo capacity of the stager, not the halo actually used): k-step and tap offsets of
+    // the operand reads fold into ds_read immediates — the f32 MFMA holds the vector issue port, address VALU is not free
+    constexpr int CSB = (BMODE == BM_PIX) ? BN : NTHREADS * EPT;
     const int nchunks = (p.Ctot + KCH - 1) / KCH;
     const int used_sp = p.IR * p.WS;
 
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                         float v = breg[kc * EPT + i];
                         if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, sc, sh);
                         v = (cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0) ? v : 0.0f;
-                        if (e < used_sp) Bs[kc * p.CS + e] = v;
+                        if (e < used_sp) Bs[kc * CSB + e] = v;
                     }
                 }
             }
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                         const int e = tid + NTHREADS * i;
                         float v = apply_pro(breg[kc * EPT + i], cc < p.C1 ? p.pro1 : p.pro2, ssc[cc], ssh[cc]);
                         v = (cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0) ? v : 0.0f;
-                        if (e < used_sp) Bs[kc * p.CS + e] = v;
+                        if (e < used_sp) Bs[kc * CSB + e] = v;
                     }
                 }
             }
@@ -578,7 +580,7 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;
     constexpr int A_FLOATS = (KCH * TT * BM + 3) & ~3;
     p.n_mtiles = cdiv(p.M, BM);
-    const size_t b_floats = (BMODE == BM_PIX) ? (size_t)KCH * BN : (size_t)KCH * p.CS;
+    const size_t b_floats = (BMODE == BM_PIX) ? (size_t)KCH * BN : (size_t)KCH * NTHREADS * EPT;
     p.b_floats = (int)b_floats;
     const size_t lds = (A_FLOATS + b_floats + 2 * (size_t)p.Ctot) * sizeof(float);
     if (BMODE == BM_SPATIAL && p.gate1) { set_error("conv: SE gate is only supported on 1x1 convs"); return S2K_EINVAL; }
