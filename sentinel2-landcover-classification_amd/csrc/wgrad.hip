@@ -57,9 +57,8 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     // SPATIAL: compile-time LDS row strides (tap / channel offsets of the operand reads and of the stager's stores fold
     // into instruction immediates instead of vector adds — the f32 MFMA holds the SIMD's vector issue port, so every
     // VALU instruction costs MFMA time)
-    constexpr int PSTR_C = NPJ + 1, CSQ_C = NTHREADS * EPT + 1;
-    const int PSTR = (MODE == WG_SPATIAL) ? PSTR_C : p.PSTR;
-    const int CSQ = (MODE == WG_SPATIAL) ? CSQ_C : p.CSQ;
+    constexpr int PSTR = NPJ + 1;
+    constexpr int CSQ = (MODE == WG_SPATIAL) ? NTHREADS * EPT + 1 : (MODE == WG_GATHER ? 4 * NPJ + 1 : NPJ + 1);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [BM][PSTR]
     float* Qs = smem + BM * PSTR;        // [BC][CSQ]
@@ -177,18 +176,27 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int b = (int)(nn / p.HWp);
             const int pp = (int)(nn - (int64_t)b * p.HWp);
             f_b = b;
-            const uint32_t pbase = (uint32_t)(((int64_t)b * p.M + m0 + prow) * p.HWp + pp) * 4u;
+            // per-lane part (image, pixel; or out of range) in the vector offset, the row / channel part in the scalar
+            // offset (clamped into the tensor: rows and channels past the end only feed discarded outputs)
+            const int prow_u = __builtin_amdgcn_readfirstlane(prow);
+            const uint32_t pvoff = f_pok ? (uint32_t)((int64_t)b * p.M * p.HWp + pp) * 4u : BUF_OOB;
 #pragma unroll
-            for (int i = 0; i < NPR; ++i)
-                preg[i] = bload(rp, (f_pok && m0 + prow + i * RSTEP < p.M) ? pbase + i * p_rstride : BUF_OOB);
+            for (int i = 0; i < NPR; ++i) {
+                if constexpr (NPJ >= 64) {   // one P row per wave and pass: the row offset is scalar
+                    preg[i] = bload_s(rp, pvoff, (uint32_t)(min(m0 + prow_u + i * RSTEP, p.M - 1) * p.HWp) * 4u);
+                } else {
+                    const int row = m0 + prow + i * RSTEP;
+                    preg[i] = bload(rp, (f_pok && row < p.M) ? pvoff + (uint32_t)(row * p.HWp) * 4u : BUF_OOB);
+                }
+            }
             if (MODE == WG_PIX) {
-                const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0 + prow) * p.HWq + pp) * 4u;
-                const uint32_t gbase = (uint32_t)((int64_t)b * p.C + c0 + prow) * 4u;
+                const uint32_t qvoff = f_pok ? (uint32_t)((int64_t)b * p.C * p.HWq + pp) * 4u : BUF_OOB;
+                const uint32_t gvoff = f_pok ? (uint32_t)(b * p.C) * 4u : BUF_OOB;
 #pragma unroll
                 for (int i = 0; i < BC / RSTEP; ++i) {
-                    const bool ok = f_pok && c0 + prow + i * RSTEP < p.C;
-                    qreg[i] = bload(rq, ok ? qbase + i * q_rstride : BUF_OOB);
-                    qgate[(MODE == WG_PIX) ? i : 0] = bload(rg, ok ? gbase + i * RSTEP * 4u : BUF_OOB);  // 0-size descriptor without a gate
+                    const int ch = min(c0 + prow_u + i * RSTEP, p.C - 1);
+                    qreg[i] = bload_s(rq, qvoff, (uint32_t)(ch * p.HWq) * 4u);
+                    qgate[(MODE == WG_PIX) ? i : 0] = bload_s(rg, gvoff, (uint32_t)ch * 4u);  // 0-size descriptor without a gate -> 0
                 }
             } else {  // GATHER: Q is [B][C][2HO][2WO]
                 const int yy = pp / p.WO, xx = pp - yy * p.WO;
@@ -214,12 +222,13 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 for (int i = 0; i < NPR; ++i) Ps[(prow + i * RSTEP) * PSTR + pj] = preg[i];
             }
         } else {
+            const float keep = f_pok ? 1.0f : 0.0f;
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
                 const int m = prow + i * RSTEP;
-                float v = preg[i];
-                if (PROP != S2K_PRO_NONE) v = apply_pro_c<PROP>(v, psc[m], psh[m]);
-                Ps[m * PSTR + pj] = (f_pok && m0 + m < p.M) ? v : 0.0f;
+                float v = preg[i];       // out-of-range pixels were loaded as 0
+                if (PROP != S2K_PRO_NONE) v = apply_pro_c<PROP>(v, psc[m], psh[m]) * keep;
+                Ps[m * PSTR + pj] = v;
             }
         }
         if (MODE == WG_GATHER) {
@@ -256,10 +265,10 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
             for (int i = 0; i < BC / RSTEP; ++i) {
                 const int c = prow + i * RSTEP;
-                float v = qreg[i];
-                if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, qsc[c], qsh[c]);
+                float v = qreg[i];       // no validity select: P is 0 wherever the pixel is out of range, and
+                if (PROQ != S2K_PRO_NONE) v = apply_pro_c<PROQ>(v, qsc[c], qsh[c]);   // channels past C feed discarded columns
                 if (p.gateq) v *= qgate[(MODE == WG_PIX) ? i : 0];
-                Qs[c * CSQ + pj] = (f_pok && c0 + c < p.C) ? v : 0.0f;
+                Qs[c * CSQ + pj] = v;
             }
         }
     };
@@ -378,7 +387,8 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
-    if (MODE == WG_SPATIAL) { p.PSTR = NPJ + 1; p.CSQ = NTHREADS * EPT + 1; }   // compile-time strides in the kernel
+    p.PSTR = NPJ + 1;                                                               // compile-time strides in the kernel
+    p.CSQ = (MODE == WG_SPATIAL) ? NTHREADS * EPT + 1 : (MODE == WG_GATHER ? 4 * NPJ + 1 : NPJ + 1);
     if ((int64_t)p.B * p.M * p.HWp * 4 >= 0x7ffffff0ll || (int64_t)p.B * p.C * p.HWq * 4 >= 0x7ffffff0ll) {
         set_error("wgrad: tensor larger than 2 GiB"); return S2K_EINVAL;
     }
