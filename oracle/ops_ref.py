@@ -443,6 +443,14 @@ def op_act_bwd(m: Mem, o):
     g.mul_(_act_grad(m.view(o["X"], (n,)), o["ACT"]))
 
 
+def op_act_fwd(m: Mem, o):
+    n = o["COUNT"]
+    x = m.view(o["X"], (n,))
+    act = o["ACT"]
+    y = F.gelu(x) if act == 4 else (F.silu(x) if act == 2 else (F.relu(x) if act == 3 else x))
+    m.view(o["Y"], (n,)).copy_(y)
+
+
 def _split_qkv(t, B, H, HD, L):   # [B][3*H*HD][L] -> q, k, v each [B,H,L,HD]
     t = t.view(B, 3, H, HD, L).permute(1, 0, 2, 4, 3)
     return t[0], t[1], t[2]
@@ -588,7 +596,7 @@ DISPATCH = {
     "SE_BWD_REDUCE": op_se_bwd_reduce, "BN_BWD_REDUCE": op_bn_bwd_reduce, "BN_BWD_FINALIZE": op_bn_bwd_finalize,
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
-    "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ATTN_FWD": op_attn_fwd,
+    "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
     "ATTN_BWD": op_attn_bwd, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
     "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate,

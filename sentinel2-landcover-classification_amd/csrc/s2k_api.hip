@@ -46,6 +46,7 @@ int launch_argmax(const S2kOp&, const Ctx&);
 int launch_chan_ln_fwd(const S2kOp&, const Ctx&);
 int launch_chan_ln_bwd(const S2kOp&, const Ctx&);
 int launch_act_bwd(const S2kOp&, const Ctx&);
+int launch_act_fwd(const S2kOp&, const Ctx&);
 int launch_attn_fwd(const S2kOp&, const Ctx&);
 int launch_attn_bwd(const S2kOp&, const Ctx&);
 int launch_mae_mask_index(const S2kOp&, const Ctx&);
@@ -73,7 +74,7 @@ static int launch_memset(const S2kOp& op, const Ctx& c) {
 static const char* const kNames[S2K_N_KINDS + 1] = {
     nullptr, "MEMSET", "AXPY", "WEIGHT_PACK", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
     "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
-    "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX",
+    "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ACT_FWD", "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX",
     "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "DROP_GATE"};
 
 static int dispatch(const S2kOp& op, const Ctx& c) {
@@ -103,6 +104,7 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_CHAN_LN_FWD: return launch_chan_ln_fwd(op, c);
         case S2K_OP_CHAN_LN_BWD: return launch_chan_ln_bwd(op, c);
         case S2K_OP_ACT_BWD: return launch_act_bwd(op, c);
+        case S2K_OP_ACT_FWD: return launch_act_fwd(op, c);
         case S2K_OP_ATTN_FWD: return launch_attn_fwd(op, c);
         case S2K_OP_ATTN_BWD: return launch_attn_bwd(op, c);
         case S2K_OP_MAE_MASK_INDEX: return launch_mae_mask_index(op, c);

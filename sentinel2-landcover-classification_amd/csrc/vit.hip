@@ -226,6 +226,23 @@ int launch_act_bwd(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
+// ---------------- Y = act(X) ------------------------------------------------------------------------------
+__global__ void act_fwd_kernel(const float* x, float* y, int64_t n, int act) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = apply_pro(x[i], act, 1.0f, 0.0f);
+}
+
+int launch_act_fwd(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_ACT_FWD_T_Y]);
+    CHECK_PTRS("act_fwd", x, y);
+    const int64_t n = op.n[S2K_ACT_FWD_N_COUNT];
+    const int act = op.d[S2K_ACT_FWD_D_ACT];
+    if (!x || !y || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU)) { set_error("act_fwd: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, x, y, n, act);
+    return S2K_OK;
+}
+
 // ---------------- Dropout2d keep gate --------------------------------------------------------------------
 __global__ void drop_gate_kernel(const float* u, float* gate, int64_t n, float prob) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -119,6 +119,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA"], [], ["B", "C", "HW", "ACCUM"], []),
     # G[i] *= act'(X[i])
     "ACT_BWD": (["G", "X"], ["COUNT"], ["ACT"], []),
+    # Y[i] = act(X[i])   (GELU of the MLP hidden layer, materialised once: the erf polynomial costs ~25 vector instructions
+    # per element, and a conv / wgrad prologue would re-evaluate it for every output-channel tile that reads the element)
+    "ACT_FWD": (["X", "Y"], ["COUNT"], ["ACT"], []),
     # multi-head attention on QKV [B][3*HEADS*HD][L] (rows q | k | v, each (head, d)):
     #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d]
     "ATTN_FWD": (["QKV", "O"], [], ["B", "HEADS", "HD", "L"], ["SCALE"]),

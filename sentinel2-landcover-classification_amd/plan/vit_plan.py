@@ -237,8 +237,12 @@ class _V:
         xm = self.linear_fwd(prefix + ".attn.proj.weight", prefix + ".attn.proj.bias", o, Dm, Dm, N, res=x)
         h2, mr2 = self.ln_fwd(prefix + ".norm2", xm, Dm, N, 1e-5)
         f1 = self.linear_fwd(prefix + ".mlp.fc1.weight", prefix + ".mlp.fc1.bias", h2, Dm, hidden, N)
-        xo = self.linear_fwd(prefix + ".mlp.fc2.weight", prefix + ".mlp.fc2.bias", f1, hidden, Dm, N, pro=D.PRO_GELU, res=xm)
-        return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, xm=xm, h2=h2, mr2=mr2, f1=f1, Dm=Dm, heads=heads,
+        # GELU is materialised once (ACT_FWD): as a conv / wgrad prologue its erf polynomial would be re-evaluated for every
+        # output-channel tile of fc2 and of fc2's weight gradient, and vector instructions are not free beside the f32 MFMA
+        a1 = p.alloc("gelu:" + prefix, (B, hidden, N))
+        p.fwd.add("ACT_FWD", X=f1, Y=a1, COUNT=B * hidden * N, ACT=D.ACT_GELU)
+        xo = self.linear_fwd(prefix + ".mlp.fc2.weight", prefix + ".mlp.fc2.bias", a1, hidden, Dm, N, res=xm)
+        return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, xm=xm, h2=h2, mr2=mr2, f1=f1, a1=a1, Dm=Dm, heads=heads,
                         hidden=hidden, N=N)
 
     def block_bwd(self, r: dict, g: TRef) -> None:
@@ -247,7 +251,7 @@ class _V:
         p, B = self.p, self.p.B
         pre, Dm, heads, hidden, N = r["prefix"], r["Dm"], r["heads"], r["hidden"], r["N"]
         g_f1 = p.alloc("g:f1:" + pre, (B, hidden, N))
-        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["f1"], g, hidden, Dm, N, pro=D.PRO_GELU, dx=g_f1)
+        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1)
         p.bwd.add("ACT_BWD", G=g_f1, X=r["f1"], COUNT=B * hidden * N, ACT=D.ACT_GELU)
         g_h = p.alloc("g:h:" + pre, (B, Dm, N))       # shared scratch for both LayerNorm output gradients
         self.linear_bwd(pre + ".mlp.fc1.weight", pre + ".mlp.fc1.bias", r["h2"], g_f1, Dm, hidden, N, dx=g_h)

@@ -49,6 +49,14 @@ def test_act_bwd(act):
     c.run("ACT_BWD", ["g"], tol=1e-5, G=g, X=x, COUNT=n, ACT=act)
 
 
+@pytest.mark.parametrize("act", [D.ACT_GELU, D.ACT_SILU, D.ACT_RELU])
+def test_act_fwd(act):
+    c = Case(3)
+    n = 10007
+    x, y = c.t("x", (n,), scale=2.0), c.t("y", (n,), "nan")
+    c.run("ACT_FWD", ["y"], tol=1e-5, X=x, Y=y, COUNT=n, ACT=act)
+
+
 def _ident_bnv(c, name, C):
     return c.t(name, (4, C), torch.cat([torch.ones(C), torch.zeros(C), torch.zeros(C), torch.ones(C)]))
 
