@@ -223,15 +223,21 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         } else if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
             const int kc0 = __builtin_amdgcn_readfirstlane(tid / BN);
+            // the pixel part (or "out of range") is the per-lane vector offset, the channel part a SCALAR offset (the channel
+            // of a pass is wave-uniform), clamped into the tensor: channels past Ctot meet zero rows of the packed weights
+            const uint32_t v1 = st_valid ? st_voff1 : BUF_OOB, v2 = st_valid ? st_voff2 : BUF_OOB;
+            const uint32_t vg = st_valid ? (uint32_t)st_gate * 4u : BUF_OOB;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int c = c0 + kc0 + i * KSTEP;
-                const bool ok = st_valid && c < p.Ctot;
-                uint32_t off;
-                if (gather) off = st_voff1 + (uint32_t)(c >> 2) * 16u * p.HW + ((c >> 1) & 1) * 8u * p.W + (c & 1) * 4u;
-                else off = (c < p.C1) ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
-                breg[i] = bload((gather || c < p.C1) ? rx1 : rx2, ok ? off : BUF_OOB);
-                greg[(BMODE == BM_PIX) ? i : 0] = bload(rgt, (ok && c < p.C1) ? (uint32_t)(st_gate + c) * 4u : BUF_OOB);
+                const int c = min(c0 + kc0 + i * KSTEP, p.Ctot - 1);
+                if (gather) {
+                    breg[i] = bload_s(rx1, v1, (uint32_t)(c >> 2) * 16u * p.HW + ((c >> 1) & 1) * 8u * p.W + (c & 1) * 4u);
+                } else if (c < p.C1) {
+                    breg[i] = bload_s(rx1, v1, (uint32_t)c * st_cs4);
+                } else {
+                    breg[i] = bload_s(rx2, v2, (uint32_t)(c - p.C1) * st_cs4);
+                }
+                greg[(BMODE == BM_PIX) ? i : 0] = bload_s(rgt, vg, (uint32_t)min(c, p.C1 - 1) * 4u);   // zero-sized descriptor without a gate
             }
         } else {
 #pragma unroll
@@ -292,10 +298,10 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                     const int kc = kc0 + i * KSTEP;
                     const int c = c0 + kc;
                     const int cc = c < p.Ctot ? c : p.Ctot - 1;
-                    float v = breg[i];
-                    if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, ssc[cc], ssh[cc]);
+                    float v = breg[i];       // no validity select: out-of-range pixels feed discarded output columns,
+                    if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, ssc[cc], ssh[cc]);   // channels past Ctot meet zero weight rows
                     if (p.gate1) v *= greg[(BMODE == BM_PIX) ? i : 0];
-                    Bs[kc * BN + j] = (st_valid && c < p.Ctot) ? v : 0.0f;
+                    Bs[kc * BN + j] = v;
                 }
             } else {
 #pragma unroll
