@@ -212,13 +212,14 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         // of a chunk's loads are in flight together
         if constexpr (BVEC) {
             const int kc0 = tid / LPR;
+            const uint32_t v1 = st_valid ? st_voff1 : BUF_OOB, v2 = st_valid ? st_voff2 : BUF_OOB;   // OOB + channel offset stays OOB
+            const uint32_t vg = st_valid ? (uint32_t)st_gate * 4u : BUF_OOB;
 #pragma unroll
             for (int i = 0; i < NBV; ++i) {
-                const int c = c0 + kc0 + i * KSTEPV;
-                const bool ok = st_valid && c < p.Ctot;
-                const uint32_t off = (c < p.C1) ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
-                bvec[i] = bload4(c < p.C1 ? rx1 : rx2, ok ? off : BUF_OOB);
-                gvec[i] = bload(rgt, (ok && c < p.C1) ? (uint32_t)(st_gate + c) * 4u : BUF_OOB);
+                const int c = min(c0 + kc0 + i * KSTEPV, p.Ctot - 1);   // channels past Ctot meet zero rows of the packed weights
+                const uint32_t off = (c < p.C1) ? v1 + (uint32_t)c * st_cs4 : v2 + (uint32_t)(c - p.C1) * st_cs4;
+                bvec[i] = bload4(c < p.C1 ? rx1 : rx2, off);
+                gvec[i] = bload(rgt, vg + (uint32_t)min(c, p.C1 - 1) * 4u);
             }
         } else if (BMODE == BM_PIX) {
             constexpr int KSTEP = (NTHREADS >= BN) ? NTHREADS / BN : 1;
@@ -275,17 +276,18 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 for (int i = 0; i < NBV; ++i) {
                     const int kc = kc0 + i * KSTEPV;
                     const int c = c0 + kc;
-                    const bool ok = st_valid && c < p.Ctot;
                     const int cc = c < p.Ctot ? c : p.Ctot - 1;
                     float sc = 1.0f, sh = 0.0f;
                     if (PRO != S2K_PRO_NONE) { sc = ssc[cc]; sh = ssh[cc]; }
-                    const float gm = p.gate1 ? gvec[i] : 1.0f;
-                    f32x4 v = bvec[i];
+                    f32x4 v = bvec[i];       // no validity select (see the scalar stager)
+                    if (PRO != S2K_PRO_NONE || p.gate1) {
+                        const float gm = p.gate1 ? gvec[i] : 1.0f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = v[e];
-                        if (PRO != S2K_PRO_NONE) t = apply_pro_c<PRO>(t, sc, sh);
-                        v[e] = ok ? t * gm : 0.0f;
+                        for (int e = 0; e < 4; ++e) {
+                            float t = v[e];
+                            if (PRO != S2K_PRO_NONE) t = apply_pro_c<PRO>(t, sc, sh);
+                            v[e] = t * gm;
+                        }
                     }
                     *reinterpret_cast<f32x4*>(Bs + kc * BN + 4 * j4) = v;
                 }
