@@ -243,15 +243,16 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         } else {
 #pragma unroll
             for (int kc = 0; kc < KCH; ++kc) {
-                const int c = c0 + kc;
-                const bool cok = c < p.Ctot;
+                // halo slot (or "outside the image") = per-lane vector offset; image + channel = SCALAR offset, the channel
+                // clamped into the tensor (channels past Ctot meet zero rows of the packed weights): no vector arithmetic
+                const int c = min(c0 + kc, p.Ctot - 1);
                 const bool first = c < p.C1;
-                const uint32_t cbase = first ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
-                const rsrc_t rr = first ? rx1 : rx2;
+                const uint32_t soff = first ? st_voff1 + (uint32_t)c * st_cs4 : st_voff2 + (uint32_t)(c - p.C1) * st_cs4;
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) {
                     const int g = sp_goff[(BMODE == BM_SPATIAL) ? i : 0];
-                    breg[kc * EPT + i] = bload(rr, (cok && g >= 0) ? cbase + (uint32_t)g * 4u : BUF_OOB);
+                    const uint32_t voff = g >= 0 ? (uint32_t)g * 4u : BUF_OOB;     // loop-invariant: hoisted out of the K loop
+                    breg[kc * EPT + i] = first ? bload_s(rx1, voff, soff) : bload_s(rx2, voff, soff);
                 }
             }
         }
@@ -316,9 +317,9 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
 #pragma unroll
                     for (int i = 0; i < EPT; ++i) {
                         const int e = tid + NTHREADS * i;
-                        float v = breg[kc * EPT + i];
-                        if (PRO != S2K_PRO_NONE) v = apply_pro_c<PRO>(v, sc, sh);
-                        v = (cok && sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0) ? v : 0.0f;
+                        float v = breg[kc * EPT + i];      // padding slots were loaded as 0; with a prologue they are zeroed
+                        if (PRO != S2K_PRO_NONE)           // again by a 0/1 factor (the reference pads ACTIVATED maps)
+                            v = apply_pro_c<PRO>(v, sc, sh) * (sp_goff[(BMODE == BM_SPATIAL) ? i : 0] >= 0 ? 1.0f : 0.0f);
                         if (e < used_sp) Bs[kc * CSB + e] = v;
                     }
                 }
