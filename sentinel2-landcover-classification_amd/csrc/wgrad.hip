@@ -45,7 +45,9 @@ __device__ __forceinline__ float ld_pro(const float* x, const float* bnv, const 
 // index arithmetic is left in the tile loop; the operands of tile i+1 are fetched into registers
 // before the MFMAs of tile i are issued and written to LDS after them (latency hidden under
 // 72..288 MFMAs per wave).
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ>
+// WSC: compile-time row stride of the Q halo tile (0 = run time).  With it the 9 tap offsets of the operand reads are
+// instruction immediates: the pair loop needs one address add instead of ten.
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ, int WSC = 0>
 __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     constexpr int BM = WM * WVM * 32;
     constexpr int BC = WN * WVN * 32;
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             for (int rm = 0; rm < WM; ++rm) a[rm] = Ps[(wm0 + rm * 32 + l31) * PSTR + n];
             int qbase;
             if (MODE == WG_SPATIAL) {
-                qbase = live ? (r_run * p.S) * p.WS + (2 * xp_run + lh) * p.S : 0;
+                qbase = live ? (r_run * p.S) * (WSC ? WSC : p.WS) + (2 * xp_run + lh) * p.S : 0;
                 xp_run += WVK;
                 while (xp_run >= half_xw) { xp_run -= half_xw; ++r_run; }
             } else {
@@ -307,7 +309,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 int toff;
-                if (MODE == WG_SPATIAL) toff = tdy * p.WS + tdx;
+                if (MODE == WG_SPATIAL) toff = WSC ? (t / 3) * WSC + (t % 3) : tdy * p.WS + tdx;   // T == 9: 3x3 taps
                 else if (MODE == WG_GATHER) toff = t * NPJ;
                 else toff = 0;
 #pragma unroll
@@ -382,7 +384,7 @@ static T* ref_ptr(const Ctx& c, int64_t ref) {
     return reinterpret_cast<T*>(static_cast<char*>(c.bases[base]) + off);
 }
 
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ>
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int PROP, int PROQ, int WSC = 0>
 static int launch_wg2(WgradP& p, hipStream_t st) {
     constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     p.n_mtiles = cdiv(p.M, BM);
@@ -395,7 +397,7 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ + 2 * (BM + BC)) * sizeof(float);
     if (p.gatep || (p.gateq && MODE != WG_PIX)) { set_error("wgrad: SE gate is only supported on the Q operand of 1x1 convs"); return S2K_EINVAL; }
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
-    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, PROP, PROQ>;
+    auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, PROP, PROQ, WSC>;
     if (MODE == WG_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("wgrad: halo exceeds EPT"); return S2K_EINVAL; }
     if (MODE == WG_SPATIAL && p.R * p.XWe > NPJ) { set_error("wgrad: tile exceeds pixel slots"); return S2K_EINVAL; }
     static bool attr_done = false;
@@ -427,9 +429,13 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
 
 // the prologue kinds are compile-time in the kernel (no per-element branches in the LDS commit); only the
 // combinations the planners emit are instantiated
-template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT>
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int EPT, int WSC = 0>
 static int launch_wg(WgradP& p, hipStream_t st) {
     const int pp = p.prop, pq = p.proq;
+    if constexpr (WSC != 0) {
+        if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_NONE, WSC>(p, st);
+        if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_RELU, WSC>(p, st);
+    }
     if constexpr (MODE == WG_GATHER) {
         if (pq == S2K_PRO_NONE && pp == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
         if (pq == S2K_PRO_NONE && pp == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_SILU, S2K_PRO_NONE>(p, st);
@@ -527,6 +533,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     if (thin && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4, 128, 2>(p, st);
     if (thin) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2, 128, 2>(p, st);
     if (wide) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 128, 2>(p, st);
+    if (p.IR * p.WS <= NTHREADS && p.WS == 66 && p.KW == 3) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1, 66>(p, st);   // 64-wide tiles
     if (p.IR * p.WS <= NTHREADS) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1>(p, st);
     return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 2>(p, st);
 }
