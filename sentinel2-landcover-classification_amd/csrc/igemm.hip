@@ -21,6 +21,8 @@
 // m-tiles sharing one activation tile run on the same XCD (shared L2).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace s2k {
@@ -97,6 +99,8 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     int64_t st_off1 = 0, st_off2 = 0, st_cstride = 0;
     int st_gate = 0;
     bool st_valid = false;
+    int img_b = 0;                                                  // image the activation descriptors are based at
+    const bool img_local = (BMODE == BM_PIX) && (p.HW % BN) == 0;
 
     if (BMODE == BM_PIX) {
         const int n0 = nt * BN;
@@ -121,12 +125,16 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         const int nn = st_valid ? n : 0;
         const int b = nn / p.HW, pp = nn - b * p.HW;
         st_gate = b * p.C1;
+        // tile inside one image (H*W % BN == 0): the descriptors below are based at that image, offsets stay image-local
+        // (tensors of more than 2 GiB — a 16 x 768 x 224 x 224 gradient — are then addressable with 32-bit offsets)
+        if (img_local) img_b = n0 / p.HW;
+        const int brel = b - img_b;
         if (gather) {  // X1 is [B][C1/4][2H][2W]; pseudo-channel k=(co,dy,dx)
             const int yy = pp / p.W, xx = pp - yy * p.W;
-            st_off1 = (int64_t)b * (p.C1 / 4) * 4 * p.HW + (int64_t)(2 * yy) * (2 * p.W) + 2 * xx;
+            st_off1 = (int64_t)brel * (p.C1 / 4) * 4 * p.HW + (int64_t)(2 * yy) * (2 * p.W) + 2 * xx;
         } else {
-            st_off1 = (int64_t)b * p.C1 * p.HW + pp;
-            st_off2 = (int64_t)b * p.C2 * p.HW + pp;
+            st_off1 = (int64_t)brel * p.C1 * p.HW + pp;
+            st_off2 = (int64_t)brel * p.C2 * p.HW + pp;
         }
         st_cstride = p.HW;
     } else {
@@ -155,16 +163,19 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
             }
             sp_goff[(BMODE == BM_SPATIAL) ? i : 0] = g;
         }
-        st_off1 = (int64_t)sb * p.C1 * p.H * p.W;
-        st_off2 = (int64_t)sb * p.C2 * p.H * p.W;
+        img_b = sb;              // a 3x3 tile always lies in one image: image-local descriptors
+        st_off1 = 0;
+        st_off2 = 0;
         st_cstride = (int64_t)p.H * p.W;
         st_gate = sb * p.C1;
     }
 
-    // bounds-checked descriptors of the activation sources (+ the SE gate; zero-sized when absent)
-    const int64_t x1_elems = gather ? (int64_t)p.B * (p.C1 / 4) * 4 * p.HW : (int64_t)p.B * p.C1 * p.H * p.W;
-    const rsrc_t rx1 = make_rsrc(p.x1, x1_elems * 4);
-    const rsrc_t rx2 = make_rsrc(p.x2 ? p.x2 : p.x1, p.x2 ? (int64_t)p.B * p.C2 * p.H * p.W * 4 : 0);
+    // bounds-checked descriptors of the activation sources (+ the SE gate; zero-sized when absent), based at image
+    // img_b and covering the rest of the tensor from there (clamped to 2 GiB: image-local tiles never reach that far)
+    const int64_t x1_img = gather ? (int64_t)(p.C1 / 4) * 4 * p.HW : (int64_t)p.C1 * p.H * p.W;   // elements per image
+    const int64_t x2_img = (int64_t)p.C2 * p.H * p.W;
+    const rsrc_t rx1 = make_rsrc(p.x1 + img_b * x1_img, (p.B - img_b) * x1_img * 4);
+    const rsrc_t rx2 = make_rsrc(p.x2 ? p.x2 + img_b * x2_img : p.x1, p.x2 ? (p.B - img_b) * x2_img * 4 : 0);
     const rsrc_t rgt = make_rsrc(p.gate1 ? p.gate1 : p.x1, p.gate1 ? (int64_t)p.B * p.C1 * 4 : 0);
     const uint32_t st_voff1 = (uint32_t)st_off1 * 4u, st_voff2 = (uint32_t)st_off2 * 4u, st_cs4 = (uint32_t)st_cstride * 4u;
 
@@ -600,6 +611,12 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
         attr_done = true;
     }
     if (lds > 160 * 1024) { set_error("conv: LDS %zu too large", lds); return S2K_EINVAL; }
+    {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
+        const bool local = BMODE == BM_SPATIAL || (p.HW % BN) == 0;
+        const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
+        const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
+        if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
+    }
     if (BMODE == BM_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("conv: halo tile exceeds EPT"); return S2K_EINVAL; }
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }

@@ -113,8 +113,11 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 
     // Operand loads are unconditional bounds-checked buffer loads (validity is a select afterwards): one
     // affine 32-bit offset stream per operand, no branch around any load
-    const rsrc_t rp = make_rsrc(p.p, (int64_t)p.B * p.M * p.HWp * 4);
-    const rsrc_t rq = make_rsrc(p.q, (int64_t)p.B * p.C * p.HWq * 4);
+    // Descriptors are based at the image of the fetched tile whenever a pixel tile cannot straddle two images (always for
+    // the 3x3 tiles; H*W % NPJ == 0 otherwise), so offsets stay image-local and tensors above 2 GiB are addressable.
+    const bool img_local = (MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0;
+    rsrc_t rp = make_rsrc(p.p, (int64_t)p.B * p.M * p.HWp * 4);
+    rsrc_t rq = make_rsrc(p.q, (int64_t)p.B * p.C * p.HWq * 4);
     const rsrc_t rg = make_rsrc(p.gateq ? p.gateq : p.q, p.gateq ? (int64_t)p.B * p.C * 4 : 0);
     const uint32_t p_rstride = (uint32_t)RSTEP * p.HWp * 4u, q_rstride = (uint32_t)RSTEP * p.HWq * 4u;
     float preg[NPR], qreg[NQR];
@@ -144,6 +147,8 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int y0 = ty * p.R, x0 = tx * p.XW;
             const int yo = y0 + pr, xo = x0 + pxx;
             f_b = b;
+            rp = make_rsrc(p.p + (int64_t)b * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
+            rq = make_rsrc(p.q + (int64_t)b * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
             f_pok = pj < np_sp && pxx < p.XW && yo < p.HO && xo < p.WO;
             // per-lane part (pixel, or out of range) in the vector offset, per-row part in the SCALAR offset: no vector
             // arithmetic per load.  Rows / channels past the tensor are clamped (their products land in discarded outputs).
@@ -152,7 +157,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
                 const int row = min(m0 + prow_u + i * RSTEP, p.M - 1);
-                preg[i] = bload_s(rp, pvoff, (uint32_t)((b * p.M + row) * p.HWp) * 4u);
+                preg[i] = bload_s(rp, pvoff, (uint32_t)(row * p.HWp) * 4u);
             }
             const int iy0 = y0 * p.S - p.PT, ix0 = x0 * p.S - p.PL;
             uint32_t goff[EPT];
@@ -166,7 +171,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             }
 #pragma unroll
             for (int c = 0; c < BC; ++c) {
-                const uint32_t soff = (uint32_t)((b * p.C + min(c0 + c, p.C - 1)) * p.HWq) * 4u;
+                const uint32_t soff = (uint32_t)(min(c0 + c, p.C - 1) * p.HWq) * 4u;
 #pragma unroll
                 for (int i = 0; i < EPT; ++i) qreg[c * EPT + i] = bload_s(rq, goff[i], soff);
             }
@@ -178,10 +183,17 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int b = (int)(nn / p.HWp);
             const int pp = (int)(nn - (int64_t)b * p.HWp);
             f_b = b;
+            int brel = b;
+            if (img_local) {
+                const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);      // image of this pixel tile (uniform)
+                rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
+                rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
+                brel = b - bt;
+            }
             // per-lane part (image, pixel; or out of range) in the vector offset, the row / channel part in the scalar
             // offset (clamped into the tensor: rows and channels past the end only feed discarded outputs)
             const int prow_u = __builtin_amdgcn_readfirstlane(prow);
-            const uint32_t pvoff = f_pok ? (uint32_t)((int64_t)b * p.M * p.HWp + pp) * 4u : BUF_OOB;
+            const uint32_t pvoff = f_pok ? (uint32_t)((int64_t)brel * p.M * p.HWp + pp) * 4u : BUF_OOB;
 #pragma unroll
             for (int i = 0; i < NPR; ++i) {
                 if constexpr (NPJ >= 64) {   // one P row per wave and pass: the row offset is scalar
@@ -192,7 +204,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 }
             }
             if (MODE == WG_PIX) {
-                const uint32_t qvoff = f_pok ? (uint32_t)((int64_t)b * p.C * p.HWq + pp) * 4u : BUF_OOB;
+                const uint32_t qvoff = f_pok ? (uint32_t)((int64_t)brel * p.C * p.HWq + pp) * 4u : BUF_OOB;
                 const uint32_t gvoff = f_pok ? (uint32_t)(b * p.C) * 4u : BUF_OOB;
 #pragma unroll
                 for (int i = 0; i < BC / RSTEP; ++i) {
@@ -202,7 +214,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
                 }
             } else {  // GATHER: Q is [B][C][2HO][2WO]
                 const int yy = pp / p.WO, xx = pp - yy * p.WO;
-                const uint32_t qbase = (uint32_t)(((int64_t)b * p.C + c0 + prow) * p.HWq + (int64_t)(2 * yy) * p.W + 2 * xx) * 4u;
+                const uint32_t qbase = (uint32_t)(((int64_t)brel * p.C + c0 + prow) * p.HWq + (int64_t)(2 * yy) * p.W + 2 * xx) * 4u;
 #pragma unroll
                 for (int i = 0; i < BC / RSTEP; ++i) {
                     const bool ok = f_pok && c0 + prow + i * RSTEP < p.C;
@@ -391,8 +403,10 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     p.n_ctiles = cdiv(p.C, BC);
     p.PSTR = NPJ + 1;                                                               // compile-time strides in the kernel
     p.CSQ = (MODE == WG_SPATIAL) ? NTHREADS * EPT + 1 : (MODE == WG_GATHER ? 4 * NPJ + 1 : NPJ + 1);
-    if ((int64_t)p.B * p.M * p.HWp * 4 >= 0x7ffffff0ll || (int64_t)p.B * p.C * p.HWq * 4 >= 0x7ffffff0ll) {
-        set_error("wgrad: tensor larger than 2 GiB"); return S2K_EINVAL;
+    {   // 32-bit buffer offsets: one image must stay below 2 GiB when tiles are image-local, else the whole tensor
+        const bool local = (MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0;
+        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
+        if (need >= 0x7ffffff0ll) { set_error("wgrad: activation %s larger than 2 GiB", local ? "image" : "tensor"); return S2K_EINVAL; }
     }
     const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ + 2 * (BM + BC)) * sizeof(float);
     if (p.gatep || (p.gateq && MODE != WG_PIX)) { set_error("wgrad: SE gate is only supported on the Q operand of 1x1 convs"); return S2K_EINVAL; }

@@ -486,3 +486,60 @@ def test_conv_1x1_split_k(B, C, M, H, stats, beta, bias):
           BNV2=None, WT=wp, BIAS=bs, Y=y, STATS=st, RES=None, SCRATCH=scratch, B=B, C1=C, C2=0, H=H, W=H, M=M, KH=1, KW=1, STRIDE=1,
           PAD_T=0, PAD_L=0, HO=H, WO=H, PRO1=D.PRO_SILU, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=beta, YC=M,
           NREP=nrep)
+
+
+# ---------------------------------------------------------------------------------------------------
+# tensors above 2 GiB (the Prithvi head at bs 16 reads a 16 x 768 x 224 x 224 map): buffer offsets are 32-bit, so the
+# kernels base their descriptors at the image of each tile; everything past the 2 GiB mark must still be read
+# ---------------------------------------------------------------------------------------------------
+def _big(B=14, C=768, H=224):
+    assert B * C * H * H * 4 > 2 ** 31
+    return B, C, H
+
+
+def test_conv3x3_reads_past_2gib():
+    B, C, H = _big()
+    M = 8
+    c = Case(31)
+    x = c.t("x", (B, C, H, H), scale=0.5)
+    w = c.t("w", (M, C, 9), scale=(C * 9) ** -0.5)
+    y = c.t("y", (B, M, H, H), "nan")
+    pre, wp, MP = c.pack(w, M, C, 9, C * 9, 9, 1, 0)
+    c.run("CONV", ["y"], tol=1e-4, pre=[pre], X1=x, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=y, STATS=None, RES=None,
+          B=B, C1=C, C2=0, H=H, W=H, M=M, KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=H, PRO1=0, PRO2=0, MODE=D.MODE_CONV,
+          W_SM=1, W_SK=9 * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=1)
+
+
+def test_convt_dgrad_gather_reads_past_2gib():
+    B, Cout, H2 = _big()          # G = [B, Cout, 2H, 2W] with 2H = 224
+    H, Cin = H2 // 2, 8
+    c = Case(32)
+    g = c.t("g", (B, Cout, H2, H2), scale=0.5)
+    w = c.t("w", (Cin, 4 * Cout), scale=(4 * Cout) ** -0.5)
+    dx = c.t("dx", (B, Cin, H, H), "nan")
+    pre, wp, MP = c.pack(w, Cin, 4 * Cout, 1, 4 * Cout, 1, 1, 0)
+    c.run("CONV", ["dx"], tol=1e-4, pre=[pre], X1=g, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=dx, STATS=None, RES=None,
+          B=B, C1=4 * Cout, C2=0, H=H, W=H, M=Cin, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=H, PRO1=0, PRO2=0,
+          MODE=D.MODE_GATHER2X2, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=Cin, NREP=1)
+
+
+def test_wgrad3x3_reads_past_2gib():
+    B, C, H = _big()
+    M = 8
+    c = Case(33)
+    dy = c.t("dy", (B, M, H, H), scale=0.1)
+    x = c.t("x", (B, C, H, H), scale=0.5)
+    wgs = c.t("wgs", (9, M, C), "zeros")
+    c.run("WGRAD", ["wgs"], tol=2e-4, P=dy, BNVP=None, GATEP=None, Q=x, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=H,
+          KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_CONV)
+
+
+def test_convt_wgrad_gather_reads_past_2gib():
+    B, Cout, H2 = _big()
+    H, Cin = H2 // 2, 8
+    c = Case(34)
+    xs = c.t("x", (B, Cin, H, H), scale=0.5)
+    g = c.t("g", (B, Cout, H2, H2), scale=0.1)
+    wgs = c.t("wgs", (4, Cin, Cout), "zeros")
+    c.run("WGRAD", ["wgs"], tol=2e-4, P=xs, BNVP=None, GATEP=None, Q=g, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=Cin, C=Cout, CTOT=Cout,
+          H=H2, W=H2, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_GATHER2X2)
