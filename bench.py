@@ -133,7 +133,8 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; a rehearsal of the N-rank code path on a single-GPU box maps every rank onto device 0
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
 
     import s2lc_amd  # noqa: F401
@@ -148,7 +149,11 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("S2K_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     ncls = 4
     torch.manual_seed(42)  # identical initial weights on every rank (configs/segmentation.py:103 seed)
