@@ -108,24 +108,43 @@ int launch_wgrad_finalize(const S2kOp& op, const Ctx& c) {
 }
 
 // ---------------- WEIGHT_PACK ----------------------------------------------------------------------
-// table rows: {src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP, start}; one thread per packed element
-__global__ void weight_pack_kernel(const int* table, int n_entries, const float* src, float* dst, int64_t total) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        int lo = 0, hi = n_entries - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((int64_t)table[mid * 12 + 11] <= e) lo = mid; else hi = mid - 1;
-        }
-        const int* r = table + lo * 12;
-        const int M = r[2], K = r[3], T = r[4], MP = r[9];
-        const int local = (int)(e - r[11]);
-        const int kk = local / MP, m = local - kk * MP;
-        const int kc = kk / T, tap = kk - kc * T;
-        float v = 0.0f;
-        if (m < M && kc < K) v = src[(int64_t)r[0] + (int64_t)m * r[5] + (int64_t)kc * r[6] + (r[8] ? T - 1 - tap : tap) * r[7]];
-        dst[(int64_t)r[1] + local] = v;
+// table rows: {src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP, start}.  One workgroup = one 64 (k,tap) x 64 (m)
+// tile of one entry (MP % 128 == 0, KP % 64 == 0, so tiles never straddle entries and `start` is a multiple of 4096).
+// Forward packs read rows of [M][K*T] weights (contiguous along (k,tap)) and write [K*T][MP] (contiguous along m): the
+// transpose goes through LDS so that both sides are 256-byte wave rows; other stride patterns read with lanes along m.
+__global__ void __launch_bounds__(NTHREADS) weight_pack_kernel(const int* table, int n_entries, const float* src, float* dst, int64_t total) {
+    __shared__ float tile[64][65];
+    const int64_t e0 = (int64_t)blockIdx.x * 4096;
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)table[mid * 12 + 11] <= e0) lo = mid; else hi = mid - 1;
     }
+    const int* r = table + lo * 12;
+    const int M = r[2], K = r[3], T = r[4], s_m = r[5], s_k = r[6], s_t = r[7], flip = r[8], MP = r[9];
+    const int u = (int)((e0 - r[11]) >> 12);
+    const int mbs = MP >> 6;
+    const int kk0 = (u / mbs) * 64, m0 = (u % mbs) * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* sp = src + r[0];
+    const bool kfast = (s_t == 1 && s_k == T && !flip);      // (k,tap) contiguous in the source
+    if (kfast) {
+        const int kk = kk0 + lane;
+        for (int mi = wave; mi < 64; mi += 4) {
+            const int m = m0 + mi;
+            tile[lane][mi] = (m < M && kk < K * T) ? sp[(int64_t)m * s_m + kk] : 0.0f;
+        }
+    } else {
+        const int m = m0 + lane;
+        for (int ki = wave; ki < 64; ki += 4) {
+            const int kk = kk0 + ki;
+            const int kc = kk / T, tap = kk - kc * T;
+            tile[ki][lane] = (m < M && kc < K) ? sp[(int64_t)m * s_m + (int64_t)kc * s_k + (flip ? T - 1 - tap : tap) * s_t] : 0.0f;
+        }
+    }
+    __syncthreads();
+    float* dp = dst + r[1];
+    for (int ki = wave; ki < 64; ki += 4) dp[(int64_t)(kk0 + ki) * MP + m0 + lane] = tile[ki][lane];
 }
 
 int launch_weight_pack(const S2kOp& op, const Ctx& c) {
@@ -135,9 +154,10 @@ int launch_weight_pack(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("weight_pack", table, src, dst);
     const int64_t total = op.n[S2K_WEIGHT_PACK_N_TOTAL];
     const int n = op.d[S2K_WEIGHT_PACK_D_N_ENTRIES];
-    if (!table || !src || !dst || n <= 0 || total <= 0 || total > 0x7fffffff) { set_error("weight_pack: bad args"); return S2K_EINVAL; }
-    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 8192);
-    hipLaunchKernelGGL(weight_pack_kernel, dim3(blocks), dim3(256), 0, c.stream, table, n, src, dst, total);
+    if (!table || !src || !dst || n <= 0 || total <= 0 || (total & 4095) || (total >> 12) > 0x7fffffff) {
+        set_error("weight_pack: bad args (total must be a multiple of 4096: MP % 128 == 0, KP % 64 == 0)"); return S2K_EINVAL;
+    }
+    hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)(total >> 12)), dim3(NTHREADS), 0, c.stream, table, n, src, dst, total);
     return S2K_OK;
 }
 
