@@ -299,11 +299,41 @@ int launch_se_bwd_reduce(const S2kOp& op, const Ctx& c) {
                                   op.d[S2K_SE_BWD_REDUCE_D_HW], pro, c.stream);
 }
 
+// short planes (token axes of the ViT: 50 .. 197 elements): one wave owns a channel, walks the batch with 4 independent
+// partial sums and adds ONCE, without atomics (a wave per (b, c) plane would be one load and one atomic each)
+__global__ void __launch_bounds__(NTHREADS) channel_sum_rows_kernel(const float* g, float* out, int B, int C, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {
+        const float* r0 = g + ((int64_t)b * C + c) * HW;
+        for (int i = lane; i < HW; i += 64) {
+            s0 += r0[i];
+            s1 += r0[(int64_t)C * HW + i];
+            s2 += r0[2 * (int64_t)C * HW + i];
+            s3 += r0[3 * (int64_t)C * HW + i];
+        }
+    }
+    for (; b < B; ++b) {
+        const float* r0 = g + ((int64_t)b * C + c) * HW;
+        for (int i = lane; i < HW; i += 64) s0 += r0[i];
+    }
+    const float s = wave_sum_hi((s0 + s1) + (s2 + s3));
+    if (lane == 63) out[c] += s;
+}
+
 int launch_channel_sum(const S2kOp& op, const Ctx& c) {
     const float* g = ref_ptr<const float>(c, op.t[S2K_CHANNEL_SUM_T_G]);
     float* out = ref_ptr<float>(c, op.t[S2K_CHANNEL_SUM_T_OUT]);
     CHECK_PTRS("channel_sum", g, out);
     if (!g || !out) { set_error("channel_sum: bad args"); return S2K_EINVAL; }
+    const int B = op.d[S2K_CHANNEL_SUM_D_B], C = op.d[S2K_CHANNEL_SUM_D_C], HW = op.d[S2K_CHANNEL_SUM_D_HW];
+    if (B > 0 && C >= 256 && HW > 0 && HW <= 512) {
+        hipLaunchKernelGGL(channel_sum_rows_kernel, dim3(cdiv(C, 4)), dim3(NTHREADS), 0, c.stream, g, out, B, C, HW);
+        return S2K_OK;
+    }
     return launch_plane_reduce<2>(g, nullptr, nullptr, out, op.d[S2K_CHANNEL_SUM_D_B], op.d[S2K_CHANNEL_SUM_D_C],
                                   op.d[S2K_CHANNEL_SUM_D_HW], 0, c.stream);
 }

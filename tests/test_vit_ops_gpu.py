@@ -210,3 +210,12 @@ def test_drop_gate():
     u = c.t("u", (n,), "rand")
     gate = c.t("gate", (n,), "nan")
     c.run("DROP_GATE", ["gate"], tol=1e-7, U=u, GATE=gate, COUNT=n, P=0.1)
+
+
+@pytest.mark.parametrize("B,C,HW", [(64, 768, 50), (7, 2304, 197), (3, 256, 512), (5, 300, 1)])
+def test_channel_sum_token_rows(B, C, HW):
+    """Bias gradients of the ViT Linears: short planes take the one-wave-per-channel path (no atomics)."""
+    c = Case(16)
+    g = c.t("g", (B, C, HW))
+    out = c.t("out", (C,), "randn")
+    c.run("CHANNEL_SUM", ["out"], 1e-4, G=g, OUT=out, B=B, C=C, HW=HW)
