@@ -625,9 +625,16 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     p.splits = 1;
     p.chunks_per_split = nchunks;
     p.y_elems = (int64_t)p.B * p.YC * p.HO * p.WO;
-    if (allow_splitk && p.scratch && p.mode == S2K_MODE_CONV && blocks <= 512 && nchunks >= 4) {
-        // too few tiles to fill 256 CUs and a long reduction: cut K so that ~4 workgroups per CU hide each other's latency
-        int splits = (int)cdiv64(1024, blocks);
+    static const int force_splits = [] { const char* e = getenv("S2K_SPLITS"); return e ? atoi(e) : 0; }();
+    if (force_splits > 1 && allow_splitk && p.scratch && p.mode == S2K_MODE_CONV && nchunks >= 2 * force_splits) {
+        p.chunks_per_split = cdiv(nchunks, force_splits);
+        p.splits = cdiv(nchunks, p.chunks_per_split);
+    } else if (force_splits == 0 && allow_splitk && p.scratch && p.mode == S2K_MODE_CONV && nchunks >= 4) {
+        // too few tiles to fill 256 CUs and a long reduction: cut K so that several workgroups per CU hide each other's
+        // latency (measured on 64x64 tiles: 160..512 tiles want ~1024 workgroups, 600 tiles x 48 chunks want x3..4)
+        int splits = 1;
+        if (blocks <= 512) splits = (int)cdiv64(1024, blocks);
+        else if (blocks <= 1024 && nchunks >= 32) splits = (int)cdiv64(1536, blocks);
         if (splits > 8) splits = 8;
         if (splits > nchunks / 2) splits = nchunks / 2;
         if (splits > 1) {
@@ -733,6 +740,9 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
 #define PIX_CFG(WMv, WNv, WVMv, WVNv, KCHv, ntl, sk) \
     (bvec ? launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, true>(p, ntl, st, sk) \
           : launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, false>(p, ntl, st, sk))
+        static const int force_cfg = [] { const char* e = getenv("S2K_PIX_FORCE"); return e ? atoi(e) : 0; }();
+        if (force_cfg == 1) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
+        if (force_cfg == 2) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), true);
         if (bm >= 64 && tiles_big < small_max) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
         if (bm == 128 && p.Ctot <= k16_max) return PIX_CFG(2, 2, 2, 2, 16, cdiv(p.Ntot, 128), false);   // short-K expand convs
         if (bm == 128) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), false);

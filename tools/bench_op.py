@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--nostats", action="store_true")
+    ap.add_argument("--scratch", action="store_true")
+    ap.add_argument("--N", type=int, default=0, help="conv1: tokens per image (H=1, W=N) instead of an HxH map")
     a = ap.parse_args()
     B, M, C, H = a.B, a.M, a.C, a.H
     ar = Arena(D.BASE["WS"])
@@ -63,13 +65,18 @@ def main():
                  H=H, W=H, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PROP=0, PROQ=a.pro, MODE=0)
         flops = 2.0 * M * C * T * B * H * H
     else:
-        X = ar.alloc("x", (B, C, H, H)); bnv = ar.alloc("bnv", (4, C)); Y = ar.alloc("y", (B, M, H, H))
+        Wd = H
+        if a.N:
+            H, Wd = 1, a.N
+        X = ar.alloc("x", (B, C, H, Wd)); bnv = ar.alloc("bnv", (4, C)); Y = ar.alloc("y", (B, M, H, Wd))
+        scr = ar.alloc("scr", (8 * B * M * H * Wd,)) if a.scratch else None
         MP, KP = (M + 127) // 128 * 128, (C + 63) // 64 * 64
         W = ar.alloc("w", (KP * T, MP)); st = ar.alloc("st", (D.stats_replicas(M), 2, M), "f64")
-        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st, B=B, C1=C,
-                 C2=0, H=H, W=H, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PRO1=a.pro, PRO2=0, MODE=0,
+        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st,
+                 SCRATCH=scr, B=B, C1=C,
+                 C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
-        flops = 2.0 * M * C * T * B * H * H
+        flops = 2.0 * M * C * T * B * H * (Wd if not a.what.startswith('wgrad') else H)
     buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * 0.5).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)
     packed = prog.pack()

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--unfrozen", action="store_true")
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--ops", action="store_true", help="with --profile: per-shape table of the MFMA stages")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(42)
@@ -88,6 +89,30 @@ def main():
             for k, (ms, cnt) in _lib.profile(prog, bases, st).items():
                 kinds[k] = kinds.get(k, 0.0) + ms
         res["kernels_ms"] = {k: round(v, 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
+        if a.ops:
+            import collections
+            from s2lc_amd.plan import opdefs as D
+            names = {v: k for k, v in D.KIND.items()}
+            agg = collections.OrderedDict()
+            for tag, prog in (("fwd", eng.fwd), ("bwd", eng.bwd)):
+                ms = _lib.profile_ops(prog, bases, st)
+                for rec, t in zip(prog, ms):
+                    kind = names[int(rec["kind"])]
+                    if kind not in ("CONV", "WGRAD"):
+                        continue
+                    d = rec["d"]
+                    g = lambda f: int(d[D.slot(kind, f)[1]])  # noqa: E731
+                    if kind == "CONV":
+                        key = (tag, kind, g("M"), g("C1") + g("C2"), g("KH"), g("B") * g("HO") * g("WO"), g("MODE"))
+                        fl = 2.0 * g("M") * (g("C1") + g("C2")) * g("KH") * g("KW") * g("B") * g("HO") * g("WO")
+                    else:
+                        key = (tag, kind, g("M"), g("C"), g("KH"), g("B") * g("HO") * g("WO"), g("MODE"))
+                        fl = 2.0 * g("M") * g("C") * g("KH") * g("KW") * g("B") * g("HO") * g("WO")
+                    e = agg.setdefault(key, [0, 0.0, 0.0])
+                    e[0] += 1; e[1] += float(t); e[2] += fl
+            print("per-shape MFMA stages (sequential, no side stream):", file=sys.stderr)
+            for key, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+                print("  %s %-5s M=%5d C=%5d k%d N=%7d mode%d  x%-3d %7.3f ms  %6.1f TF/s" % (*key, n, t, fl / t / 1e9), file=sys.stderr)
     print(json.dumps(res))
 
 
