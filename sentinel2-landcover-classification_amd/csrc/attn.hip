@@ -30,6 +30,7 @@ struct AttnP {
     float *o, *dqkv;
     int B, H, HD, L;
     int Lp, LS, hdp, hd2, ntq, mtiles;   // keys padded to 32, LDS row stride (odd), head dim padded to 32 / to even
+    int red_ok;                          // backward: LDS has room for the dQ partial tiles
     float scale;
 };
 
@@ -252,6 +253,24 @@ __global__ void __launch_bounds__(NTHREADS, 1) attn_bwd_kernel(const AttnP p) {
             f32x16 acc;
             zero16(acc);
             mfma_loop(acc, Ks + (32 * mt + l31) * p.LS + part * klen, 1, Ss + l31 * p.LS + part * klen, 1, klen, lh);
+            if (p.red_ok) {   // LDS has room for the partial tiles: one barrier, fixed-order sum, coalesced store
+                float* red = dpart + 128;                       // [parts][hdp][32]
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    red[(part * p.hdp + d) * 32 + l31] = acc[r];
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < p.hdp * 32; e += NTHREADS) {
+                    const int d = e >> 5, i = e & 31;
+                    if (d < p.HD && i0 + i < p.L) {
+                        float sum = 0.0f;
+                        for (int pp = 0; pp < parts; ++pp) sum += red[(pp * p.hdp + d) * 32 + i];
+                        dq[(int64_t)d * p.L + i0 + i] = sum;
+                    }
+                }
+                __syncthreads();
+            } else
             for (int pp = 0; pp < parts; ++pp) {
                 if (part == pp) {
 #pragma unroll
@@ -332,8 +351,10 @@ int launch_attn_bwd(const S2kOp& op, const Ctx& c) {
     if (p.mtiles * (p.Lp / 32) > 4 * MAX_TPW || p.Lp / 32 > 8) {
         set_error("attn_bwd: %d tokens x head dim %d exceeds the register-resident dK/dV tiles", p.L, p.HD); return S2K_EINVAL;
     }
-    const size_t lds = (2 * (size_t)p.hdp * p.LS + 2 * (size_t)p.hdp * QS + 32 * (size_t)p.LS + 128) * sizeof(float);
+    size_t lds = (2 * (size_t)p.hdp * p.LS + 2 * (size_t)p.hdp * QS + 32 * (size_t)p.LS + 128) * sizeof(float);
     if (lds > 160 * 1024) { set_error("attn_bwd: %d tokens x head dim %d needs %zu B of LDS (max 160 KB)", p.L, p.HD, lds); return S2K_EINVAL; }
+    p.red_ok = lds + 128 * 32 * sizeof(float) <= 160 * 1024;
+    if (p.red_ok) lds += 128 * 32 * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
