@@ -583,6 +583,15 @@ def op_transpose_cl(m: Mem, o):
     m.view(o["Y"], (B, Lout, C)).copy_(x[:, :, LO:LO + Lout].permute(0, 2, 1))
 
 
+def op_confusion(m: Mem, o):
+    n, C = o["COUNT"], o["C"]
+    pred = m.view(o["PRED"], (n,), "i64")
+    lab = m.view(o["LABELS"], (n,), "i64")
+    ok = (pred >= 0) & (pred < C) & (lab >= 0) & (lab < C)
+    idx = lab[ok] * C + pred[ok]
+    m.view(o["HIST"], (C * C,), "i64").add_(torch.bincount(idx, minlength=C * C))
+
+
 def op_drop_gate(m: Mem, o):
     n = o["COUNT"]
     u = m.view(o["U"], (n,))
@@ -599,7 +608,7 @@ DISPATCH = {
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
     "ATTN_BWD": op_attn_bwd, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
-    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate,
+    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }
 
 

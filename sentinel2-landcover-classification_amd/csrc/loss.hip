@@ -6,6 +6,8 @@
 // (train_segmentation.py:145,206).  One thread per pixel: the C logits of a pixel are C coalesced
 // plane reads; log-softmax, NLL, smoothing term and focal modulation stay in registers; the sum
 // is a wave shuffle reduction + one f64 atomic per wave.  Pure HBM streaming (read logits once).
+#include <algorithm>
+
 #include "common.h"
 
 namespace s2k {
@@ -212,6 +214,37 @@ int launch_argmax(const S2kOp& op, const Ctx& c) {
     if (!logits || !mask || B <= 0 || C <= 0 || HW <= 0) { set_error("argmax: bad args"); return S2K_EINVAL; }
     const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)B * HW, NTHREADS), 2048);
     hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, logits, mask, B, C, HW);
+    return S2K_OK;
+}
+
+// ---------------- confusion histogram ----------------------------------------------------------------------
+// hist[t][p] += 1 per pixel: per-workgroup LDS histogram (C <= 64), flushed with one 64-bit atomic per non-empty bin
+__global__ void __launch_bounds__(NTHREADS) confusion_kernel(const int64_t* pred, const int64_t* labels, unsigned long long* hist,
+                                                             int64_t n, int C) {
+    extern __shared__ unsigned int bins[];
+    for (int i = threadIdx.x; i < C * C; i += NTHREADS) bins[i] = 0u;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t t = labels[i], q = pred[i];
+        if (t >= 0 && t < C && q >= 0 && q < C) atomicAdd(&bins[(int)t * C + (int)q], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += NTHREADS)
+        if (bins[i]) atomicAdd(hist + i, (unsigned long long)bins[i]);
+}
+
+int launch_confusion(const S2kOp& op, const Ctx& c) {
+    const int64_t* pred = ref_ptr<const int64_t>(c, op.t[S2K_CONFUSION_T_PRED]);
+    const int64_t* labels = ref_ptr<const int64_t>(c, op.t[S2K_CONFUSION_T_LABELS]);
+    unsigned long long* hist = ref_ptr<unsigned long long>(c, op.t[S2K_CONFUSION_T_HIST]);
+    if (bad(pred) || bad(labels) || bad(hist)) { set_error("confusion: null base"); return S2K_EFAULT; }
+    const int64_t n = op.n[S2K_CONFUSION_N_COUNT];
+    const int C = op.d[S2K_CONFUSION_D_C];
+    if (!pred || !labels || !hist || n <= 0 || C <= 0 || C > MAXC) { set_error("confusion: bad args (C <= %d)", MAXC); return S2K_EINVAL; }
+    // each workgroup counts at most 2^32 - 1 pixels per bin: cap the pixels per workgroup
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>(cdiv64(n, 1 << 20), std::min<int64_t>(cdiv64(n, 4096), 1024)), 65535);
+    hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(NTHREADS), (size_t)C * C * sizeof(unsigned int), c.stream, pred, labels, hist, n, C);
     return S2K_OK;
 }
 

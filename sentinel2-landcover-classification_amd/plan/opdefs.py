@@ -146,6 +146,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
                      ["B", "C", "T", "H", "W", "P", "TUB", "LP", "L_OFF", "NORM_PIX"], []),
     # Y[b][j][c] = X[b][c][j + L_OFF], j < LOUT   (feature-major -> the reference's token-major tensors at the API boundary)
     "TRANSPOSE_CL": (["X", "Y"], [], ["B", "C", "L", "L_OFF", "LOUT"], []),
+    # HIST[t*C + p] += #{i : LABELS[i] == t, PRED[i] == p}  (int64; labels / predictions outside [0, C) are skipped):
+    # the one accumulator behind confusion matrix, IoU, accuracy and F1 (train_segmentation.py:53-63,145-159) — no host sync
+    "CONFUSION": (["PRED", "LABELS", "HIST"], ["COUNT"], ["C"], []),
     # GATE[i] = (U[i] >= P) / (1 - P)   (Dropout2d: one draw per (sample, channel), applied as a channel gate of the next conv)
     "DROP_GATE": (["U", "GATE"], ["COUNT"], [], ["P"]),
 }

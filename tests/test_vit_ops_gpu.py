@@ -219,3 +219,34 @@ def test_channel_sum_token_rows(B, C, HW):
     g = c.t("g", (B, C, HW))
     out = c.t("out", (C,), "randn")
     c.run("CHANNEL_SUM", ["out"], 1e-4, G=g, OUT=out, B=B, C=C, HW=HW)
+
+
+@pytest.mark.parametrize("n,C", [(100003, 4), (64 * 224 * 224, 10), (17, 2), (5000, 64)])
+def test_confusion_histogram_exact(n, C):
+    c = Case(17)
+    pred = c.t("pred", (n,), torch.randint(-1, C + 1, (n,), generator=c.gen), "i64")
+    lab = c.t("lab", (n,), torch.randint(0, C, (n,), generator=c.gen), "i64")
+    hist = c.t("hist", (C * C,), torch.randint(0, 5, (C * C,), generator=c.gen), "i64")
+    c.run("CONFUSION", ["hist"], tol=1e-30, PRED=pred, LABELS=lab, HIST=hist, COUNT=n, C=C)
+
+
+def test_seg_metrics_accumulate_on_gpu():
+    from s2lc_amd.metrics import SegMetrics, metrics_from_hist
+
+    g = torch.Generator().manual_seed(5)
+    C = 4
+    m = SegMetrics(C, ignore_index=0, device="cuda:0")
+    hist = torch.zeros(C, C, dtype=torch.int64)
+    for _ in range(3):
+        y = torch.randint(0, C, (2, 64, 64), generator=g)
+        p = torch.where(torch.rand(2, 64, 64, generator=g) < 0.7, y, torch.randint(0, C, (2, 64, 64), generator=g))
+        m.update(p.cuda(), y.cuda())
+        hist += torch.bincount((y * C + p).reshape(-1), minlength=C * C).view(C, C)
+    assert torch.equal(m.hist.view(C, C).cpu(), hist)
+    out = m.compute()
+    ref = metrics_from_hist(hist, 0)
+    tp = hist.diag().double()
+    assert abs(out["accuracy"].item() - (tp.sum() / hist.sum()).item()) < 1e-6
+    iou = (tp / (hist.sum(0) + hist.sum(1) - tp).double()).mean().item()
+    assert abs(out["iou"].item() - iou) < 1e-6 and abs(ref["f1"].item() - out["f1"].item()) < 1e-7
+    assert out["confusion_matrix"][0].abs().sum() == 0 and torch.allclose(out["confusion_matrix"][1:].sum(1), torch.ones(C - 1))
