@@ -185,9 +185,11 @@ int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, in
         (void)hipStreamWaitEvent(main_st, sq.join, 0);
         side_busy = false;
     };
+    static const int skip_side = [] { const char* e = getenv("S2K_EXPERIMENT_SKIP_SIDE"); return e ? atoi(e) : 0; }();   // timing experiments only
     for (int i = begin; i < end; ++i) {
         const S2kOp& op = ops[i];
         int rc;
+        if (skip_side && (op.flags & S2K_FLAG_SIDE)) continue;
         if ((op.flags & S2K_FLAG_SIDE) && sq.ok) {
             if (main_dirty) {
                 (void)hipEventRecord(sq.fork, main_st);

@@ -423,7 +423,8 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     // ~3 per CU: pick the split count whose workgroup count fills whole rounds of those slots (288 workgroups on 256
     // slots take two rounds: 1.8x the time of 256), preferring fewer splits (each ends in an atomic combine of its tile).
     const int mc = p.n_mtiles * p.n_ctiles;
-    const int slots = (T == 9) ? 256 : 768;
+    // workgroups that run at once: the 9-tap and the 128x128 kernels need > 256 registers (one workgroup per CU)
+    const int slots = (T == 9 || WM * WN >= 4) ? 256 : 768;
     int max_splits = cdiv(p.ntiles, 4);          // at least 4 pixel tiles per split
     if (max_splits > 65535) max_splits = 65535;
     if (max_splits < 1) max_splits = 1;
@@ -432,7 +433,9 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     const int s_hi = std::min(max_splits, std::max(1, 4 * slots / mc));
     for (int sp = 1; sp <= s_hi; ++sp) {
         const double rounds = (double)cdiv(mc * sp, slots);
-        const double cost = rounds * ((double)cdiv(p.ntiles, sp) + (T == 9 ? 1.5 : 0.5));   // tiles + the combine, in tile times
+        // tiles + pipeline fill + the atomic combine of the accumulator tile, in tile times
+        // (a single round has no slack for a slow workgroup: a few rounds of shorter workgroups balance better)
+        const double cost = rounds * ((double)cdiv(p.ntiles, sp) + (T == 9 ? 1.5 : (WM * WN >= 4 ? 2.0 : 0.7))) * (T == 9 ? 1.0 : 1.0 + 0.15 / rounds);
         if (cost < best * 0.999) { best = cost; splits = sp; }
     }
     p.tiles_per_split = cdiv(p.ntiles, splits);
