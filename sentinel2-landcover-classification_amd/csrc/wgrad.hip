@@ -424,7 +424,7 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     // slots take two rounds: 1.8x the time of 256), preferring fewer splits (each ends in an atomic combine of its tile).
     const int mc = p.n_mtiles * p.n_ctiles;
     // workgroups that run at once: the 9-tap and the 128x128 kernels need > 256 registers (one workgroup per CU)
-    const int slots = (T == 9 || WM * WN >= 4) ? 256 : 768;
+    const int slots = (T == 9 || WM * WN >= 4) ? 256 : (WM * WN >= 2 ? 512 : 768);
     int max_splits = cdiv(p.ntiles, 4);          // at least 4 pixel tiles per split
     if (max_splits > 65535) max_splits = 65535;
     if (max_splits < 1) max_splits = 1;
@@ -517,8 +517,13 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         p.CSQ = p.NP + 1;
         p.ntiles = (int)cdiv64(npix, p.NP);
         if (p.M <= 32 && p.C <= 32) return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 64, 1>(p, st);
-        if (p.M <= 64 || p.C <= 64) return launch_wg<WG_PIX, 1, 1, 1, 2, 2, 1, 64, 1>(p, st);
-        return launch_wg<WG_PIX, 1, 2, 2, 2, 2, 1, 64, 1>(p, st);
+        // tile edge per side: 128 unless it pads the side by more than 12 % (176 -> 256 wastes 45 %, 3 x 64 = 192 wastes 9 %)
+        auto edge = [](int n) { return (n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64; };
+        const int em = edge(p.M), ec = edge(p.C);
+        if (em == 128 && ec == 128) return launch_wg<WG_PIX, 1, 2, 2, 2, 2, 1, 64, 1>(p, st);
+        if (em == 128) return launch_wg<WG_PIX, 1, 2, 1, 2, 2, 1, 64, 1>(p, st);
+        if (ec == 128) return launch_wg<WG_PIX, 1, 1, 2, 2, 2, 1, 64, 1>(p, st);
+        return launch_wg<WG_PIX, 1, 1, 1, 2, 2, 1, 64, 1>(p, st);
     }
     if (p.T != 9) { set_error("wgrad: only 1x1, 3x3 and 2x2-transpose kernels are on this path"); return S2K_EINVAL; }
     // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles; thin layers (few
