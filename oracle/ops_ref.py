@@ -452,32 +452,43 @@ def op_act_fwd(m: Mem, o):
 
 
 def _split_qkv(t, B, H, HD, L):   # [B][3*H*HD][L] -> q, k, v each [B,H,L,HD]
-    t = t.view(B, 3, H, HD, L).permute(1, 0, 2, 4, 3)
+    t = t.reshape(B, 3, H, HD, L).permute(1, 0, 2, 4, 3)
     return t[0], t[1], t[2]
 
 
+def _attn_ls(o):
+    return o["LS"] if o.get("LS", 0) else o["L"]
+
+
 def op_attn_fwd(m: Mem, o):
-    B, H, HD, L = o["B"], o["HEADS"], o["HD"], o["L"]
-    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, L)), B, H, HD, L)
-    p = torch.softmax((q @ k.transpose(-2, -1)) * o["SCALE"], dim=-1)
+    B, H, HD, L, LS = o["B"], o["HEADS"], o["HD"], o["L"], _attn_ls(o)
+    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, LS))[..., :L], B, H, HD, L)
+    s = (q @ k.transpose(-2, -1)) * o["SCALE"]
+    p = torch.softmax(s, dim=-1)
     out = p @ v                                              # [B,H,L,HD]
-    m.view(o["O"], (B, H, HD, L)).copy_(out.permute(0, 1, 3, 2))
+    dst = m.view(o["O"], (B, H, HD, LS))
+    dst.zero_()
+    dst[..., :L].copy_(out.permute(0, 1, 3, 2))
+    lse = m.view(o["LSE"], (B, H, LS))
+    lse.zero_()
+    lse[..., :L].copy_(torch.logsumexp(s, dim=-1))
 
 
 def op_attn_bwd(m: Mem, o):
-    B, H, HD, L = o["B"], o["HEADS"], o["HD"], o["L"]
-    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, L)), B, H, HD, L)
-    do = m.view(o["DO"], (B, H, HD, L)).permute(0, 1, 3, 2)  # [B,H,L,HD]
+    B, H, HD, L, LS = o["B"], o["HEADS"], o["HD"], o["L"], _attn_ls(o)
+    q, k, v = _split_qkv(m.view(o["QKV"], (B, 3 * H * HD, LS))[..., :L], B, H, HD, L)
+    do = m.view(o["DO"], (B, H, HD, LS))[..., :L].permute(0, 1, 3, 2)  # [B,H,L,HD]
     p = torch.softmax((q @ k.transpose(-2, -1)) * o["SCALE"], dim=-1)
     dv = p.transpose(-2, -1) @ do
     dp = do @ v.transpose(-2, -1)
     ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * o["SCALE"]
     dq = ds @ k
     dk = ds.transpose(-2, -1) @ q
-    dst = m.view(o["DQKV"], (B, 3, H, HD, L))
-    dst[:, 0].copy_(dq.permute(0, 1, 3, 2))
-    dst[:, 1].copy_(dk.permute(0, 1, 3, 2))
-    dst[:, 2].copy_(dv.permute(0, 1, 3, 2))
+    dst = m.view(o["DQKV"], (B, 3, H, HD, LS))
+    dst.zero_()
+    dst[:, 0, ..., :L].copy_(dq.permute(0, 1, 3, 2))
+    dst[:, 1, ..., :L].copy_(dk.permute(0, 1, 3, 2))
+    dst[:, 2, ..., :L].copy_(dv.permute(0, 1, 3, 2))
 
 
 def op_mae_mask_index(m: Mem, o):

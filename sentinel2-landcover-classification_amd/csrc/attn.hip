@@ -1,17 +1,24 @@
 // Multi-head softmax attention of the ViT blocks (timm `Attention` as used by prithvi.py:162-164,178-183:
 // q,k,v = split(qkv(x)); softmax(q k^T * hd^-0.5) v) on the gfx950 f32 matrix cores, forward and backward.
 //
-// QKV is feature-major [B][3*H*hd][L]: one head's q / k / v are [hd][L] row-major tiles, which are exactly the
-// LDS operand layouts of v_mfma_f32_32x32x2_f32 used here:
-//   S[i][j]  = sum_d Q[d][i] K[d][j]      A(m=i,k=d) = Qs[d][i]  (lanes along i)   B(k=d,n=j) = Ks[d][j] (lanes along j)
-//   O[d][i]  = sum_j V[d][j] P[i][j]      A(m=d,k=j) = Vs[d][j]  (row stride odd)  B(k=j,n=i) = Ps[i][j] (row stride odd)
-// so nothing is transposed on the way in, and O / dQ / dK / dV come out feature-major with tokens on the lanes
-// (128-B coalesced rows).  Rows of every LDS tile have an odd stride: a half-wave reading one column hits 32 banks.
-// Softmax rows are reduced with wave shuffles; scores never leave LDS.
-//
-// forward:  one workgroup per (batch, head, 32-query tile).
-// backward: one workgroup per (batch, head); it walks the query tiles, recomputes P, and keeps the dK / dV
-//           accumulator tiles in registers (no atomics, deterministic).
+// QKV is feature-major [B][3*H*hd][LS] (LS = row stride >= L tokens): one head's q / k / v are [hd][LS] row-major
+// tiles, and v_mfma_f32_32x32x2_f32 takes them straight from global memory, one element per lane:
+//   streamed A(m = token, k = d) and held B(k = d, n = token) are 128-B coalesced row segments (lanes along tokens).
+// Every wave is an independent unit - no LDS, no barriers, no atomics - so occupancy hides the load latency:
+//   forward   unit = (batch, head, 32-query tile): S^T[j][i] = sum_d K[d][j] Q[d][i] per 32-key tile, with the QUERY on
+//             the lanes, so the softmax row statistics are per-lane scalars (online softmax: running max / sum, the
+//             output tile rescaled in place; one cross-half exchange per tile).  The probabilities never leave their
+//             accumulator registers: P^T[j][i] is already the B operand (k = j, n = i) of O[d][i] += V[d][j] P^T[j][i]
+//             if step s of the contraction takes key (s&3) + 8(s>>2) + 4*half - the accumulator's own row order - and
+//             in that order the A operand V[d][j..j+3] is a 16-byte load per lane (lanes along d).
+//             The per-query log-sum-exp is kept for the backward.
+//   backward  two kernels of the same shape.  dQ: unit = (b, h, query tile) recomputes S^T and dP^T per key tile,
+//             dS^T = P^T (dP^T - delta_i) with delta_i = sum_d dO[d][i] O[d][i] a per-lane scalar, dQ[d][i] += K[d][j] dS^T[j][i].
+//             dK/dV: unit = (b, h, key tile) recomputes S and dP with the KEY on the lanes and walks the query tiles:
+//             dV[d][j] += dO[d][i] P[i][j], dK[d][j] += Q[d][i] dS[i][j].  Recomputing the scores in both
+//             orientations costs 7 tile products per (query tile, key tile) pair instead of 5, and removes every
+//             cross-wave reduction (the results are deterministic).
+// Tokens L..LS-1 (row padding) are written as zeros in O, dQKV, LSE.
 #include "common.h"
 
 namespace s2k {
@@ -26,315 +33,259 @@ static T* ref_ptr(const Ctx& c, int64_t ref) {
 }
 
 struct AttnP {
-    const float *qkv, *dout;
-    float *o, *dqkv;
-    int B, H, HD, L;
-    int Lp, LS, hdp, hd2, ntq, mtiles;   // keys padded to 32, LDS row stride (odd), head dim padded to 32 / to even
-    int red_ok;                          // backward: LDS has room for the dQ partial tiles
+    const float *qkv, *dout, *o_in;
+    float *o, *dqkv, *lse, *delta;
+    int B, H, HD, L, LS;
+    int nt;       // 32-token tiles
     float scale;
 };
 
-constexpr int QS = 33;   // row stride of the 32-query tiles
-
-// acc += sum_k A(l31, k) * B(k, l31); element k of the operands at a[k * a_ks], b[k * b_ks]; K even
-__device__ __forceinline__ void mfma_loop(f32x16& acc, const float* a, int a_ks, const float* b, int b_ks, int K, int lh) {
-    for (int k2 = 0; k2 < K; k2 += 2) {
-        const int k = k2 + lh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k * a_ks], b[k * b_ks], acc, 0, 0, 0);
-    }
-}
+constexpr int AW = 4;   // independent waves per workgroup
 
 __device__ __forceinline__ void zero16(f32x16& v) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = 0.0f;
 }
+// row (M index) of accumulator register r in lane half lh of a 32x32 tile; the column is lane & 31
+__device__ __forceinline__ int mrow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
-// rows [row0, row0 + nrows) of a [.][L] global matrix -> dst[r * stride + j], zero for r >= valid_rows or j >= L (j < Lp)
-__device__ __forceinline__ void stage_rows(float* dst, int stride, const float* src, int L, int Lp, int nrows, int valid_rows) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < nrows; r += 4)            // one row per wave and pass, lanes along the tokens: no index division
-        for (int j = lane; j < Lp; j += 64) dst[r * stride + j] = (r < valid_rows && j < L) ? src[(int64_t)r * L + j] : 0.0f;
-}
-
-// 32 columns [i0, i0 + 32) of a [rows][L] matrix -> dst[r * QS + i]
-__device__ __forceinline__ void stage_cols32(float* dst, const float* src, int L, int i0, int nrows, int valid_rows) {
-    for (int e = threadIdx.x; e < nrows * 32; e += NTHREADS) {
-        const int r = e >> 5, i = e & 31;
-        dst[r * QS + i] = (r < valid_rows && i0 + i < L) ? src[(int64_t)r * L + i0 + i] : 0.0f;
+// held B operand (k = d = 2s + lh, n = token): reg[s] = mul * T[d][tok], zero for d >= HD
+template <int MT>
+__device__ __forceinline__ void load_held(float (&reg)[16 * MT], rsrc_t rs, uint32_t row0, int tok, int HD, int LS, int lh, float mul) {
+#pragma unroll
+    for (int s = 0; s < 16 * MT; ++s) {
+        const int d = 2 * s + lh;
+        const float x = bload(rs, (row0 + (uint32_t)min(d, HD - 1) * LS + tok) * 4u);
+        reg[s] = x * (d < HD ? mul : 0.0f);
     }
 }
 
-// scores of one query tile: Ss[i][j] = scale * <q_i, k_j>, -inf for j >= L; the waves split the 32-key column tiles
-__device__ __forceinline__ void scores_tile(const AttnP& p, const float* Qs, const float* Ks, float* Ss, int wave, int l31, int lh) {
-    const int ntiles = p.Lp >> 5;
-    for (int nt = wave; nt < ntiles; nt += 4) {
-        f32x16 acc;
-        zero16(acc);
-        mfma_loop(acc, Qs + l31, QS, Ks + 32 * nt + l31, p.LS, p.hd2, lh);
-        const int j = 32 * nt + l31;
+// acc[m = streamed token][n = held token] = sum_d T[d][tok] * held[d][n]   (rows d >= HD meet held zeros)
+template <int MT>
+__device__ __forceinline__ f32x16 tile_dd(rsrc_t rs, uint32_t row0, int tok, int LS, int lh, const float (&held)[16 * MT]) {
+    float a[16 * MT];
+#pragma unroll
+    for (int s = 0; s < 16 * MT; ++s) a[s] = bload(rs, (row0 + (uint32_t)(2 * s + lh) * LS + tok) * 4u);
+    f32x16 acc;
+    zero16(acc);
+#pragma unroll
+    for (int s = 0; s < 16 * MT; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], held[s], acc, 0, 0, 0);
+    return acc;
+}
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_t4(rsrc_t rs, uint32_t elem) {
+    if (VEC) return bload4(rs, elem * 4u);
+    f32x4 v;
+    v[0] = bload(rs, elem * 4u);
+    v[1] = bload(rs, elem * 4u + 4u);
+    v[2] = bload(rs, elem * 4u + 8u);
+    v[3] = bload(rs, elem * 4u + 12u);
+    return v;
+}
+
+// acc[mt][m = d][n] += sum_t T[d][tok0 + t] * b[t][n], b = an accumulator tile (rows t in register order)
+template <int MT, bool VEC>
+__device__ __forceinline__ void tile_acc(f32x16 (&acc)[MT], rsrc_t rs, uint32_t row0, int tok0, int LS, int l31, int lh, const f32x16& b) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const uint32_t base = row0 + (uint32_t)(32 * mt + l31) * LS + tok0 + 4 * lh;
+        f32x4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = load_t4<VEC>(rs, base + 8 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[g][c], b[4 * g + c], acc[mt], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+struct Unit { int b, h, tile; int64_t bh; bool ok; };
+__device__ __forceinline__ Unit unit_of(const AttnP& p) {
+    Unit u;
+    const int64_t id = (int64_t)blockIdx.x * AW + (threadIdx.x >> 6);
+    u.tile = (int)(id % p.nt);
+    u.bh = id / p.nt;
+    u.ok = u.bh < (int64_t)p.B * p.H;
+    u.h = (int)(u.bh % p.H);
+    u.b = (int)(u.bh / p.H);
+    return u;
+}
+
+// store acc rows d < HD of lane column tok: value * mul for tok < L, zero for the row padding
+template <int MT>
+__device__ __forceinline__ void store_rows(float* dst, const f32x16 (&acc)[MT], int tok, int lh, const AttnP& p, float mul) {
+    if (tok >= p.LS) return;
+    const float keep = tok < p.L ? mul : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            Ss[i * p.LS + j] = j < p.L ? acc[r] * p.scale : -INFINITY;
+            const int d = 32 * mt + mrow(r, lh);
+            if (d < p.HD) dst[(int64_t)d * p.LS + tok] = acc[mt][r] * keep;
         }
-    }
-}
-
-// row softmax in place (wave w owns rows 8w .. 8w+7); padded key columns come out as exact zeros
-__device__ __forceinline__ void softmax_rows(const AttnP& p, float* Ss, int wave, int lane) {
-    for (int i = 8 * wave; i < 8 * wave + 8; ++i) {
-        float* row = Ss + i * p.LS;
-        float mx = -INFINITY;
-        for (int j = lane; j < p.Lp; j += 64) mx = fmaxf(mx, row[j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.0f;
-        for (int j = lane; j < p.Lp; j += 64) {
-            const float e = j < p.L ? __expf(row[j] - mx) : 0.0f;   // v_exp_f32: ~1 ulp, far inside the 1e-3 bar
-            row[j] = e;
-            sum += e;
-        }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        for (int j = lane; j < p.Lp; j += 64) row[j] *= inv;
-    }
 }
 
 // ---------------- forward ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NTHREADS) attn_fwd_kernel(const AttnP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* KV = smem;                           // [hdp][LS]  K, then V
-    float* Qs = KV + p.hdp * p.LS;              // [hdp][QS]
-    float* Ss = Qs + p.hdp * QS;                // [32][LS]
-    float* red = Ss + 32 * p.LS;                // [parts][hdp][32]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int qt = blockIdx.x % p.ntq;
-    const int h = (blockIdx.x / p.ntq) % p.H;
-    const int b = blockIdx.x / (p.ntq * p.H);
-    const int D = p.H * p.HD, i0 = qt * 32;
-    const float* q = p.qkv + ((int64_t)b * 3 * D + h * p.HD) * p.L;
-    const float* k = q + (int64_t)D * p.L;
-    const float* v = k + (int64_t)D * p.L;
-
-    stage_rows(KV, p.LS, k, p.L, p.Lp, p.hdp, p.HD);
-    stage_cols32(Qs, q, p.L, i0, p.hdp, p.HD);
-    __syncthreads();
-    scores_tile(p, Qs, KV, Ss, wave, l31, lh);
-    __syncthreads();
-    stage_rows(KV, p.LS, v, p.L, p.Lp, p.hdp, p.HD);   // K is done: V takes its place while the softmax runs
-    softmax_rows(p, Ss, wave, lane);
-    __syncthreads();
-    // O[d][i] = sum_j V[d][j] P[i][j]: (row tile mt, key range part) per wave, partial tiles summed through LDS
-    const int parts = 4 / p.mtiles;
-    const int mt = wave % p.mtiles, part = wave / p.mtiles;
-    const int klen = p.Lp / parts;
-    f32x16 acc;
-    zero16(acc);
-    mfma_loop(acc, KV + (32 * mt + l31) * p.LS + part * klen, 1, Ss + l31 * p.LS + part * klen, 1, klen, lh);
+template <int MT, bool VEC>
+__global__ void __launch_bounds__(64 * AW, 2) attn_fwd_kernel(const AttnP p) {
+    const Unit u = unit_of(p);
+    if (!u.ok) return;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const int D = p.H * p.HD, LS = p.LS, L = p.L;
+    const rsrc_t rs = make_rsrc(p.qkv + (int64_t)u.b * 3 * D * LS, (int64_t)3 * D * LS * 4);
+    const uint32_t qo = (uint32_t)u.h * p.HD * LS, ko = qo + (uint32_t)D * LS, vo = ko + (uint32_t)D * LS;
+    const int i = 32 * u.tile + l31;
+    float qreg[16 * MT];
+    load_held<MT>(qreg, rs, qo, min(i, L - 1), p.HD, LS, lh, p.scale);
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        red[(part * p.hdp + d) * 32 + l31] = acc[r];
-    }
-    __syncthreads();
-    float* o = p.o + ((int64_t)b * D + h * p.HD) * p.L;
-    for (int e = threadIdx.x; e < p.hdp * 32; e += NTHREADS) {
-        const int d = e >> 5, i = e & 31;
-        if (d < p.HD && i0 + i < p.L) {
-            float s = 0.0f;
-            for (int pp = 0; pp < parts; ++pp) s += red[(pp * p.hdp + d) * 32 + i];
-            o[(int64_t)d * p.L + i0 + i] = s;
+    for (int mt = 0; mt < MT; ++mt) zero16(acc[mt]);
+    float m = -INFINITY, l = 0.0f;
+    for (int kt = 0; kt < p.nt; ++kt) {
+        f32x16 s = tile_dd<MT>(rs, ko, min(32 * kt + l31, L - 1), LS, lh, qreg);   // rows: key, columns: query
+        float tm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = 32 * kt + mrow(r, lh) < L ? s[r] : -INFINITY;
+            tm = fmaxf(tm, s[r]);
         }
+        tm = fmaxf(tm, xhalf(tm));
+        const float mn = fmaxf(m, tm);            // finite: every tile holds at least one real key
+        const float corr = __expf(m - mn);
+        float ts = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __expf(s[r] - mn);             // v_exp_f32: ~1 ulp, far inside the 1e-3 bar
+            ts += s[r];
+        }
+        ts += xhalf(ts);
+        l = l * corr + ts;
+        m = mn;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] *= corr;
+        tile_acc<MT, VEC>(acc, rs, vo, 32 * kt, LS, l31, lh, s);
     }
+    store_rows<MT>(p.o + ((int64_t)u.b * D + u.h * p.HD) * LS, acc, i, lh, p, 1.0f / l);
+    if (lh == 0 && i < LS) p.lse[u.bh * LS + i] = i < L ? m + __logf(l) : 0.0f;
 }
 
 // ---------------- backward -------------------------------------------------------------------------------
-constexpr int MAX_TPW = 4;   // dK / dV accumulator tiles per wave
-
-__global__ void __launch_bounds__(NTHREADS, 1) attn_bwd_kernel(const AttnP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                           // [hdp][LS]
-    float* Vs = Ks + p.hdp * p.LS;              // [hdp][LS]
-    float* Qs = Vs + p.hdp * p.LS;              // [hdp][QS]
-    float* dOs = Qs + p.hdp * QS;               // [hdp][QS]
-    float* Ss = dOs + p.hdp * QS;               // [32][LS]   P, then dS
-    float* dpart = Ss + 32 * p.LS;              // [4][32]    per-wave partial row sums of dP * P
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
-    const int D = p.H * p.HD;
-    const float* q = p.qkv + ((int64_t)b * 3 * D + h * p.HD) * p.L;
-    const float* k = q + (int64_t)D * p.L;
-    const float* v = k + (int64_t)D * p.L;
-    const float* dO = p.dout + ((int64_t)b * D + h * p.HD) * p.L;
-    float* dq = p.dqkv + ((int64_t)b * 3 * D + h * p.HD) * p.L;
-    float* dk = dq + (int64_t)D * p.L;
-    float* dv = dk + (int64_t)D * p.L;
-    const int ntiles = p.Lp >> 5;
-    const int ntot = p.mtiles * ntiles;         // dK / dV tiles (mt, nt), dealt round-robin to the waves
-
-    f32x16 aK[MAX_TPW], aV[MAX_TPW];
+template <int MT, bool VEC>
+__global__ void __launch_bounds__(64 * AW, 2) attn_bwd_dq_kernel(const AttnP p) {
+    const Unit u = unit_of(p);
+    if (!u.ok) return;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const int D = p.H * p.HD, LS = p.LS, L = p.L;
+    const rsrc_t rs = make_rsrc(p.qkv + (int64_t)u.b * 3 * D * LS, (int64_t)3 * D * LS * 4);
+    const rsrc_t rdo = make_rsrc(p.dout + (int64_t)u.b * D * LS, (int64_t)D * LS * 4);
+    const rsrc_t ro = make_rsrc(p.o_in + (int64_t)u.b * D * LS, (int64_t)D * LS * 4);
+    const uint32_t qo = (uint32_t)u.h * p.HD * LS, ko = qo + (uint32_t)D * LS, vo = ko + (uint32_t)D * LS;
+    const int i = 32 * u.tile + l31, ic = min(i, L - 1);
+    float qreg[16 * MT], doreg[16 * MT];
+    load_held<MT>(qreg, rs, qo, ic, p.HD, LS, lh, p.scale);
+    load_held<MT>(doreg, rdo, qo, ic, p.HD, LS, lh, 1.0f);
+    float dl = 0.0f;                              // delta_i = sum_d dO[d][i] O[d][i] = sum_j P[i][j] dP[i][j]
 #pragma unroll
-    for (int t = 0; t < MAX_TPW; ++t) { zero16(aK[t]); zero16(aV[t]); }
-
-    stage_rows(Ks, p.LS, k, p.L, p.Lp, p.hdp, p.HD);
-    stage_rows(Vs, p.LS, v, p.L, p.Lp, p.hdp, p.HD);
-    const int parts = 4 / p.mtiles;
-    const int klen = p.Lp / parts;
-
-    for (int qt = 0; qt < p.ntq; ++qt) {
-        const int i0 = qt * 32;
-        stage_cols32(Qs, q, p.L, i0, p.hdp, p.HD);
-        stage_cols32(dOs, dO, p.L, i0, p.hdp, p.HD);
-        __syncthreads();
-        scores_tile(p, Qs, Ks, Ss, wave, l31, lh);
-        __syncthreads();
-        softmax_rows(p, Ss, wave, lane);
-        __syncthreads();
-        // dV[d][j] += sum_i dO[d][i] P[i][j]
+    for (int s = 0; s < 16 * MT; ++s) dl = fmaf(doreg[s], bload(ro, (qo + (uint32_t)min(2 * s + lh, p.HD - 1) * LS + ic) * 4u), dl);
+    dl += xhalf(dl);
+    const float lse = p.lse[u.bh * LS + ic];
+    if (lh == 0 && i < LS) p.delta[u.bh * LS + i] = i < L ? dl : 0.0f;
+    f32x16 acc[MT];
 #pragma unroll
-        for (int t = 0; t < MAX_TPW; ++t) {
-            const int tile = wave + 4 * t;
-            if (tile < ntot) {
-                const int mt = tile % p.mtiles, nt = tile / p.mtiles;
-                mfma_loop(aV[t], dOs + (32 * mt + l31) * QS, 1, Ss + 32 * nt + l31, p.LS, 32, lh);
-            }
-        }
-        // dP[i][j] = sum_d dO[d][i] V[d][j] for this wave's key tiles; delta_i = sum_j dP * P
-        f32x16 dP[2];
-        float rowpart[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rowpart[r] = 0.0f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            zero16(dP[u]);
-            const int nt = wave + 4 * u;
-            if (nt < ntiles) {
-                mfma_loop(dP[u], dOs + l31, QS, Vs + 32 * nt + l31, p.LS, p.hd2, lh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    rowpart[r] = fmaf(dP[u][r], Ss[i * p.LS + 32 * nt + l31], rowpart[r]);
-                }
-            }
-        }
+    for (int mt = 0; mt < MT; ++mt) zero16(acc[mt]);
+    for (int kt = 0; kt < p.nt; ++kt) {
+        const int jc = min(32 * kt + l31, L - 1);
+        f32x16 s = tile_dd<MT>(rs, ko, jc, LS, lh, qreg);            // S^T[j][i] (scaled)
+        const f32x16 dp = tile_dd<MT>(rs, vo, jc, LS, lh, doreg);    // dP^T[j][i] = sum_d V[d][j] dO[d][i]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = half_sum_hi(rowpart[r]);
-            if (l31 == 31) dpart[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = s;
+            const float pr = 32 * kt + mrow(r, lh) < L ? __expf(s[r] - lse) : 0.0f;
+            s[r] = pr * (dp[r] - dl);
         }
-        __syncthreads();   // every wave is done reading P (dV above, delta here): Ss may be overwritten with dS
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int nt = wave + 4 * u;
-            if (nt < ntiles) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float delta = (dpart[i] + dpart[32 + i]) + (dpart[64 + i] + dpart[96 + i]);
-                    float* s = Ss + i * p.LS + 32 * nt + l31;
-                    *s = *s * (dP[u][r] - delta) * p.scale;
-                }
-            }
-        }
-        __syncthreads();
-        // dK[d][j] += sum_i Q[d][i] dS[i][j]
-#pragma unroll
-        for (int t = 0; t < MAX_TPW; ++t) {
-            const int tile = wave + 4 * t;
-            if (tile < ntot) {
-                const int mt = tile % p.mtiles, nt = tile / p.mtiles;
-                mfma_loop(aK[t], Qs + (32 * mt + l31) * QS, 1, Ss + 32 * nt + l31, p.LS, 32, lh);
-            }
-        }
-        // dQ[d][i] = sum_j K[d][j] dS[i][j]: (row tile, key range) per wave; the key-range partials are combined in a
-        // fixed order (part 0 stores, the others add after a barrier) so the result is reproducible
-        {
-            const int mt = wave % p.mtiles, part = wave / p.mtiles;
-            f32x16 acc;
-            zero16(acc);
-            mfma_loop(acc, Ks + (32 * mt + l31) * p.LS + part * klen, 1, Ss + l31 * p.LS + part * klen, 1, klen, lh);
-            if (p.red_ok) {   // LDS has room for the partial tiles: one barrier, fixed-order sum, coalesced store
-                float* red = dpart + 128;                       // [parts][hdp][32]
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int d = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    red[(part * p.hdp + d) * 32 + l31] = acc[r];
-                }
-                __syncthreads();
-                for (int e = threadIdx.x; e < p.hdp * 32; e += NTHREADS) {
-                    const int d = e >> 5, i = e & 31;
-                    if (d < p.HD && i0 + i < p.L) {
-                        float sum = 0.0f;
-                        for (int pp = 0; pp < parts; ++pp) sum += red[(pp * p.hdp + d) * 32 + i];
-                        dq[(int64_t)d * p.L + i0 + i] = sum;
-                    }
-                }
-                __syncthreads();
-            } else
-            for (int pp = 0; pp < parts; ++pp) {
-                if (part == pp) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int d = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (d < p.HD && i0 + l31 < p.L) {
-                            float* dst = dq + (int64_t)d * p.L + i0 + l31;
-                            if (pp == 0) *dst = acc[r];
-                            else atomicAdd(dst, acc[r]);
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        tile_acc<MT, VEC>(acc, rs, ko, 32 * kt, LS, l31, lh, s);
     }
+    store_rows<MT>(p.dqkv + ((int64_t)u.b * 3 * D + u.h * p.HD) * LS, acc, i, lh, p, p.scale);
+}
+
+template <int MT, bool VEC>
+__global__ void __launch_bounds__(64 * AW, 2) attn_bwd_dkv_kernel(const AttnP p) {
+    const Unit u = unit_of(p);
+    if (!u.ok) return;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const int D = p.H * p.HD, LS = p.LS, L = p.L;
+    const rsrc_t rs = make_rsrc(p.qkv + (int64_t)u.b * 3 * D * LS, (int64_t)3 * D * LS * 4);
+    const rsrc_t rdo = make_rsrc(p.dout + (int64_t)u.b * D * LS, (int64_t)D * LS * 4);
+    const uint32_t qo = (uint32_t)u.h * p.HD * LS, ko = qo + (uint32_t)D * LS, vo = ko + (uint32_t)D * LS;
+    const int j = 32 * u.tile + l31, jc = min(j, L - 1);
+    float kreg[16 * MT], vreg[16 * MT];
+    load_held<MT>(kreg, rs, ko, jc, p.HD, LS, lh, p.scale);
+    load_held<MT>(vreg, rs, vo, jc, p.HD, LS, lh, 1.0f);
+    const float* lse = p.lse + u.bh * LS;
+    const float* delta = p.delta + u.bh * LS;
+    f32x16 aK[MT], aV[MT];
 #pragma unroll
-    for (int t = 0; t < MAX_TPW; ++t) {
-        const int tile = wave + 4 * t;
-        if (tile < ntot) {
-            const int mt = tile % p.mtiles, nt = tile / p.mtiles;
-            const int j = 32 * nt + l31;
+    for (int mt = 0; mt < MT; ++mt) { zero16(aK[mt]); zero16(aV[mt]); }
+    for (int qt = 0; qt < p.nt; ++qt) {
+        const int ic = min(32 * qt + l31, L - 1);
+        f32x16 s = tile_dd<MT>(rs, qo, ic, LS, lh, kreg);             // S[i][j] (scaled): rows query, columns key
+        f32x16 dp = tile_dd<MT>(rdo, qo, ic, LS, lh, vreg);           // dP[i][j] = sum_d dO[d][i] V[d][j]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (d < p.HD && j < p.L) {
-                    dk[(int64_t)d * p.L + j] = aK[t][r];
-                    dv[(int64_t)d * p.L + j] = aV[t][r];
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int ii = 32 * qt + mrow(r, lh), iic = min(ii, L - 1);
+            const float pr = ii < L ? __expf(s[r] - lse[iic]) : 0.0f;
+            s[r] = pr;
+            dp[r] = pr * (dp[r] - delta[iic]);
         }
+        tile_acc<MT, VEC>(aV, rdo, qo, 32 * qt, LS, l31, lh, s);
+        tile_acc<MT, VEC>(aK, rs, qo, 32 * qt, LS, l31, lh, dp);
     }
+    float* dk = p.dqkv + ((int64_t)u.b * 3 * D + D + u.h * p.HD) * LS;
+    store_rows<MT>(dk, aK, j, lh, p, p.scale);
+    store_rows<MT>(dk + (int64_t)D * LS, aV, j, lh, p, 1.0f);
 }
 
 // -------------------------------------------------------------------------------------------------------------
 static int fill_attn(AttnP& p, const int32_t* d, float scale) {
-    p.B = d[0]; p.H = d[1]; p.HD = d[2]; p.L = d[3];
+    p.B = d[0]; p.H = d[1]; p.HD = d[2]; p.L = d[3]; p.LS = d[4] > 0 ? d[4] : d[3];
     p.scale = scale;
-    if (p.B <= 0 || p.H <= 0 || p.HD <= 0 || p.L <= 0 || p.HD > 64) { set_error("attention: unsupported dims (head dim <= 64)"); return S2K_EINVAL; }
-    p.Lp = cdiv(p.L, 32) * 32;
-    p.LS = p.Lp + 1;
-    p.hdp = cdiv(p.HD, 32) * 32;
-    p.hd2 = (p.HD + 1) & ~1;
-    p.ntq = p.Lp / 32;
-    p.mtiles = p.hdp / 32;
+    if (p.B <= 0 || p.H <= 0 || p.HD <= 0 || p.L <= 0 || p.HD > 64 || p.LS < p.L) {
+        set_error("attention: unsupported dims (head dim <= 64, row stride >= tokens)"); return S2K_EINVAL;
+    }
+    if ((int64_t)3 * p.H * p.HD * p.LS * 4 + 64ll * p.LS * 4 > 0x7ffffff0ll) { set_error("attention: one image's qkv exceeds 2 GiB"); return S2K_EINVAL; }
+    p.nt = cdiv(p.L, 32);
     return S2K_OK;
 }
+
+static bool bad(const void* q) { return q == nullptr || q == reinterpret_cast<const void*>(1); }
+static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+#define ATTN_LAUNCH(kernel, p, vec, stream)                                                                          \
+    do {                                                                                                             \
+        const int64_t units = (int64_t)(p).B * (p).H * (p).nt;                                                       \
+        const dim3 grid((unsigned)cdiv64(units, AW)), block(64 * AW);                                                \
+        if ((p).HD <= 32) {                                                                                          \
+            if (vec) hipLaunchKernelGGL((kernel<1, true>), grid, block, 0, stream, p);                               \
+            else hipLaunchKernelGGL((kernel<1, false>), grid, block, 0, stream, p);                                  \
+        } else {                                                                                                     \
+            if (vec) hipLaunchKernelGGL((kernel<2, true>), grid, block, 0, stream, p);                               \
+            else hipLaunchKernelGGL((kernel<2, false>), grid, block, 0, stream, p);                                  \
+        }                                                                                                            \
+    } while (0)
 
 int launch_attn_fwd(const S2kOp& op, const Ctx& c) {
     AttnP p{};
     if (int e = fill_attn(p, op.d, op.f[S2K_ATTN_FWD_F_SCALE])) return e;
     p.qkv = ref_ptr<const float>(c, op.t[S2K_ATTN_FWD_T_QKV]);
     p.o = ref_ptr<float>(c, op.t[S2K_ATTN_FWD_T_O]);
-    if (p.qkv == reinterpret_cast<const float*>(1) || p.o == reinterpret_cast<float*>(1)) { set_error("attn_fwd: null base"); return S2K_EFAULT; }
-    if (!p.qkv || !p.o) { set_error("attn_fwd: missing tensor"); return S2K_EINVAL; }
-    const size_t lds = ((size_t)p.hdp * p.LS + (size_t)p.hdp * QS + 32 * (size_t)p.LS + 128 * 32) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("attn_fwd: %d tokens x head dim %d needs %zu B of LDS (single-pass kernel, max 160 KB)", p.L, p.HD, lds); return S2K_EINVAL; }
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    const int64_t blocks = (int64_t)p.B * p.H * p.ntq;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), lds, c.stream, p);
+    p.lse = ref_ptr<float>(c, op.t[S2K_ATTN_FWD_T_LSE]);
+    if (bad(p.qkv) || bad(p.o) || bad(p.lse)) { set_error("attn_fwd: missing tensor or null base"); return S2K_EINVAL; }
+    const bool vec = p.LS % 4 == 0 && aligned16(p.qkv);
+    ATTN_LAUNCH(attn_fwd_kernel, p, vec, c.stream);
     return S2K_OK;
 }
 
@@ -344,23 +295,15 @@ int launch_attn_bwd(const S2kOp& op, const Ctx& c) {
     p.qkv = ref_ptr<const float>(c, op.t[S2K_ATTN_BWD_T_QKV]);
     p.dout = ref_ptr<const float>(c, op.t[S2K_ATTN_BWD_T_DO]);
     p.dqkv = ref_ptr<float>(c, op.t[S2K_ATTN_BWD_T_DQKV]);
-    if (p.qkv == reinterpret_cast<const float*>(1) || p.dout == reinterpret_cast<const float*>(1) || p.dqkv == reinterpret_cast<float*>(1)) {
-        set_error("attn_bwd: null base"); return S2K_EFAULT;
+    p.o_in = ref_ptr<const float>(c, op.t[S2K_ATTN_BWD_T_O]);
+    p.lse = ref_ptr<float>(c, op.t[S2K_ATTN_BWD_T_LSE]);
+    p.delta = ref_ptr<float>(c, op.t[S2K_ATTN_BWD_T_DELTA]);
+    if (bad(p.qkv) || bad(p.dout) || bad(p.dqkv) || bad(p.o_in) || bad(p.lse) || bad(p.delta)) {
+        set_error("attn_bwd: missing tensor or null base"); return S2K_EINVAL;
     }
-    if (!p.qkv || !p.dout || !p.dqkv) { set_error("attn_bwd: missing tensor"); return S2K_EINVAL; }
-    if (p.mtiles * (p.Lp / 32) > 4 * MAX_TPW || p.Lp / 32 > 8) {
-        set_error("attn_bwd: %d tokens x head dim %d exceeds the register-resident dK/dV tiles", p.L, p.HD); return S2K_EINVAL;
-    }
-    size_t lds = (2 * (size_t)p.hdp * p.LS + 2 * (size_t)p.hdp * QS + 32 * (size_t)p.LS + 128) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("attn_bwd: %d tokens x head dim %d needs %zu B of LDS (max 160 KB)", p.L, p.HD, lds); return S2K_EINVAL; }
-    p.red_ok = lds + 128 * 32 * sizeof(float) <= 160 * 1024;
-    if (p.red_ok) lds += 128 * 32 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(p.B * p.H)), dim3(NTHREADS), lds, c.stream, p);
+    const bool vec = p.LS % 4 == 0 && aligned16(p.qkv) && aligned16(p.dout);
+    ATTN_LAUNCH(attn_bwd_dq_kernel, p, vec, c.stream);      // also writes delta, which the dK/dV kernel reads
+    ATTN_LAUNCH(attn_bwd_dkv_kernel, p, vec, c.stream);
     return S2K_OK;
 }
 

@@ -122,10 +122,11 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # Y[i] = act(X[i])   (GELU of the MLP hidden layer, materialised once: the erf polynomial costs ~25 vector instructions
     # per element, and a conv / wgrad prologue would re-evaluate it for every output-channel tile that reads the element)
     "ACT_FWD": (["X", "Y"], ["COUNT"], ["ACT"], []),
-    # multi-head attention on QKV [B][3*HEADS*HD][L] (rows q | k | v, each (head, d)):
-    #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d]
-    "ATTN_FWD": (["QKV", "O"], [], ["B", "HEADS", "HD", "L"], ["SCALE"]),
-    "ATTN_BWD": (["QKV", "DO", "DQKV"], [], ["B", "HEADS", "HD", "L"], ["SCALE"]),
+    # multi-head attention on QKV [B][3*HEADS*HD][LS] (rows q | k | v, each (head, d); LS >= L is the row stride, 0 = L):
+    #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d];  LSE[b][h][i] = log sum_j exp(SCALE * <q_i, k_j>)
+    # backward reads O and LSE back, uses DELTA [B][HEADS][LS] as scratch (sum_d DO * O);  O / DQKV / LSE columns L..LS-1 := 0
+    "ATTN_FWD": (["QKV", "O", "LSE"], [], ["B", "HEADS", "HD", "L", "LS"], ["SCALE"]),
+    "ATTN_BWD": (["QKV", "DO", "DQKV", "O", "LSE", "DELTA"], [], ["B", "HEADS", "HD", "L", "LS"], ["SCALE"]),
     # rank r of NOISE[b][l] in its row (ties: lower index first = a stable argsort): IDS_RESTORE[b][l] = r (int64),
     # MASK[b][l] = r >= KEEP (f32);  gather tables (int32): ENC_IDX[b] = {-1 (cls), index of rank 0 .. KEEP-1},
     # DEC_IDX[b] = {0, (r_l < KEEP ? 1 + r_l : -1) for l < L}

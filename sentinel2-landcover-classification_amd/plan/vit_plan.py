@@ -233,7 +233,8 @@ class _V:
         h1, mr1 = self.ln_fwd(prefix + ".norm1", x, Dm, N, 1e-5)
         qkv = self.linear_fwd(prefix + ".attn.qkv.weight", prefix + ".attn.qkv.bias", h1, Dm, 3 * Dm, N)
         o = p.alloc("attn:" + prefix, (B, Dm, N))
-        p.fwd.add("ATTN_FWD", QKV=qkv, O=o, B=B, HEADS=heads, HD=hd, L=N, SCALE=float(hd) ** -0.5)
+        lse = p.alloc("lse:" + prefix, (B, heads, N))
+        p.fwd.add("ATTN_FWD", QKV=qkv, O=o, LSE=lse, B=B, HEADS=heads, HD=hd, L=N, LS=N, SCALE=float(hd) ** -0.5)
         xm = self.linear_fwd(prefix + ".attn.proj.weight", prefix + ".attn.proj.bias", o, Dm, Dm, N, res=x)
         h2, mr2 = self.ln_fwd(prefix + ".norm2", xm, Dm, N, 1e-5)
         f1 = self.linear_fwd(prefix + ".mlp.fc1.weight", prefix + ".mlp.fc1.bias", h2, Dm, hidden, N)
@@ -242,7 +243,7 @@ class _V:
         a1 = p.alloc("gelu:" + prefix, (B, hidden, N))
         p.fwd.add("ACT_FWD", X=f1, Y=a1, COUNT=B * hidden * N, ACT=D.ACT_GELU)
         xo = self.linear_fwd(prefix + ".mlp.fc2.weight", prefix + ".mlp.fc2.bias", a1, hidden, Dm, N, res=xm)
-        return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, xm=xm, h2=h2, mr2=mr2, f1=f1, a1=a1, Dm=Dm, heads=heads,
+        return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, lse=lse, xm=xm, h2=h2, mr2=mr2, f1=f1, a1=a1, Dm=Dm, heads=heads,
                         hidden=hidden, N=N)
 
     def block_bwd(self, r: dict, g: TRef) -> None:
@@ -259,7 +260,8 @@ class _V:
         g_o = p.alloc("g:o:" + pre, (B, Dm, N))
         self.linear_bwd(pre + ".attn.proj.weight", pre + ".attn.proj.bias", r["o"], g, Dm, Dm, N, dx=g_o)
         g_qkv = p.alloc("g:qkv:" + pre, (B, 3 * Dm, N))
-        p.bwd.add("ATTN_BWD", QKV=r["qkv"], DO=g_o, DQKV=g_qkv, B=B, HEADS=heads, HD=Dm // heads, L=N, SCALE=float(Dm // heads) ** -0.5)
+        p.bwd.add("ATTN_BWD", QKV=r["qkv"], DO=g_o, DQKV=g_qkv, O=r["o"], LSE=r["lse"], DELTA=p.alloc("delta:" + pre, (B, heads, N)),
+                  B=B, HEADS=heads, HD=Dm // heads, L=N, LS=N, SCALE=float(Dm // heads) ** -0.5)
         self.linear_bwd(pre + ".attn.qkv.weight", pre + ".attn.qkv.bias", r["h1"], g_qkv, Dm, 3 * Dm, N, dx=g_h)
         self.ln_bwd(pre + ".norm1", g_h, r["x"], r["mr1"], g, Dm, N, accum=1)
 

@@ -97,24 +97,45 @@ def test_convt_wgrad_with_gelu_operand():
           H=2 * H, W=2 * H, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=D.PRO_GELU, PROQ=D.PRO_NONE, MODE=D.MODE_GATHER2X2)
 
 
-ATTN = [(2, 2, 16, 17), (2, 2, 8, 50), (1, 3, 64, 197), (1, 2, 32, 197), (2, 2, 64, 50), (1, 1, 64, 224), (1, 2, 32, 33), (1, 1, 5, 3)]
+# (B, heads, head dim, tokens, row stride; 0 = tokens)
+ATTN = [(2, 2, 16, 17, 0), (2, 2, 8, 50, 0), (1, 3, 64, 197, 0), (1, 2, 32, 197, 0), (2, 2, 64, 50, 0), (1, 1, 64, 224, 0), (1, 2, 32, 33, 0),
+        (1, 1, 5, 3, 0), (2, 2, 32, 50, 52), (1, 2, 64, 197, 200), (1, 2, 32, 197, 200), (2, 2, 16, 17, 20), (1, 1, 32, 300, 0),
+        (1, 2, 64, 260, 264), (1, 1, 7, 1, 4)]
 
 
-@pytest.mark.parametrize("B,H,HD,L", ATTN)
-def test_attn_fwd(B, H, HD, L):
+def _attn_reference(qkv, B, H, HD, L, scale):
+    t = qkv[..., :L].double().reshape(B, 3, H, HD, L).permute(1, 0, 2, 4, 3)
+    s = (t[0] @ t[1].transpose(-2, -1)) * scale
+    return (torch.softmax(s, -1) @ t[2]).permute(0, 1, 3, 2), torch.logsumexp(s, -1)   # [B,H,HD,L], [B,H,L]
+
+
+@pytest.mark.parametrize("B,H,HD,L,LS", ATTN)
+def test_attn_fwd(B, H, HD, L, LS):
     c = Case(7)
-    qkv = c.t("qkv", (B, 3 * H * HD, L))
-    o = c.t("o", (B, H * HD, L), "nan")
-    c.run("ATTN_FWD", ["o"], tol=1e-4, QKV=qkv, O=o, B=B, HEADS=H, HD=HD, L=L, SCALE=HD ** -0.5)
+    S = LS or L
+    qkv = c.t("qkv", (B, 3 * H * HD, S))
+    o = c.t("o", (B, H * HD, S), "nan")
+    lse = c.t("lse", (B, H, S), "nan")
+    c.run("ATTN_FWD", ["o", "lse"], tol=1e-4, QKV=qkv, O=o, LSE=lse, B=B, HEADS=H, HD=HD, L=L, LS=LS, SCALE=HD ** -0.5)
 
 
-@pytest.mark.parametrize("B,H,HD,L", ATTN)
-def test_attn_bwd(B, H, HD, L):
+@pytest.mark.parametrize("B,H,HD,L,LS", ATTN)
+def test_attn_bwd(B, H, HD, L, LS):
+    """the backward reads the forward's O and log-sum-exp back; row padding (columns L..LS-1) comes out as zeros"""
     c = Case(8)
-    qkv = c.t("qkv", (B, 3 * H * HD, L))
-    do = c.t("do", (B, H * HD, L))
-    dqkv = c.t("dqkv", (B, 3 * H * HD, L), "nan")
-    c.run("ATTN_BWD", ["dqkv"], tol=2e-4, QKV=qkv, DO=do, DQKV=dqkv, B=B, HEADS=H, HD=HD, L=L, SCALE=HD ** -0.5)
+    S = LS or L
+    qd = torch.randn(B, 3 * H * HD, S, generator=c.gen)
+    od, ld = _attn_reference(qd, B, H, HD, L, HD ** -0.5)
+    o_full, l_full = torch.zeros(B, H, HD, S), torch.zeros(B, H, S)
+    o_full[..., :L], l_full[..., :L] = od.float(), ld.float()
+    qkv = c.t("qkv", (B, 3 * H * HD, S), qd)
+    o = c.t("o", (B, H * HD, S), o_full.reshape(B, H * HD, S))
+    lse = c.t("lse", (B, H, S), l_full)
+    do = c.t("do", (B, H * HD, S))
+    dqkv = c.t("dqkv", (B, 3 * H * HD, S), "nan")
+    delta = c.t("delta", (B, H, S), "nan")
+    c.run("ATTN_BWD", ["dqkv"], tol=2e-4, QKV=qkv, DO=do, DQKV=dqkv, O=o, LSE=lse, DELTA=delta, B=B, HEADS=H, HD=HD, L=L, LS=LS,
+          SCALE=HD ** -0.5)
 
 
 @pytest.mark.parametrize("B,L,keep,ties", [(3, 196, 49, False), (2, 196, 196, False), (2, 16, 4, True), (1, 588, 147, False), (2, 7, 0, False)])

@@ -59,11 +59,12 @@ def main():
                      STATS2=None if a.nostats or not a.pro else st, BETA=0, NREP=nrep, **geo)
         flops = 4.0 * B * C * (H * H + HO * HO) * 1000   # "TF/s" column = TB/s of (in + out) bytes
     elif a.what.startswith("wgrad"):
-        P = ar.alloc("p", (B, M, H, H)); Q = ar.alloc("q", (B, C, H, H)); bq = ar.alloc("bnv", (4, C))
+        Hh, Wd = (1, a.N) if a.N else (H, H)
+        P = ar.alloc("p", (B, M, Hh, Wd)); Q = ar.alloc("q", (B, C, Hh, Wd)); bq = ar.alloc("bnv", (4, C))
         wgs = ar.alloc("wgs", (T, M, C))
         prog.add("WGRAD", P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bq if a.pro else None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C,
-                 H=H, W=H, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=H, PROP=0, PROQ=a.pro, MODE=0)
-        flops = 2.0 * M * C * T * B * H * H
+                 H=Hh, W=Wd, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=Hh, WO=Wd, PROP=0, PROQ=a.pro, MODE=0)
+        flops = 2.0 * M * C * T * B * Hh * Wd
     else:
         Wd = H
         if a.N:
@@ -76,7 +77,7 @@ def main():
                  SCRATCH=scr, B=B, C1=C,
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
-        flops = 2.0 * M * C * T * B * H * (Wd if not a.what.startswith('wgrad') else H)
+        flops = 2.0 * M * C * T * B * H * Wd
     buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * 0.5).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)
     packed = prog.pack()
