@@ -508,7 +508,8 @@ def op_mae_mask_index(m: Mem, o):
 
 def op_token_gather(m: Mem, o):
     B, C, Lin, Lout = o["B"], o["C"], o["LIN"], o["LOUT"]
-    src = m.view(o["IN"], (B, C, Lin))
+    LinS, LoutS = o.get("LIN_S", 0) or Lin, o.get("LOUT_S", 0) or Lout   # row strides; padding columns of OUT := 0
+    src = m.view(o["IN"], (B, C, LinS))[..., :Lin]
     idx = m.view(o["IDX"], (B, Lout), "i32").long()
     fill = m.view(o["FILL"], (C,))
     got = torch.gather(src, 2, idx.clamp(min=0).unsqueeze(1).expand(-1, C, -1))
@@ -519,14 +520,17 @@ def op_token_gather(m: Mem, o):
         nrows = int(prow.max().item()) + 1
         pos = m.view(o["POS"], (nrows, C))
         got = got + pos[prow].permute(0, 2, 1)
-    m.view(o["OUT"], (B, C, Lout)).copy_(got)
+    out = m.view(o["OUT"], (B, C, LoutS))
+    out.zero_()
+    out[..., :Lout].copy_(got)
 
 
 def op_token_scatter(m: Mem, o):
     B, C, Lin, Lout = o["B"], o["C"], o["LIN"], o["LOUT"]
-    dout = m.view(o["DOUT"], (B, C, Lout))
+    LinS, LoutS = o.get("LIN_S", 0) or Lin, o.get("LOUT_S", 0) or Lout
+    dout = m.view(o["DOUT"], (B, C, LoutS))[..., :Lout]
     idx = m.view(o["IDX"], (B, Lout), "i32").long()
-    din = m.view(o["DIN"], (B, C, Lin))
+    din = m.view(o["DIN"], (B, C, LinS))
     din.zero_()
     valid = idx >= 0
     for b in range(B):

@@ -305,18 +305,22 @@ struct TokP {
     const int* idx;
     float *out, *din, *dfill;
     int B, C, Lin, Lout, pos_by_src, pos_off;
+    int LinS, LoutS;   // row strides (>= Lin / Lout); columns Lout..LoutS-1 of OUT and Lin..LinS-1 of DIN are written as zeros
 };
 
 __global__ void token_gather_kernel(const TokP p) {
-    const int64_t n = (int64_t)p.B * p.C * p.Lout;
+    const int64_t n = (int64_t)p.B * p.C * p.LoutS;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int j = (int)(i % p.Lout);
-        const int64_t bc = i / p.Lout;
-        const int cc = (int)(bc % p.C), b = (int)(bc / p.C);
-        const int src = p.idx[(int64_t)b * p.Lout + j];
-        float v = src >= 0 ? p.in[bc * p.Lin + src] : (p.fill ? p.fill[cc] : 0.0f);
-        if (p.pos) v += p.pos[(int64_t)(p.pos_by_src ? src + p.pos_off : j) * p.C + cc];
+        const int j = (int)(i % p.LoutS);
+        const int64_t bc = i / p.LoutS;
+        float v = 0.0f;
+        if (j < p.Lout) {
+            const int cc = (int)(bc % p.C), b = (int)(bc / p.C);
+            const int src = p.idx[(int64_t)b * p.Lout + j];
+            v = src >= 0 ? p.in[bc * p.LinS + src] : (p.fill ? p.fill[cc] : 0.0f);
+            if (p.pos) v += p.pos[(int64_t)(p.pos_by_src ? src + p.pos_off : j) * p.C + cc];
+        }
         p.out[i] = v;
     }
 }
@@ -331,8 +335,12 @@ int launch_token_gather(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("token_gather", p.in, p.idx, p.fill, p.pos, p.out);
     p.B = op.d[S2K_TOKEN_GATHER_D_B]; p.C = op.d[S2K_TOKEN_GATHER_D_C]; p.Lin = op.d[S2K_TOKEN_GATHER_D_LIN];
     p.Lout = op.d[S2K_TOKEN_GATHER_D_LOUT]; p.pos_by_src = op.d[S2K_TOKEN_GATHER_D_POS_BY_SRC]; p.pos_off = op.d[S2K_TOKEN_GATHER_D_POS_OFF];
-    if (!p.in || !p.idx || !p.out || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0) { set_error("token_gather: bad args"); return S2K_EINVAL; }
-    const int64_t n = (int64_t)p.B * p.C * p.Lout;
+    p.LinS = op.d[S2K_TOKEN_GATHER_D_LIN_S] > 0 ? op.d[S2K_TOKEN_GATHER_D_LIN_S] : p.Lin;
+    p.LoutS = op.d[S2K_TOKEN_GATHER_D_LOUT_S] > 0 ? op.d[S2K_TOKEN_GATHER_D_LOUT_S] : p.Lout;
+    if (!p.in || !p.idx || !p.out || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0 || p.LinS < p.Lin || p.LoutS < p.Lout) {
+        set_error("token_gather: bad args"); return S2K_EINVAL;
+    }
+    const int64_t n = (int64_t)p.B * p.C * p.LoutS;
     hipLaunchKernelGGL(token_gather_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, p);
     return S2K_OK;
 }
@@ -340,27 +348,27 @@ int launch_token_gather(const S2kOp& op, const Ctx& c) {
 // one wave per (b, c) row: the row of DIN is assembled in LDS (zero, scatter, copy out), the gradient of the fill
 // token is a wave sum + one atomic per row
 __global__ void __launch_bounds__(NTHREADS) token_scatter_kernel(const TokP p) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];   // [4][Lin]
+    extern __shared__ __attribute__((aligned(16))) float rows[];   // [4][LinS]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* row = rows + (size_t)wave * p.Lin;
+    float* row = rows + (size_t)wave * p.LinS;
     const int64_t nrows = (int64_t)p.B * p.C;
     for (int64_t r0 = (int64_t)blockIdx.x * 4; r0 < nrows; r0 += (int64_t)gridDim.x * 4) {
         const int64_t r = r0 + wave;
         const bool ok = r < nrows;
         const int b = ok ? (int)(r / p.C) : 0, cc = ok ? (int)(r % p.C) : 0;
-        for (int i = lane; i < p.Lin; i += 64) row[i] = 0.0f;
+        for (int i = lane; i < p.LinS; i += 64) row[i] = 0.0f;
         __syncthreads();
         float acc = 0.0f;
         if (ok)
             for (int j = lane; j < p.Lout; j += 64) {
                 const int dst = p.idx[(int64_t)b * p.Lout + j];
-                const float v = p.dout[r * p.Lout + j];
+                const float v = p.dout[r * p.LoutS + j];
                 if (dst >= 0) row[dst] = v;
                 else acc += v;
             }
         __syncthreads();
         if (ok)
-            for (int i = lane; i < p.Lin; i += 64) p.din[r * p.Lin + i] = row[i];
+            for (int i = lane; i < p.LinS; i += 64) p.din[r * p.LinS + i] = row[i];
         if (p.dfill) {
             acc = wave_sum_hi(acc);
             if (ok && lane == 63) atomicAdd(p.dfill + cc, acc);
@@ -377,9 +385,13 @@ int launch_token_scatter(const S2kOp& op, const Ctx& c) {
     p.dfill = ref_ptr<float>(c, op.t[S2K_TOKEN_SCATTER_T_DFILL]);
     CHECK_PTRS("token_scatter", p.dout, p.idx, p.din, p.dfill);
     p.B = op.d[S2K_TOKEN_SCATTER_D_B]; p.C = op.d[S2K_TOKEN_SCATTER_D_C]; p.Lin = op.d[S2K_TOKEN_SCATTER_D_LIN]; p.Lout = op.d[S2K_TOKEN_SCATTER_D_LOUT];
-    if (!p.dout || !p.idx || !p.din || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0 || p.Lin > 4096) { set_error("token_scatter: bad args"); return S2K_EINVAL; }
+    p.LinS = op.d[S2K_TOKEN_SCATTER_D_LIN_S] > 0 ? op.d[S2K_TOKEN_SCATTER_D_LIN_S] : p.Lin;
+    p.LoutS = op.d[S2K_TOKEN_SCATTER_D_LOUT_S] > 0 ? op.d[S2K_TOKEN_SCATTER_D_LOUT_S] : p.Lout;
+    if (!p.dout || !p.idx || !p.din || p.B <= 0 || p.C <= 0 || p.Lin <= 0 || p.Lout <= 0 || p.LinS > 4096 || p.LinS < p.Lin || p.LoutS < p.Lout) {
+        set_error("token_scatter: bad args"); return S2K_EINVAL;
+    }
     const int64_t nrows = (int64_t)p.B * p.C;
-    hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nrows, 4), 4096)), dim3(NTHREADS), (size_t)4 * p.Lin * sizeof(float), c.stream, p);
+    hipLaunchKernelGGL(token_scatter_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(nrows, 4), 4096)), dim3(NTHREADS), (size_t)4 * p.LinS * sizeof(float), c.stream, p);
     return S2K_OK;
 }
 

@@ -133,9 +133,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "MAE_MASK_INDEX": (["NOISE", "IDS_RESTORE", "MASK", "ENC_IDX", "DEC_IDX"], [], ["B", "L", "KEEP"], []),
     # OUT[b][c][j] = (i = IDX[b][j]) >= 0 ? IN[b][c][i] : FILL[c];  then + POS[(POS_BY_SRC ? i + POS_OFF : j) * C + c]
     # (POS is token-major, as the reference's pos_embed parameters)
-    "TOKEN_GATHER": (["IN", "IDX", "FILL", "POS", "OUT"], [], ["B", "C", "LIN", "LOUT", "POS_BY_SRC", "POS_OFF"], []),
+    "TOKEN_GATHER": (["IN", "IDX", "FILL", "POS", "OUT"], [], ["B", "C", "LIN", "LOUT", "POS_BY_SRC", "POS_OFF", "LIN_S", "LOUT_S"], []),
     # DIN[b][c][i] = DOUT[b][c][j] for i = IDX[b][j] >= 0 (other DIN entries zero);  DFILL[c] += sum_{b, j: IDX < 0} DOUT[b][c][j]
-    "TOKEN_SCATTER": (["DOUT", "IDX", "DIN", "DFILL"], [], ["B", "C", "LIN", "LOUT"], []),
+    "TOKEN_SCATTER": (["DOUT", "IDX", "DIN", "DFILL"], [], ["B", "C", "LIN", "LOUT", "LIN_S", "LOUT_S"], []),
     # im2col of non-overlapping patches (PatchEmbed's Conv3d as a GEMM):
     #   OUT[b][((c*TUB + tt)*P + py)*P + px][(t, h, w)] = X[b][c][t*TUB + tt][h*P + py][w*P + px]
     "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB"], []),

@@ -11,6 +11,13 @@ Layout: ViT activations are FEATURE-MAJOR, [B][C][L] — tokens take the place o
   * q/k/v rows of one head are [hd][L] tiles that feed the MFMA operands of QK^T and PV without a transpose,
   * the neck consumes the encoder output as [B][768][14][14] directly.
 The reference's token-major tensors (pred, latent) are produced by a TRANSPOSE_CL stage at the API boundary.
+
+Token rows are padded to a multiple of 4 floats ([B][C][NS], NS = row_stride(N)): 50 -> 52 (MAE encoder), 197 -> 200, so
+that every row is 16-byte aligned and the conv / attention stagers use their vector loads.  The padding columns are
+ordinary pixels to the conv / LayerNorm / activation stages (finite values, 1.5-4 % extra work); attention ignores
+them as keys and writes zeros for them; every gradient tensor is exactly zero there (the loss, token-scatter and
+attention backward stages write zeros, all other backward stages map zero columns to zero columns), so weight,
+bias and LayerNorm-parameter gradients summed over NS columns equal the sums over the N real tokens.
 """
 from __future__ import annotations
 
@@ -167,6 +174,10 @@ def seg_layout(s: SegSpec) -> ParamLayout:
     return L
 
 
+def row_stride(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
 # ---- building blocks ----------------------------------------------------------------------------------
 class _V:
     """ViT emission helpers on top of the shared planner state."""
@@ -227,14 +238,16 @@ class _V:
                   B=B, C=C, HW=N, ACCUM=accum)
 
     # timm Block on [B][Dm][N] ------------------------------------------------------------------------
-    def block_fwd(self, prefix: str, x: TRef, Dm: int, heads: int, hidden: int, N: int) -> tuple[TRef, dict]:
+    def block_fwd(self, prefix: str, x: TRef, Dm: int, heads: int, hidden: int, L: int) -> tuple[TRef, dict]:
+        """L real tokens in rows of N = row_stride(L) floats."""
         p, B = self.p, self.p.B
         hd = Dm // heads
+        N = row_stride(L)
         h1, mr1 = self.ln_fwd(prefix + ".norm1", x, Dm, N, 1e-5)
         qkv = self.linear_fwd(prefix + ".attn.qkv.weight", prefix + ".attn.qkv.bias", h1, Dm, 3 * Dm, N)
         o = p.alloc("attn:" + prefix, (B, Dm, N))
         lse = p.alloc("lse:" + prefix, (B, heads, N))
-        p.fwd.add("ATTN_FWD", QKV=qkv, O=o, LSE=lse, B=B, HEADS=heads, HD=hd, L=N, LS=N, SCALE=float(hd) ** -0.5)
+        p.fwd.add("ATTN_FWD", QKV=qkv, O=o, LSE=lse, B=B, HEADS=heads, HD=hd, L=L, LS=N, SCALE=float(hd) ** -0.5)
         xm = self.linear_fwd(prefix + ".attn.proj.weight", prefix + ".attn.proj.bias", o, Dm, Dm, N, res=x)
         h2, mr2 = self.ln_fwd(prefix + ".norm2", xm, Dm, N, 1e-5)
         f1 = self.linear_fwd(prefix + ".mlp.fc1.weight", prefix + ".mlp.fc1.bias", h2, Dm, hidden, N)
@@ -244,7 +257,7 @@ class _V:
         p.fwd.add("ACT_FWD", X=f1, Y=a1, COUNT=B * hidden * N, ACT=D.ACT_GELU)
         xo = self.linear_fwd(prefix + ".mlp.fc2.weight", prefix + ".mlp.fc2.bias", a1, hidden, Dm, N, res=xm)
         return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, lse=lse, xm=xm, h2=h2, mr2=mr2, f1=f1, a1=a1, Dm=Dm, heads=heads,
-                        hidden=hidden, N=N)
+                        hidden=hidden, N=N, L=L)
 
     def block_bwd(self, r: dict, g: TRef) -> None:
         """g = gradient of the block output, [B][Dm][N]; on return it holds the gradient of the block INPUT (the
@@ -261,13 +274,13 @@ class _V:
         self.linear_bwd(pre + ".attn.proj.weight", pre + ".attn.proj.bias", r["o"], g, Dm, Dm, N, dx=g_o)
         g_qkv = p.alloc("g:qkv:" + pre, (B, 3 * Dm, N))
         p.bwd.add("ATTN_BWD", QKV=r["qkv"], DO=g_o, DQKV=g_qkv, O=r["o"], LSE=r["lse"], DELTA=p.alloc("delta:" + pre, (B, heads, N)),
-                  B=B, HEADS=heads, HD=Dm // heads, L=N, LS=N, SCALE=float(Dm // heads) ** -0.5)
+                  B=B, HEADS=heads, HD=Dm // heads, L=r["L"], LS=N, SCALE=float(Dm // heads) ** -0.5)
         self.linear_bwd(pre + ".attn.qkv.weight", pre + ".attn.qkv.bias", r["h1"], g_qkv, Dm, 3 * Dm, N, dx=g_h)
         self.ln_bwd(pre + ".norm1", g_h, r["x"], r["mr1"], g, Dm, N, accum=1)
 
 
 def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int, outs: dict, need_input_grads: bool):
-    """forward_encoder (prithvi.py:285-305).  Returns (latent [B][Dm][N], N, record for the backward)."""
+    """forward_encoder (prithvi.py:285-305).  Returns (latent [B][Dm][row_stride(N)], N, record for the backward)."""
     p, B = v.p, v.p.B
     C, T, Hh, P, tub = s.in_chans, s.num_frames, s.img_size, s.patch_size, s.tubelet_size
     Lp, Dm = s.num_patches, s.embed_dim
@@ -280,29 +293,32 @@ def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int
     p.fwd.add("MAE_MASK_INDEX", NOISE=noise, IDS_RESTORE=outs["ids_restore"], MASK=outs["mask"], ENC_IDX=enc_idx, DEC_IDX=dec_idx,
               B=B, L=Lp, KEEP=keep)
     N = 1 + keep
-    x0 = p.alloc("x0:" + prefix, (B, Dm, N))
+    NS = row_stride(N)
+    x0 = p.alloc("x0:" + prefix, (B, Dm, NS))
     p.fwd.add("TOKEN_GATHER", IN=pe, IDX=enc_idx, FILL=p.param(prefix + "cls_token"), POS=p.param(prefix + "pos_embed"), OUT=x0,
-              B=B, C=Dm, LIN=Lp, LOUT=N, POS_BY_SRC=1, POS_OFF=1)
+              B=B, C=Dm, LIN=Lp, LOUT=N, POS_BY_SRC=1, POS_OFF=1, LIN_S=Lp, LOUT_S=NS)
     recs = []
     x = x0
     for i in range(s.depth):
         x, r = v.block_fwd(f"{prefix}blocks.{i}", x, Dm, s.num_heads, int(Dm * s.mlp_ratio), N)
         recs.append(r)
-    latent, mr = v.ln_fwd(prefix + "norm", x, Dm, N, 1e-5)
-    rec = dict(prefix=prefix, cols=cols, pe=pe, enc_idx=enc_idx, dec_idx=dec_idx, x_last=x, mr=mr, blocks=recs, N=N, Kp=Kp, Lp=Lp, Dm=Dm)
+    latent, mr = v.ln_fwd(prefix + "norm", x, Dm, NS, 1e-5)
+    rec = dict(prefix=prefix, cols=cols, pe=pe, enc_idx=enc_idx, dec_idx=dec_idx, x_last=x, mr=mr, blocks=recs, N=N, NS=NS, Kp=Kp, Lp=Lp,
+               Dm=Dm)
     return latent, N, rec
 
 
 def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef):
-    """g_latent: gradient of the normalised encoder output [B][Dm][N] (consumed)."""
+    """g_latent: gradient of the normalised encoder output [B][Dm][NS] (consumed; zero in the padding columns)."""
     p, B = v.p, v.p.B
-    prefix, N, Dm, Lp, Kp = rec["prefix"], rec["N"], rec["Dm"], rec["Lp"], rec["Kp"]
-    g = p.alloc("g:enc:" + prefix, (B, Dm, N))
-    v.ln_bwd(prefix + "norm", g_latent, rec["x_last"], rec["mr"], g, Dm, N, accum=0)
+    prefix, N, NS, Dm, Lp, Kp = rec["prefix"], rec["N"], rec["NS"], rec["Dm"], rec["Lp"], rec["Kp"]
+    g = p.alloc("g:enc:" + prefix, (B, Dm, NS))
+    v.ln_bwd(prefix + "norm", g_latent, rec["x_last"], rec["mr"], g, Dm, NS, accum=0)
     for r in reversed(rec["blocks"]):
         v.block_bwd(r, g)
     g_pe = p.alloc("g:pe:" + prefix, (B, Dm, Lp))
-    p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token"), B=B, C=Dm, LIN=Lp, LOUT=N)
+    p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token"), B=B, C=Dm, LIN=Lp, LOUT=N,
+              LIN_S=Lp, LOUT_S=NS)
     v.linear_bwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", rec["cols"], g_pe, Kp, Dm, Lp)
 
 
@@ -334,40 +350,43 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
     _out(outs, cur, "ids_restore", (B, Lp), "i64")
     latent, N, erec = _encoder(v, s, "", x_img, noise, keep, outs, True)
     _out(outs, cur, "latent", (B, N, Dm))
-    p.fwd.add("TRANSPOSE_CL", X=latent, Y=outs["latent"], B=B, C=Dm, L=N, L_OFF=0, LOUT=N)
+    NS = erec["NS"]
+    p.fwd.add("TRANSPOSE_CL", X=latent, Y=outs["latent"], B=B, C=Dm, L=NS, L_OFF=0, LOUT=N)
     # decoder (:307-331)
-    dx = v.linear_fwd("decoder_embed.weight", "decoder_embed.bias", latent, Dm, Dd, N)
+    dx = v.linear_fwd("decoder_embed.weight", "decoder_embed.bias", latent, Dm, Dd, NS)
     ND = Lp + 1
-    y0 = p.alloc("y0", (B, Dd, ND))
+    NDS = row_stride(ND)
+    y0 = p.alloc("y0", (B, Dd, NDS))
     p.fwd.add("TOKEN_GATHER", IN=dx, IDX=erec["dec_idx"], FILL=p.param("mask_token"), POS=p.param("decoder_pos_embed"), OUT=y0,
-              B=B, C=Dd, LIN=N, LOUT=ND, POS_BY_SRC=0, POS_OFF=0)
+              B=B, C=Dd, LIN=N, LOUT=ND, POS_BY_SRC=0, POS_OFF=0, LIN_S=NS, LOUT_S=NDS)
     drecs = []
     y = y0
     for i in range(s.decoder_depth):
         y, r = v.block_fwd(f"decoder_blocks.{i}", y, Dd, s.decoder_num_heads, int(Dd * s.mlp_ratio), ND)
         drecs.append(r)
-    yn, mrd = v.ln_fwd("decoder_norm", y, Dd, ND, 1e-5)
-    pred_fm = v.linear_fwd("decoder_pred.weight", "decoder_pred.bias", yn, Dd, PD, ND)
-    p.fwd.add("TRANSPOSE_CL", X=pred_fm, Y=outs["pred"], B=B, C=PD, L=ND, L_OFF=1, LOUT=Lp)
+    yn, mrd = v.ln_fwd("decoder_norm", y, Dd, NDS, 1e-5)
+    pred_fm = v.linear_fwd("decoder_pred.weight", "decoder_pred.bias", yn, Dd, PD, NDS)
+    p.fwd.add("TRANSPOSE_CL", X=pred_fm, Y=outs["pred"], B=B, C=PD, L=NDS, L_OFF=1, LOUT=Lp)
     acc = p.aux.alloc("mae_acc", (2,), "f64")
-    geo = dict(B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size, TUB=s.tubelet_size, LP=ND, L_OFF=1,
+    geo = dict(B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size, TUB=s.tubelet_size, LP=NDS, L_OFF=1,
                NORM_PIX=int(s.norm_pix_loss))
     p.fwd.add("MAE_LOSS_FWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], LOSS=outs["loss"], ACC=acc, **geo)
 
     def backward():
         gout = TRef(D.BASE["DOUT"], 0, (1,), "f32", "dloss")
-        g_pred = p.alloc("g:pred", (B, PD, ND))
+        g_pred = p.alloc("g:pred", (B, PD, NDS))
         p.bwd.add("MAE_LOSS_BWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], ACC=acc, GOUT=gout, DPRED=g_pred, **geo)
-        g_yn = p.alloc("g:yn", (B, Dd, ND))
-        v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, ND, dx=g_yn)
-        g = p.alloc("g:dec", (B, Dd, ND))
-        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, ND, accum=0)
+        g_yn = p.alloc("g:yn", (B, Dd, NDS))
+        v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, NDS, dx=g_yn)
+        g = p.alloc("g:dec", (B, Dd, NDS))
+        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0)
         for r in reversed(drecs):
             v.block_bwd(r, g)
-        g_dx = p.alloc("g:dx", (B, Dd, N))
-        p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=erec["dec_idx"], DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND)
-        g_lat = p.alloc("g:latent", (B, Dm, N))
-        v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, N, dx=g_lat)
+        g_dx = p.alloc("g:dx", (B, Dd, NS))
+        p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=erec["dec_idx"], DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND,
+                  LIN_S=NS, LOUT_S=NDS)
+        g_lat = p.alloc("g:latent", (B, Dm, NS))
+        v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, NS, dx=g_lat)
         _encoder_bwd(v, s, erec, g_lat)
 
     p.tape.append(backward)
@@ -404,7 +423,9 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
     # neck (:66-72): drop cls, tokens -> [B][E][g][g]
     drop_idx = p.const_table([[j + 1 for j in range(Lp)] for _ in range(B)], Lp)
     t0 = p.alloc("neck_in", (B, Dm, Lp))
-    p.fwd.add("TOKEN_GATHER", IN=latent, IDX=drop_idx, FILL=None, POS=None, OUT=t0, B=B, C=Dm, LIN=N, LOUT=Lp, POS_BY_SRC=0, POS_OFF=0)
+    NS = erec["NS"]
+    p.fwd.add("TOKEN_GATHER", IN=latent, IDX=drop_idx, FILL=None, POS=None, OUT=t0, B=B, C=Dm, LIN=N, LOUT=Lp, POS_BY_SRC=0, POS_OFF=0,
+              LIN_S=NS, LOUT_S=Lp)
     a0 = Act(t0, Dm, g, g, needs_grad=(training and not frozen))
     nk = "neck.feature_pyramid_net."
 
@@ -427,8 +448,8 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
     def encoder_tail_backward():
         if not (training and not frozen):
             return
-        g_lat = p.alloc("g:latent", (B, Dm, N))
-        p.bwd.add("TOKEN_SCATTER", DOUT=a0.grad, IDX=drop_idx, DIN=g_lat, DFILL=None, B=B, C=Dm, LIN=N, LOUT=Lp)
+        g_lat = p.alloc("g:latent", (B, Dm, NS))
+        p.bwd.add("TOKEN_SCATTER", DOUT=a0.grad, IDX=drop_idx, DIN=g_lat, DFILL=None, B=B, C=Dm, LIN=N, LOUT=Lp, LIN_S=NS, LOUT_S=Lp)
         _encoder_bwd(v, m, erec, g_lat)
 
     p.tape.append(encoder_tail_backward)

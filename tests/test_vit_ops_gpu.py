@@ -153,34 +153,36 @@ def test_mae_mask_index_exact(B, L, keep, ties):
           B=B, L=L, KEEP=keep)
 
 
-@pytest.mark.parametrize("by_src", [0, 1])
-def test_token_gather(by_src):
+@pytest.mark.parametrize("by_src,LinS,LoutS", [(0, 0, 0), (1, 0, 0), (1, 32, 24), (0, 30, 28)])
+def test_token_gather(by_src, LinS, LoutS):
+    """LIN_S / LOUT_S: row strides; the padding columns of OUT come out as zeros"""
     c = Case(10)
     B, C, Lin, Lout = 3, 40, 30, 23
-    src = c.t("in", (B, C, Lin))
+    src = c.t("in", (B, C, LinS or Lin))
     idxv = torch.stack([torch.randperm(Lin, generator=c.gen)[:Lout] for _ in range(B)])
     idxv[:, 0] = -1
     idxv[1, 5] = -1
     idx = c.t("idx", (B, Lout), idxv, "i32")
     fill = c.t("fill", (C,))
     pos = c.t("pos", (Lin + 1 if by_src else Lout, C))
-    out = c.t("out", (B, C, Lout), "nan")
+    out = c.t("out", (B, C, LoutS or Lout), "nan")
     c.run("TOKEN_GATHER", ["out"], tol=1e-6, IN=src, IDX=idx, FILL=fill, POS=pos, OUT=out, B=B, C=C, LIN=Lin, LOUT=Lout,
-          POS_BY_SRC=by_src, POS_OFF=1 if by_src else 0)
+          POS_BY_SRC=by_src, POS_OFF=1 if by_src else 0, LIN_S=LinS, LOUT_S=LoutS)
 
 
-@pytest.mark.parametrize("with_fill", [True, False])
-def test_token_scatter(with_fill):
+@pytest.mark.parametrize("with_fill,LinS,LoutS", [(True, 0, 0), (False, 0, 0), (True, 52, 32), (False, 50, 30)])
+def test_token_scatter(with_fill, LinS, LoutS):
     c = Case(11)
     B, C, Lin, Lout = 3, 37, 50, 29
-    dout = c.t("dout", (B, C, Lout))
+    dout = c.t("dout", (B, C, LoutS or Lout))
     idxv = torch.stack([torch.randperm(Lin, generator=c.gen)[:Lout] for _ in range(B)])
     idxv[:, 0] = -1
     idxv[2, 9] = -1
     idx = c.t("idx", (B, Lout), idxv, "i32")
-    din = c.t("din", (B, C, Lin), "nan")
+    din = c.t("din", (B, C, LinS or Lin), "nan")
     dfill = c.t("dfill", (C,), "randn") if with_fill else None
-    c.run("TOKEN_SCATTER", ["din"] + (["dfill"] if with_fill else []), tol=1e-5, DOUT=dout, IDX=idx, DIN=din, DFILL=dfill, B=B, C=C, LIN=Lin, LOUT=Lout)
+    c.run("TOKEN_SCATTER", ["din"] + (["dfill"] if with_fill else []), tol=1e-5, DOUT=dout, IDX=idx, DIN=din, DFILL=dfill, B=B, C=C, LIN=Lin,
+          LOUT=Lout, LIN_S=LinS, LOUT_S=LoutS)
 
 
 @pytest.mark.parametrize("B,C,T,H,P,TUB", [(2, 3, 1, 32, 8, 1), (1, 6, 1, 224, 16, 1), (2, 3, 3, 32, 8, 1), (1, 2, 4, 16, 4, 2)])
