@@ -342,7 +342,16 @@ def op_bn_bwd_finalize(m: Mem, o):
 def op_bn_bwd_apply(m: Mem, o):
     B, C, HW = o["B"], o["C"], o["HW"]
     gp, y = m.view(o["GP"], (B, C, HW)), m.view(o["Y"], (B, C, HW))
-    bnv, coef = m.view(o["BNV"], (4, C)), m.view(o["COEF"], (3, C))
+    bnv = m.view(o["BNV"], (4, C))
+    if o["COEF"] >= 0:
+        coef = m.view(o["COEF"], (3, C))
+    else:   # fused form: BN_BWD_FINALIZE's arithmetic
+        n = float(o["COUNT"])
+        st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
+        m.view(o["DGAMMA"], (C,)).add_(st[1].to(m.fdtype))
+        m.view(o["DBETA"], (C,)).add_(st[0].to(m.fdtype))
+        a = (m.view(o["GAMMA"], (C,)) * bnv[3]).double()
+        coef = torch.stack([a, -a * st[1] / n, -a * st[0] / n]).to(m.fdtype)
     xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
     dy = coef[0].view(1, C, 1) * gp + coef[1].view(1, C, 1) * xhat + coef[2].view(1, C, 1)
     m.view(o["DY"], (B, C, HW)).copy_(dy)

@@ -628,17 +628,45 @@ int launch_bn_bwd_finalize(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
-// MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY);  MODE 1: xout = (scale*y+shift)*dcs[b] + ident (BN_RESIDUAL)
+// the per-channel work of BN_BWD_FINALIZE done by the consumer: sums of g' and g'*xhat over the replicas -> coefficients;
+// the wave that owns the first chunk of sample 0 publishes the parameter gradients
+struct BnFuse {
+    const double* st2;
+    const float* gamma;
+    float *dgamma, *dbeta;
+    double count;
+    int nrep;
+};
+
+// MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY; MODE 2 = the same with the coefficients computed here from STATS2);
+// MODE 1: xout = (scale*y+shift)*dcs[b] + ident (BN_RESIDUAL)
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, const float* y, const float* bnv, const float* coef,
                                                              const float* noise, float* out, int C, int HW, int64_t nplanes,
-                                                             float keep) {
+                                                             float keep, const BnFuse fz) {
     Task t;
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
     const int c = (int)(t.plane % C);
     float k0, k1, k2;  // out = k0*a + k1*y + k2
-    if (MODE == 0) {
+    if (MODE == 2) {
+        double s1 = 0.0, s2 = 0.0;
+        if (fz.nrep <= 8) {   // wave-uniform addresses: scalar loads
+            for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+        } else {
+            for (int r = lane; r < fz.nrep; r += 64) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+            s1 = wave_sum_d(s1);
+            s2 = wave_sum_d(s2);
+        }
+        const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+        const double aa = (double)fz.gamma[c] * (double)invstd;
+        const float A = (float)aa, Bq = (float)(-aa * s2 / fz.count), Cq = (float)(-aa * s1 / fz.count);
+        k0 = A; k1 = Bq * invstd; k2 = Cq - Bq * invstd * mean;
+        if (t.plane < C && t.start == 0 && lane == 0) {
+            fz.dgamma[c] += (float)s2;
+            fz.dbeta[c] += (float)s1;
+        }
+    } else if (MODE == 0) {
         const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
         const float A = coef[c], Bq = coef[C + c], Cq = coef[2 * C + c];
         k0 = A; k1 = Bq * invstd; k2 = Cq - Bq * invstd * mean;
@@ -669,13 +697,13 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
 
 template <int MODE>
 static void launch_plane_map(const float* a, const float* y, const float* bnv, const float* coef, const float* noise, float* out,
-                             int B, int C, int HW, float keep, hipStream_t st) {
+                             int B, int C, int HW, float keep, hipStream_t st, const BnFuse& fz = BnFuse{}) {
     const int64_t nplanes = (int64_t)B * C;
     const unsigned blocks = task_blocks(HW, nplanes);
     if ((HW & 3) == 0)
-        hipLaunchKernelGGL((plane_map_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep);
+        hipLaunchKernelGGL((plane_map_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz);
     else
-        hipLaunchKernelGGL((plane_map_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep);
+        hipLaunchKernelGGL((plane_map_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz);
 }
 
 int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
@@ -684,9 +712,23 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     const float* bnv = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_BNV]);
     const float* coef = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_COEF]);
     float* dy = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DY]);
-    CHECK_PTRS("bn_bwd_apply", gp, y, bnv, coef, dy);
-    if (!gp || !y || !bnv || !coef || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
-    launch_plane_map<0>(gp, y, bnv, coef, nullptr, dy, op.d[S2K_BN_BWD_APPLY_D_B], op.d[S2K_BN_BWD_APPLY_D_C], op.d[S2K_BN_BWD_APPLY_D_HW], 1.0f, c.stream);
+    BnFuse fz{};
+    fz.st2 = ref_ptr<const double>(c, op.t[S2K_BN_BWD_APPLY_T_STATS2]);
+    fz.gamma = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_GAMMA]);
+    fz.dgamma = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DGAMMA]);
+    fz.dbeta = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DBETA]);
+    fz.count = (double)op.n[S2K_BN_BWD_APPLY_N_COUNT];
+    fz.nrep = op.d[S2K_BN_BWD_APPLY_D_NREP] > 0 ? op.d[S2K_BN_BWD_APPLY_D_NREP] : 1;
+    CHECK_PTRS("bn_bwd_apply", gp, y, bnv, coef, dy, fz.st2, fz.gamma, fz.dgamma, fz.dbeta);
+    if (!gp || !y || !bnv || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
+    const int B = op.d[S2K_BN_BWD_APPLY_D_B], C = op.d[S2K_BN_BWD_APPLY_D_C], HW = op.d[S2K_BN_BWD_APPLY_D_HW];
+    if (coef) {
+        launch_plane_map<0>(gp, y, bnv, coef, nullptr, dy, B, C, HW, 1.0f, c.stream);
+        return S2K_OK;
+    }
+    // no COEF table: the BN_BWD_FINALIZE arithmetic is done here (one launch less per BatchNorm)
+    if (!fz.st2 || !fz.gamma || !fz.dgamma || !fz.dbeta || fz.count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2, GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
+    launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
     return S2K_OK;
 }
 

@@ -98,7 +98,8 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
                       ["B", "C", "HW", "ACT", "NREP"], ["KEEP", "ADDSCALE"]),
     # DGAMMA += S2; DBETA += S1; COEF = {A, Bq, Cq}[C] with dY = A*g' + Bq*xhat + Cq
     "BN_BWD_FINALIZE": (["STATS2", "GAMMA", "BNV", "DGAMMA", "DBETA", "COEF"], ["COUNT"], ["C", "NREP"], []),
-    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY"], [], ["B", "C", "HW"], []),
+    # COEF null: the FINALIZE arithmetic is done inside (from STATS2 / GAMMA / COUNT / NREP; DGAMMA, DBETA += the sums)
+    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA"], ["COUNT"], ["B", "C", "HW", "NREP"], []),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"], [], ["B", "C", "HW"], ["KEEP"]),
     # OUT[c] += sum_{b,hw} G[b][c][hw]

@@ -239,11 +239,10 @@ def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: in
         gp = G if inplace else p.alloc("gp:" + prefix, (B, C, HW))
         p.bwd.add("BN_BWD_REDUCE", G=G, Y=y, BNV=bnv, MULBC=mulbc, ADDBC=addbc, NOISE=noise, GOUT=gp, STATS2=st2,
                   B=B, C=C, HW=HW, ACT=act, NREP=D.stats_replicas(C), KEEP=keep, ADDSCALE=addscale)
-    coef = p.alloc("coef:" + prefix, (3, C))
-    p.bwd.add("BN_BWD_FINALIZE", STATS2=st2, GAMMA=p.param(prefix + ".weight"), BNV=bnv,
-              DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COEF=coef,
-              COUNT=B * HW, C=C, NREP=D.stats_replicas(C))
-    p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=coef, DY=gp, B=B, C=C, HW=HW)
+    # the FINALIZE step (replica sums -> coefficients, dgamma / dbeta) runs inside APPLY: one launch less per BatchNorm
+    p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=p.param(prefix + ".weight"),
+              DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COUNT=B * HW, B=B, C=C, HW=HW,
+              NREP=D.stats_replicas(C))
     return gp
 
 

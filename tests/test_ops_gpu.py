@@ -374,6 +374,16 @@ def test_bn_backward_trio(B, C, HW, variant):
     bnv, coef = c3.bnv("bnv", C), c3.t("coef", (3, C))
     dy = c3.t("dy", (B, C, HW), "nan")
     c3.run("BN_BWD_APPLY", ["dy"], 1e-5, GP=gp, Y=y, BNV=bnv, COEF=coef, DY=dy, B=B, C=C, HW=HW)
+    # the form the planner emits: no COEF table, FINALIZE's arithmetic inside APPLY (replica sums, dgamma / dbeta)
+    for nrep in (2, 20):
+        c4 = Case(9)
+        gp, y = c4.t("gp", (B, C, HW)), c4.t("y", (B, C, HW))
+        bnv, gam = c4.bnv("bnv", C), c4.t("gamma", (C,), "pos")
+        st2 = c4.t("stats2", (nrep, 2, C), torch.randn(nrep, 2, C, dtype=torch.float64, generator=c4.gen) * 10, "f64")
+        dg, db = c4.t("dgamma", (C,)), c4.t("dbeta", (C,))
+        dy = c4.t("dy", (B, C, HW), "nan")
+        c4.run("BN_BWD_APPLY", ["dy", "dgamma", "dbeta"], 1e-5, GP=gp, Y=y, BNV=bnv, COEF=None, DY=dy, STATS2=st2, GAMMA=gam, DGAMMA=dg,
+               DBETA=db, COUNT=B * HW, B=B, C=C, HW=HW, NREP=nrep)
 
 
 @pytest.mark.parametrize("B,C,HW,ident,noise", [(2, 24, 256, True, True), (3, 10, 49, False, False), (1, 3, 9000, True, False)])
