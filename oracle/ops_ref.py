@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32}
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8}
 
 
 class Mem:
@@ -616,6 +616,33 @@ def op_confusion(m: Mem, o):
     m.view(o["HIST"], (C * C,), "i64").add_(torch.bincount(idx, minlength=C * C))
 
 
+def op_tile_prep(m: Mem, o):
+    """crop -> flips -> normalise (two separately rounded fp32 steps, as numpy's `img -= mean; img *= denominator`) + label LUT"""
+    B, C, H, W, S, N = o["B"], o["C"], o["H"], o["W"], o["S"], o["NSRC"]
+    raw = m.view(o["RAW"], (N, C, H, W), "i16")
+    par = m.view(o["PARAMS"], (B, 4), "i32")
+    norm = m.view(o["NORM"], (2, C)).to(torch.float32)
+    x = m.view(o["X"], (B, C, S, S))
+    y = m.view(o["Y"], (B, S, S), "i64")
+    lab = m.view(o["LABELS"], (N, H, W), "u8")
+    lut = m.view(o["LUT"], (256,), "i32")
+    for b in range(B):
+        src, y0, x0, fl = (int(v) for v in par[b])
+        img = raw[src, :, y0:y0 + S, x0:x0 + S].to(torch.float32)
+        msk = lab[src, y0:y0 + S, x0:x0 + S].long() if y is not None else None
+        if fl & 1:
+            img = img.flip(-1)
+            msk = msk.flip(-1) if msk is not None else None
+        if fl & 2:
+            img = img.flip(-2)
+            msk = msk.flip(-2) if msk is not None else None
+        img = img - norm[0].view(C, 1, 1)
+        img = img * norm[1].view(C, 1, 1)
+        x[b].copy_(img)
+        if y is not None:
+            y[b].copy_(lut[msk].long())
+
+
 def op_drop_gate(m: Mem, o):
     n = o["COUNT"]
     u = m.view(o["U"], (n,))
@@ -630,7 +657,7 @@ DISPATCH = {
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
-    "ATTN_BWD": op_attn_bwd, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
+    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
     "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }

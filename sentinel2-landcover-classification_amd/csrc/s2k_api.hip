@@ -58,6 +58,7 @@ int launch_mae_loss_bwd(const S2kOp&, const Ctx&);
 int launch_transpose_cl(const S2kOp&, const Ctx&);
 int launch_drop_gate(const S2kOp&, const Ctx&);
 int launch_confusion(const S2kOp&, const Ctx&);
+int launch_tile_prep(const S2kOp&, const Ctx&);
 int launch_adam(float*, const float*, float*, float*, int64_t, float, float, float, float, float, int, hipStream_t);
 int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
 
@@ -76,7 +77,7 @@ static const char* const kNames[S2K_N_KINDS + 1] = {
     nullptr, "MEMSET", "AXPY", "WEIGHT_PACK", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
     "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
     "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ACT_FWD", "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX",
-    "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "CONFUSION", "DROP_GATE"};
+    "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "CONFUSION", "DROP_GATE", "TILE_PREP"};
 
 static int dispatch(const S2kOp& op, const Ctx& c) {
     switch (op.kind) {
@@ -117,6 +118,7 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_TRANSPOSE_CL: return launch_transpose_cl(op, c);
         case S2K_OP_DROP_GATE: return launch_drop_gate(op, c);
         case S2K_OP_CONFUSION: return launch_confusion(op, c);
+        case S2K_OP_TILE_PREP: return launch_tile_prep(op, c);
         default: set_error("unknown stage kind %d", op.kind); return S2K_ENOSYS;
     }
 }

@@ -153,6 +153,12 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "CONFUSION": (["PRED", "LABELS", "HIST"], ["COUNT"], ["C"], []),
     # GATE[i] = (U[i] >= P) / (1 - P)   (Dropout2d: one draw per (sample, channel), applied as a channel gate of the next conv)
     "DROP_GATE": (["U", "GATE"], ["COUNT"], [], ["P"]),
+    # input pipeline (s2osm_dataset.py:51-71 + the albumentations Compose of s2osm_datamodule.py:75-87): for output sample b,
+    # PARAMS[b] = {src tile, y0, x0, flip bits (1 = horizontal, 2 = vertical)}:
+    #   X[b][c][i][j] = (float(RAW[src][c][y0 + i'][x0 + j']) - NORM[0][c]) * NORM[1][c],  i' = vflip ? S-1-i : i, j' likewise
+    #   Y[b][i][j]    = LUT[LABELS[src][y0 + i'][x0 + j']]     (int64; LUT has 256 int32 entries: the CNES remap, or identity)
+    # RAW int16 [NSRC][C][H][W], LABELS uint8 [NSRC][H][W]; subtract and multiply are separately rounded (numpy semantics)
+    "TILE_PREP": (["RAW", "LABELS", "PARAMS", "NORM", "LUT", "X", "Y"], [], ["B", "C", "H", "W", "S", "NSRC"], []),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 

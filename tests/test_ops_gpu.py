@@ -15,7 +15,7 @@ from s2lc_amd.plan.program import Arena, Program
 pytestmark = pytest.mark.gpu
 
 WS = D.BASE["WS"]
-_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32}
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8}
 
 
 class Case:

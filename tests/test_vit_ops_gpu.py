@@ -100,7 +100,7 @@ def test_convt_wgrad_with_gelu_operand():
 # (B, heads, head dim, tokens, row stride; 0 = tokens)
 ATTN = [(2, 2, 16, 17, 0), (2, 2, 8, 50, 0), (1, 3, 64, 197, 0), (1, 2, 32, 197, 0), (2, 2, 64, 50, 0), (1, 1, 64, 224, 0), (1, 2, 32, 33, 0),
         (1, 1, 5, 3, 0), (2, 2, 32, 50, 52), (1, 2, 64, 197, 200), (1, 2, 32, 197, 200), (2, 2, 16, 17, 20), (1, 1, 32, 300, 0),
-        (1, 2, 64, 260, 264), (1, 1, 7, 1, 4)]
+        (1, 2, 64, 260, 264), (1, 1, 7, 1, 4), (1, 2, 64, 589, 592)]   # 589 = 3 frames x 196 patches + cls
 
 
 def _attn_reference(qkv, B, H, HD, L, scale):
