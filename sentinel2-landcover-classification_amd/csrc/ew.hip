@@ -634,7 +634,7 @@ struct BnFuse {
     const double* st2;
     const float* gamma;
     float *dgamma, *dbeta;
-    double count;
+    double inv_count;
     int nrep;
 };
 
@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
         }
         const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
         const double aa = (double)fz.gamma[c] * (double)invstd;
-        const float A = (float)aa, Bq = (float)(-aa * s2 / fz.count), Cq = (float)(-aa * s1 / fz.count);
+        const float A = (float)aa, Bq = (float)(-aa * s2 * fz.inv_count), Cq = (float)(-aa * s1 * fz.inv_count);   // no f64 divide per wave
         k0 = A; k1 = Bq * invstd; k2 = Cq - Bq * invstd * mean;
         if (t.plane < C && t.start == 0 && lane == 0) {
             fz.dgamma[c] += (float)s2;
@@ -717,7 +717,8 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     fz.gamma = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_GAMMA]);
     fz.dgamma = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DGAMMA]);
     fz.dbeta = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DBETA]);
-    fz.count = (double)op.n[S2K_BN_BWD_APPLY_N_COUNT];
+    const double count = (double)op.n[S2K_BN_BWD_APPLY_N_COUNT];
+    fz.inv_count = count > 0 ? 1.0 / count : 0.0;
     fz.nrep = op.d[S2K_BN_BWD_APPLY_D_NREP] > 0 ? op.d[S2K_BN_BWD_APPLY_D_NREP] : 1;
     CHECK_PTRS("bn_bwd_apply", gp, y, bnv, coef, dy, fz.st2, fz.gamma, fz.dgamma, fz.dbeta);
     if (!gp || !y || !bnv || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
@@ -727,7 +728,7 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
         return S2K_OK;
     }
     // no COEF table: the BN_BWD_FINALIZE arithmetic is done here (one launch less per BatchNorm)
-    if (!fz.st2 || !fz.gamma || !fz.dgamma || !fz.dbeta || fz.count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2, GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
+    if (!fz.st2 || !fz.gamma || !fz.dgamma || !fz.dbeta || count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2, GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
     launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
     return S2K_OK;
 }

@@ -743,6 +743,9 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         static const int force_cfg = [] { const char* e = getenv("S2K_PIX_FORCE"); return e ? atoi(e) : 0; }();
         if (force_cfg == 1) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
         if (force_cfg == 2) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), true);
+        if (force_cfg == 3) return PIX_CFG(2, 2, 1, 4, 16, cdiv(p.Ntot, 256), false);
+        if (force_cfg == 4) return PIX_CFG(1, 2, 1, 4, 16, cdiv(p.Ntot, 256), false);
+        if (force_cfg == 5) return PIX_CFG(2, 2, 2, 2, 16, cdiv(p.Ntot, 128), false);
         if (bm >= 64 && tiles_big < small_max) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
         if (bm == 128 && p.Ctot <= k16_max) return PIX_CFG(2, 2, 2, 2, 16, cdiv(p.Ntot, 128), false);   // short-K expand convs
         if (bm == 128) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), false);
