@@ -607,6 +607,46 @@ def _numel(shape) -> int:
     return n
 
 
+_HBM_KINDS = ("DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_BWD_REDUCE", "BN_BWD_APPLY", "SE_BWD_REDUCE", "BN_RESIDUAL")
+
+
+def _defer_decoder_wgrads(ops: list, min_gflop: float = 4.0) -> list:
+    """Re-order the backward program so that the large, matrix-core-bound weight gradients of the decoder are issued
+    (on the executor's side stream) while the main stream works through the encoder's backward, which is mostly HBM-bound
+    (depthwise, BatchNorm, SE): issued where the tape emits them they run next to the decoder's data-gradient convs and the
+    two only share the matrix cores.  Nothing reads a weight gradient before the bucket's WGRAD_FINALIZE, which
+    `_bucket_backward` places after the last writer in the NEW order; the operands (dY of the layer, forward activations)
+    are never overwritten later in the backward (bump arena, in-place updates only touch gradient buffers of the layer
+    being processed).  Deferred ops keep their relative order and are spread over the encoder section in proportion to its
+    element traffic."""
+    first = next((i for i, (k, _) in enumerate(ops) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD")), None)
+    if first is None:
+        return ops
+
+    def gflop(f):
+        return 2.0e-9 * f["M"] * f["C"] * f["KH"] * f["KW"] * f["B"] * f["HO"] * f["WO"]
+
+    moved = [(i, gflop(f)) for i, (k, f) in enumerate(ops[:first]) if k == "WGRAD" and gflop(f) >= min_gflop]
+    if not moved:
+        return ops
+    take = {i for i, _ in moved}
+    head = [op for i, op in enumerate(ops[:first]) if i not in take]
+    tail = ops[first:]
+    cost = [float(f["B"] * f["C"] * f.get("HW", f.get("H", 1) * f.get("W", 1))) if k in _HBM_KINDS else 0.0 for k, f in tail]
+    total_cost, total_side = sum(cost) or 1.0, sum(g for _, g in moved)
+    out, j, cum_c, cum_s = [], 0, 0.0, 0.0
+    for (op, c) in zip(tail, cost):
+        # issue the next deferred wgrad once the main stream's share of traffic catches up with the side work already issued
+        while j < len(moved) and cum_c / total_cost >= cum_s / total_side:
+            out.append(ops[moved[j][0]])
+            cum_s += moved[j][1]
+            j += 1
+        out.append(op)
+        cum_c += c
+    out.extend(ops[i] for i, _ in moved[j:])
+    return head + out
+
+
 def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int):
     """Common tail of every planner: emit the backward from the tape, zero the accumulators, cut the backward
     into bucketed segments (+ WGRAD_FINALIZE per bucket) and put the WEIGHT_PACK stages in front."""
@@ -645,6 +685,9 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
             back()
             p.marks.append(len(p.bwd.ops))
         bwd_aux_end = p.aux.mark()
+        import os
+        if os.environ.get("S2K_DEFER_WGRAD", "1") != "0":
+            p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(os.environ.get("S2K_DEFER_MIN_GFLOP", "4")))
         pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
         if bwd_aux_end > fwd_aux_end:
             pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),

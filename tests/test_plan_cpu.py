@@ -50,12 +50,23 @@ def oracle_grads(net, sd, x, y, noise, ncls, dtype):
 
 # wide cases use drop-connect rates whose keep probabilities are exact in fp32 (the stage record
 # carries KEEP as a float), so the float64 comparison is not limited by that 1e-8 rounding
-@pytest.mark.parametrize("version,C,H,B,wide,dcr", [("b0", 6, 64, 2, True, 0.25), ("b5", 13, 64, 2, True, None),
-                                                     ("b0", 4, 128, 2, False, 0.2)])
-def test_train_programs_match_oracle_autograd(version, C, H, B, wide, dcr):
+@pytest.mark.parametrize("version,C,H,B,wide,dcr,defer_all", [("b0", 6, 64, 2, True, 0.25, False), ("b5", 13, 64, 2, True, None, False),
+                                                               ("b0", 4, 128, 2, False, 0.2, False), ("b0", 6, 64, 2, True, 0.25, True)])
+def test_train_programs_match_oracle_autograd(version, C, H, B, wide, dcr, defer_all, monkeypatch):
+    """defer_all: every decoder weight gradient is moved into the encoder's backward section (at the benchmark's size the
+    planner does that for the large ones): the re-ordered program must give the same gradients and bucket segments that
+    still cover the whole gradient buffer."""
     ncls = 4
+    if defer_all:
+        monkeypatch.setenv("S2K_DEFER_MIN_GFLOP", "0")
     model, net, sd, x, y, noise = _setup(version, C, H, B, ncls, seed=21, dcr=dcr)
     plan = model._make_plan(B, H, H, True)
+    if defer_all:
+        kinds = [k for k, _ in plan.bwd.ops]
+        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD"))
+        assert kinds[:first_enc].count("WGRAD") <= 1 and kinds.count("WGRAD") > 20   # (the first deferred one sits at the boundary)
+        segs = plan.bwd_param_marks
+        assert segs[0][3] == plan.layout.n_params and segs[-1][2] == 0 and all(a[2] == b[3] for a, b in zip(segs, segs[1:]))
     bases = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H, wide)
     emulate(plan.fwd.pack(), bases, wide)
     logits = fview(bases, "OUT", wide).view(B, ncls, H, H).clone()
