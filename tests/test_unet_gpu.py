@@ -244,3 +244,29 @@ def test_gradient_accumulation_and_zero_grad_semantics():
     opt.step()
     assert not torch.equal(before, model._flat_params)
     assert model.out_conv1x1.weight.data_ptr() >= model._flat_params.data_ptr()
+
+
+def test_deferred_decoder_wgrads_give_the_same_gradients(monkeypatch):
+    """The planner issues the decoder's large weight gradients during the encoder's backward (side stream); at test sizes
+    nothing is large, so force every decoder wgrad to be deferred and compare with the in-order program."""
+    from s2lc_amd.losses import FocalLoss
+
+    dev = torch.device("cuda:0")
+    x = detgen.normal("defer.x", (2, 6, 64, 64), seed=43).to(dev)
+    y = detgen.labels("defer.y", (2, 64, 64), 4, seed=43).to(dev)
+    grads = []
+    for min_gflop, on in (("0", "1"), ("4", "0")):
+        monkeypatch.setenv("S2K_DEFER_MIN_GFLOP", min_gflop)
+        monkeypatch.setenv("S2K_DEFER_WGRAD", on)
+        model, net, sd = _model("b0", 6, 4, seed=43)
+        model.to(dev).train()
+        model.drop_connect_noise = detgen.uniform("defer.dc", (len(net.blocks), 2), 0, 1, seed=43)
+        FocalLoss(torch.ones(4), 2.0, 0.0, ignore_index=0)(model(x), y).backward()
+        torch.cuda.synchronize()
+        plan = next(iter(model._engines.values())).plan
+        kinds = [k for k, _ in plan.bwd.ops]
+        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD"))
+        assert (kinds[:first_enc].count("WGRAD") <= 1) == (on == "1")
+        grads.append(model._grad_buffer().clone())
+    scale = grads[1].abs().max()
+    assert (grads[0] - grads[1]).abs().max() <= 1e-5 * scale
