@@ -7,6 +7,9 @@ import os
 from pathlib import Path
 
 import numpy as np
+import torch  # noqa: F401  -- BEFORE libs2k.so is loaded: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; dlopen-ing
+#                        libs2k.so first would bind the process to /opt/rocm's copies (same SONAME) and leave two HIP runtimes that
+#                        do not see each other's device state (launches then fail with "no ROCm-capable device is detected")
 
 from .plan import opdefs as D
 from .plan.program import OP_DTYPE
