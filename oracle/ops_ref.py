@@ -353,6 +353,12 @@ def op_bn_bwd_apply(m: Mem, o):
         a = (m.view(o["GAMMA"], (C,)) * bnv[3]).double()
         coef = torch.stack([a, -a * st[1] / n, -a * st[0] / n]).to(m.fdtype)
     xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
+    if o["COEF"] < 0 and (o.get("ACT", 0) or o.get("MULBC", -1) >= 0 or o.get("ADDBC", -1) >= 0):   # recompute g' from the raw gradient
+        mul, add = m.view(o["MULBC"], (B, C)), m.view(o["ADDBC"], (B, C))
+        g = gp * (mul.view(B, C, 1) if mul is not None else 1.0)
+        if add is not None:
+            g = g + add.view(B, C, 1) * o["ADDSCALE"]
+        gp = g * _act_grad(y * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1), o["ACT"])
     dy = coef[0].view(1, C, 1) * gp + coef[1].view(1, C, 1) * xhat + coef[2].view(1, C, 1)
     m.view(o["DY"], (B, C, HW)).copy_(dy)
 
@@ -616,6 +622,31 @@ def op_confusion(m: Mem, o):
     m.view(o["HIST"], (C * C,), "i64").add_(torch.bincount(idx, minlength=C * C))
 
 
+def op_se_bn_sums(m: Mem, o):
+    B, C, HW = o["B"], o["C"], o["HW"]
+    g, y, bnv = m.view(o["G"], (B, C, HW)), m.view(o["Y"], (B, C, HW)), m.view(o["BNV"], (4, C))
+    u = y * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)
+    ap = _act_grad(u, o["ACT"])
+    xhat = (y - bnv[2].view(1, C, 1)) * bnv[3].view(1, C, 1)
+    m.view(o["DGATE"], (B, C)).copy_((g * F.silu(u)).sum(-1))
+    ps = m.view(o["PS"], (4, B, C))
+    ps[0] = (g * ap).sum(-1)
+    ps[1] = ap.sum(-1)
+    ps[2] = (g * ap * xhat).sum(-1)
+    ps[3] = (ap * xhat).sum(-1)
+
+
+def op_se_bn_combine(m: Mem, o):
+    B, C = o["B"], o["C"]
+    ps = m.view(o["PS"], (4, B, C)).double()
+    mul, add = m.view(o["MULBC"], (B, C)), m.view(o["ADDBC"], (B, C))
+    mul = mul.double() if mul is not None else torch.ones(B, C, dtype=torch.float64)
+    add = add.double() * o["ADDSCALE"] if add is not None else torch.zeros(B, C, dtype=torch.float64)
+    st = m.view(o["STATS2"], (2, C), "f64")
+    st[0] = (mul * ps[0] + add * ps[1]).sum(0)
+    st[1] = (mul * ps[2] + add * ps[3]).sum(0)
+
+
 def op_tile_prep(m: Mem, o):
     """crop -> flips -> normalise (two separately rounded fp32 steps, as numpy's `img -= mean; img *= denominator`) + label LUT"""
     B, C, H, W, S, N = o["B"], o["C"], o["H"], o["W"], o["S"], o["NSRC"]
@@ -657,7 +688,7 @@ DISPATCH = {
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
-    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
+    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
     "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }

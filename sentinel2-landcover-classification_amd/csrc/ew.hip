@@ -299,6 +299,99 @@ int launch_se_bwd_reduce(const S2kOp& op, const Ctx& c) {
                                   op.d[S2K_SE_BWD_REDUCE_D_HW], pro, c.stream);
 }
 
+// ---------------- SE + BatchNorm backward of the depthwise output in two passes over the expanded tensor -------------
+// The chain SE_BWD_REDUCE -> SE_FC_BWD -> BN_BWD_REDUCE -> BN_BWD_APPLY reads the (b, c, hw) gradient d and the raw conv
+// output y three times and writes twice, because BN_BWD_REDUCE needs the SE result (ADDBC) of the first pass.  Its sums are
+// linear in the per-plane factors, g' = (d*mul + add) * a'(u):
+//   sum g'      = mul * sum d a'      + add * sum a'
+//   sum g' xhat = mul * sum d a' xhat + add * sum a' xhat
+// so ONE pass collects dgate = sum d*a and the four plane sums (SE_BN_SUMS), a per-channel kernel combines them once mul /
+// add are known (SE_BN_COMBINE), and BN_BWD_APPLY recomputes g' on the fly: 4 reads + 1 write instead of 6 + 2.
+template <bool VEC>
+__global__ void __launch_bounds__(NTHREADS) se_bn_sums_kernel(const float* g, const float* y, const float* bnv, float* dgate,
+                                                              float* ps, int C, int HW, int64_t nplanes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= nplanes) return;
+    const int c = (int)(plane % C);
+    const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+    const int64_t base = plane * HW;
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
+    auto acc = [&](float d, float yy) {
+        const float u = fmaf(yy, scale, shift);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        const float ap = sg * (1.0f + u * (1.0f - sg)), xh = (yy - mean) * invstd;
+        const float t = d * ap;
+        p0 = fmaf(d, u * sg, p0);
+        p1 += t;
+        p2 += ap;
+        p3 = fmaf(t, xh, p3);
+        p4 = fmaf(ap, xh, p4);
+    };
+    if (VEC) {
+        for (int i = lane; i < (HW >> 2); i += 64) {
+            const float4 dv = reinterpret_cast<const float4*>(g + base)[i];
+            const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+            acc(dv.x, yv.x); acc(dv.y, yv.y); acc(dv.z, yv.z); acc(dv.w, yv.w);
+        }
+    } else {
+        for (int i = lane; i < HW; i += 64) acc(g[base + i], y[base + i]);
+    }
+    p0 = wave_sum_hi(p0); p1 = wave_sum_hi(p1); p2 = wave_sum_hi(p2); p3 = wave_sum_hi(p3); p4 = wave_sum_hi(p4);
+    if (lane == 63) {
+        dgate[plane] = p0;
+        ps[plane] = p1;
+        ps[nplanes + plane] = p2;
+        ps[2 * nplanes + plane] = p3;
+        ps[3 * nplanes + plane] = p4;
+    }
+}
+
+int launch_se_bn_sums(const S2kOp& op, const Ctx& c) {
+    const float* g = ref_ptr<const float>(c, op.t[S2K_SE_BN_SUMS_T_G]);
+    const float* y = ref_ptr<const float>(c, op.t[S2K_SE_BN_SUMS_T_Y]);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_SE_BN_SUMS_T_BNV]);
+    float* dgate = ref_ptr<float>(c, op.t[S2K_SE_BN_SUMS_T_DGATE]);
+    float* ps = ref_ptr<float>(c, op.t[S2K_SE_BN_SUMS_T_PS]);
+    CHECK_PTRS("se_bn_sums", g, y, bnv, dgate, ps);
+    const int B = op.d[S2K_SE_BN_SUMS_D_B], C = op.d[S2K_SE_BN_SUMS_D_C], HW = op.d[S2K_SE_BN_SUMS_D_HW];
+    if (!g || !y || !bnv || !dgate || !ps || B <= 0 || C <= 0 || HW <= 0 || op.d[S2K_SE_BN_SUMS_D_ACT] != S2K_PRO_SILU) {
+        set_error("se_bn_sums: bad args (SiLU only)"); return S2K_EINVAL;
+    }
+    const int64_t nplanes = (int64_t)B * C;
+    const unsigned blocks = (unsigned)cdiv64(nplanes, 4);
+    if ((HW & 3) == 0) hipLaunchKernelGGL((se_bn_sums_kernel<true>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, C, HW, nplanes);
+    else hipLaunchKernelGGL((se_bn_sums_kernel<false>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, C, HW, nplanes);
+    return S2K_OK;
+}
+
+__global__ void se_bn_combine_kernel(const float* ps, const float* mulbc, const float* addbc, double* st2, int B, int C, float addscale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t np = (int64_t)B * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t pl = (int64_t)b * C + c;
+        const double mul = mulbc ? (double)mulbc[pl] : 1.0, add = addbc ? (double)addbc[pl] * (double)addscale : 0.0;
+        s1 += mul * (double)ps[pl] + add * (double)ps[np + pl];
+        s2 += mul * (double)ps[2 * np + pl] + add * (double)ps[3 * np + pl];
+    }
+    st2[c] = s1;
+    st2[C + c] = s2;
+}
+
+int launch_se_bn_combine(const S2kOp& op, const Ctx& c) {
+    const float* ps = ref_ptr<const float>(c, op.t[S2K_SE_BN_COMBINE_T_PS]);
+    const float* mulbc = ref_ptr<const float>(c, op.t[S2K_SE_BN_COMBINE_T_MULBC]);
+    const float* addbc = ref_ptr<const float>(c, op.t[S2K_SE_BN_COMBINE_T_ADDBC]);
+    double* st2 = ref_ptr<double>(c, op.t[S2K_SE_BN_COMBINE_T_STATS2]);
+    CHECK_PTRS("se_bn_combine", ps, mulbc, addbc, st2);
+    const int B = op.d[S2K_SE_BN_COMBINE_D_B], C = op.d[S2K_SE_BN_COMBINE_D_C];
+    if (!ps || !st2 || B <= 0 || C <= 0) { set_error("se_bn_combine: bad args"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(se_bn_combine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, c.stream, ps, mulbc, addbc, st2, B, C, op.f[S2K_SE_BN_COMBINE_F_ADDSCALE]);
+    return S2K_OK;
+}
+
 // short planes (token axes of the ViT: 50 .. 197 elements): one wave owns a channel, walks the batch with 4 independent
 // partial sums and adds ONCE, without atomics (a wave per (b, c) plane would be one load and one atomic each)
 __global__ void __launch_bounds__(NTHREADS) channel_sum_rows_kernel(const float* g, float* out, int B, int C, int HW) {
@@ -636,9 +729,12 @@ struct BnFuse {
     float *dgamma, *dbeta;
     double inv_count;
     int nrep;
+    const float *mulbc, *addbc;   // MODE 3: g' = (GP * mul + add * addscale) * silu'(u) is recomputed here
+    float addscale;
 };
 
-// MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY; MODE 2 = the same with the coefficients computed here from STATS2);
+// MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY; MODE 2 = the same with the coefficients computed here from STATS2;
+// MODE 3 = MODE 2 with gp = (a*mul + add) * silu'(scale*y + shift) recomputed per element, see SE_BN_SUMS);
 // MODE 1: xout = (scale*y+shift)*dcs[b] + ident (BN_RESIDUAL)
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, const float* y, const float* bnv, const float* coef,
@@ -649,7 +745,14 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     const int lane = threadIdx.x & 63;
     const int c = (int)(t.plane % C);
     float k0, k1, k2;  // out = k0*a + k1*y + k2
-    if (MODE == 2) {
+    float gmul = 1.0f, gadd = 0.0f, bscale = 1.0f, bshift = 0.0f;
+    if (MODE == 3) {
+        gmul = fz.mulbc ? fz.mulbc[t.plane] : 1.0f;
+        gadd = fz.addbc ? fz.addbc[t.plane] * fz.addscale : 0.0f;
+        bscale = bnv[c];
+        bshift = bnv[C + c];
+    }
+    if (MODE >= 2) {
         double s1 = 0.0, s2 = 0.0;
         if (fz.nrep <= 8) {   // wave-uniform addresses: scalar loads
             for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
@@ -682,6 +785,12 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
             float4 av = make_float4(0, 0, 0, 0);
             if (a) av = reinterpret_cast<const float4*>(a + base)[i];
             const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+            if (MODE == 3) {
+                av.x = fmaf(av.x, gmul, gadd) * act_grad(fmaf(yv.x, bscale, bshift), S2K_PRO_SILU);
+                av.y = fmaf(av.y, gmul, gadd) * act_grad(fmaf(yv.y, bscale, bshift), S2K_PRO_SILU);
+                av.z = fmaf(av.z, gmul, gadd) * act_grad(fmaf(yv.z, bscale, bshift), S2K_PRO_SILU);
+                av.w = fmaf(av.w, gmul, gadd) * act_grad(fmaf(yv.w, bscale, bshift), S2K_PRO_SILU);
+            }
             float4 o;
             o.x = fmaf(k0, av.x, fmaf(k1, yv.x, k2)); o.y = fmaf(k0, av.y, fmaf(k1, yv.y, k2));
             o.z = fmaf(k0, av.z, fmaf(k1, yv.z, k2)); o.w = fmaf(k0, av.w, fmaf(k1, yv.w, k2));
@@ -689,7 +798,8 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
         }
     } else {
         for (int i = lane; i < t.count; i += 64) {
-            const float av = a ? a[base + i] : 0.0f;
+            float av = a ? a[base + i] : 0.0f;
+            if (MODE == 3) av = fmaf(av, gmul, gadd) * act_grad(fmaf(y[base + i], bscale, bshift), S2K_PRO_SILU);
             out[base + i] = fmaf(k0, av, fmaf(k1, y[base + i], k2));
         }
     }
@@ -729,7 +839,17 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     }
     // no COEF table: the BN_BWD_FINALIZE arithmetic is done here (one launch less per BatchNorm)
     if (!fz.st2 || !fz.gamma || !fz.dgamma || !fz.dbeta || count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2, GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
-    launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
+    fz.mulbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_MULBC]);
+    fz.addbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_ADDBC]);
+    fz.addscale = op.f[S2K_BN_BWD_APPLY_F_ADDSCALE];
+    CHECK_PTRS("bn_bwd_apply", fz.mulbc, fz.addbc);
+    if (op.d[S2K_BN_BWD_APPLY_D_ACT] == S2K_PRO_NONE && !fz.mulbc && !fz.addbc) {
+        launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
+        return S2K_OK;
+    }
+    // GP holds the raw upstream gradient: g' = (GP * MULBC + ADDBC * ADDSCALE) * silu'(u) is recomputed per element
+    if (op.d[S2K_BN_BWD_APPLY_D_ACT] != S2K_PRO_SILU) { set_error("bn_bwd_apply: the recomputing form is SiLU only"); return S2K_EINVAL; }
+    launch_plane_map<3>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
     return S2K_OK;
 }
 

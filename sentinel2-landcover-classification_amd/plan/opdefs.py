@@ -99,7 +99,10 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # DGAMMA += S2; DBETA += S1; COEF = {A, Bq, Cq}[C] with dY = A*g' + Bq*xhat + Cq
     "BN_BWD_FINALIZE": (["STATS2", "GAMMA", "BNV", "DGAMMA", "DBETA", "COEF"], ["COUNT"], ["C", "NREP"], []),
     # COEF null: the FINALIZE arithmetic is done inside (from STATS2 / GAMMA / COUNT / NREP; DGAMMA, DBETA += the sums)
-    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA"], ["COUNT"], ["B", "C", "HW", "NREP"], []),
+    # ACT / MULBC / ADDBC given (COEF null): GP is the raw upstream gradient and g' = (GP*MULBC + ADDBC*ADDSCALE) * act'(u) is
+    # recomputed per element (the sums in STATS2 then come from SE_BN_SUMS / SE_BN_COMBINE instead of BN_BWD_REDUCE)
+    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC"], ["COUNT"],
+                     ["B", "C", "HW", "NREP", "ACT"], ["ADDSCALE"]),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"], [], ["B", "C", "HW"], ["KEEP"]),
     # OUT[c] += sum_{b,hw} G[b][c][hw]
@@ -159,6 +162,12 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   Y[b][i][j]    = LUT[LABELS[src][y0 + i'][x0 + j']]     (int64; LUT has 256 int32 entries: the CNES remap, or identity)
     # RAW int16 [NSRC][C][H][W], LABELS uint8 [NSRC][H][W]; subtract and multiply are separately rounded (numpy semantics)
     "TILE_PREP": (["RAW", "LABELS", "PARAMS", "NORM", "LUT", "X", "Y"], [], ["B", "C", "H", "W", "S", "NSRC"], []),
+    # SE + BatchNorm backward of a SiLU(BN(y)) * gate activation in two passes (see csrc/ew.hip): per (b, c) plane,
+    # u = scale*y + shift, a' = silu'(u), xhat = (y - mean)*invstd:
+    #   DGATE = sum G*silu(u);  PS[0] = sum G*a';  PS[1] = sum a';  PS[2] = sum G*a'*xhat;  PS[3] = sum a'*xhat     (PS [4][B][C])
+    "SE_BN_SUMS": (["G", "Y", "BNV", "DGATE", "PS"], [], ["B", "C", "HW", "ACT"], []),
+    # STATS2[0][c] = sum_b MULBC*PS[0] + ADDBC*ADDSCALE*PS[1];  STATS2[1][c] = sum_b MULBC*PS[2] + ADDBC*ADDSCALE*PS[3]   (f64 [2][C])
+    "SE_BN_COMBINE": (["PS", "MULBC", "ADDBC", "STATS2"], [], ["B", "C"], ["ADDSCALE"]),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 

@@ -81,6 +81,10 @@ class Act:
     addscale: float = 0.0
     # set when a consumer's dgrad already applied act' and accumulated the BN-backward sums
     fused_stats2: TRef | None = None
+    # SiLU(BN(y)) produced by dwconv_bn: the SE backward may collect the BatchNorm-backward plane sums in its own pass
+    # (SE_BN_SUMS); `se_sums` then tells the producer's backward to combine them instead of running BN_BWD_REDUCE
+    bn_silu_producer: bool = False
+    se_sums: TRef | None = None
 
 
 @dataclass
@@ -372,10 +376,21 @@ def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, e
     nrep = D.stats_replicas(C)
     p.fwd.add("DWCONV_FWD", X=src.raw, BNV=src.bnv, WT=p.param(wname), Y=y, STATS=stats, NREP=nrep, **geo)
     bnv = _bn_forward(p, bnprefix, y, C, B * Ho * Wo, stats, eps, mom)
-    out = Act(y, C, Ho, Wo, bnv, D.PRO_SILU)
+    out = Act(y, C, Ho, Wo, bnv, D.PRO_SILU, bn_silu_producer=True)
 
     def backward():
-        dY = _bn_backward(p, bnprefix, out.grad, y, bnv, C, Ho * Wo, D.ACT_SILU, out.mulbc, out.addbc, out.addscale)
+        if out.se_sums is not None:
+            # two-pass form (csrc/ew.hip, SE_BN_SUMS): the plane sums were collected by the SE backward's pass; combine them
+            # with the SE result and let APPLY recompute g' = (d * gate + dpool / HW) * silu'(u) while it streams d and y
+            HWo = Ho * Wo
+            st2 = p.aux.alloc("stats2c:" + bnprefix, (1, 2, C), "f64")
+            p.bwd.add("SE_BN_COMBINE", PS=out.se_sums, MULBC=out.mulbc, ADDBC=out.addbc, STATS2=st2, B=B, C=C, ADDSCALE=out.addscale)
+            dY = out.grad
+            p.bwd.add("BN_BWD_APPLY", GP=dY, Y=y, BNV=bnv, COEF=None, DY=dY, STATS2=st2, GAMMA=p.param(bnprefix + ".weight"),
+                      DGAMMA=p.pgrad(bnprefix + ".weight"), DBETA=p.pgrad(bnprefix + ".bias"), MULBC=out.mulbc, ADDBC=out.addbc,
+                      COUNT=B * HWo, B=B, C=C, HW=HWo, NREP=1, ACT=D.ACT_SILU, ADDSCALE=out.addscale)
+        else:
+            dY = _bn_backward(p, bnprefix, out.grad, y, bnv, C, Ho * Wo, D.ACT_SILU, out.mulbc, out.addbc, out.addscale)
         p.bwd.add("DWCONV_WGRAD", DY=dY, X=src.raw, BNV=src.bnv, DW=p.pgrad(wname), **geo)
         if not src.needs_grad:
             return
@@ -416,7 +431,12 @@ def squeeze_excite(p: _P, prefix: str, a: Act, se: int) -> Act:
         dgate = p.alloc("dgate:" + prefix, (B, C))
         dpool = p.alloc("dpool:" + prefix, (B, C))
         hs = p.alloc("hs:" + prefix, (B, se))
-        p.bwd.add("SE_BWD_REDUCE", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, B=B, C=C, HW=HW, PRO=a.pro)
+        import os
+        if a.bn_silu_producer and a.pro == D.PRO_SILU and os.environ.get("S2K_SE_BN_TWO_PASS", "1") != "0":
+            a.se_sums = p.alloc("se_sums:" + prefix, (4, B, C))
+            p.bwd.add("SE_BN_SUMS", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, PS=a.se_sums, B=B, C=C, HW=HW, ACT=D.ACT_SILU)
+        else:
+            p.bwd.add("SE_BWD_REDUCE", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, B=B, C=C, HW=HW, PRO=a.pro)
         p.bwd.add("SE_FC_BWD", DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=p.param(w1), W2=p.param(w2),
                   DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2), DB2=p.pgrad(b2), DPOOL=dpool, HS=hs,
                   B=B, C=C, CSQ=se)
@@ -607,7 +627,7 @@ def _numel(shape) -> int:
     return n
 
 
-_HBM_KINDS = ("DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_BWD_REDUCE", "BN_BWD_APPLY", "SE_BWD_REDUCE", "BN_RESIDUAL")
+_HBM_KINDS = ("DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_BWD_REDUCE", "BN_BWD_APPLY", "SE_BWD_REDUCE", "SE_BN_SUMS", "BN_RESIDUAL")
 
 
 def _defer_decoder_wgrads(ops: list, min_gflop: float = 4.0) -> list:
@@ -619,7 +639,7 @@ def _defer_decoder_wgrads(ops: list, min_gflop: float = 4.0) -> list:
     are never overwritten later in the backward (bump arena, in-place updates only touch gradient buffers of the layer
     being processed).  Deferred ops keep their relative order and are spread over the encoder section in proportion to its
     element traffic."""
-    first = next((i for i, (k, _) in enumerate(ops) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD")), None)
+    first = next((i for i, (k, _) in enumerate(ops) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_BN_SUMS", "SE_FC_BWD")), None)
     if first is None:
         return ops
 

@@ -553,3 +553,27 @@ def test_convt_wgrad_gather_reads_past_2gib():
     wgs = c.t("wgs", (4, Cin, Cout), "zeros")
     c.run("WGRAD", ["wgs"], tol=2e-4, P=xs, BNVP=None, GATEP=None, Q=g, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=Cin, C=Cout, CTOT=Cout,
           H=H2, W=H2, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_GATHER2X2)
+
+
+@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 5, 4100)])
+def test_se_bn_two_pass_stages(B, C, HW):
+    """SE_BN_SUMS (one pass: dgate + the four plane sums), SE_BN_COMBINE (per-channel BatchNorm-backward sums once the SE
+    factors are known) and the recomputing form of BN_BWD_APPLY; together they equal SE_BWD_REDUCE + BN_BWD_REDUCE + APPLY."""
+    c = Case(21)
+    g, y = c.t("g", (B, C, HW)), c.t("y", (B, C, HW))
+    bnv = c.bnv("bnv", C)
+    dgate, ps = c.t("dgate", (B, C), "nan"), c.t("ps", (4, B, C), "nan")
+    c.run("SE_BN_SUMS", ["dgate", "ps"], 2e-4, G=g, Y=y, BNV=bnv, DGATE=dgate, PS=ps, B=B, C=C, HW=HW, ACT=D.ACT_SILU)
+    c2 = Case(22)
+    ps = c2.t("ps", (4, B, C), scale=5.0)
+    mul, add = c2.t("mul", (B, C), "rand"), c2.t("add", (B, C))
+    st2 = c2.t("st2", (2, C), "nan", "f64")
+    c2.run("SE_BN_COMBINE", ["st2"], 1e-6, PS=ps, MULBC=mul, ADDBC=add, STATS2=st2, B=B, C=C, ADDSCALE=1.0 / HW)
+    c3 = Case(23)
+    gp, y = c3.t("gp", (B, C, HW)), c3.t("y", (B, C, HW))
+    bnv, gam = c3.bnv("bnv", C), c3.t("gamma", (C,), "pos")
+    mul, add = c3.t("mul", (B, C), "rand"), c3.t("add", (B, C))
+    st2 = c3.t("st2", (1, 2, C), torch.randn(1, 2, C, dtype=torch.float64, generator=c3.gen) * 10, "f64")
+    dg, db = c3.t("dgamma", (C,)), c3.t("dbeta", (C,))
+    c3.run("BN_BWD_APPLY", ["gp", "dgamma", "dbeta"], 2e-5, GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=gam, DGAMMA=dg, DBETA=db,
+           MULBC=mul, ADDBC=add, COUNT=B * HW, B=B, C=C, HW=HW, NREP=1, ACT=D.ACT_SILU, ADDSCALE=1.0 / HW)

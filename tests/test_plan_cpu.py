@@ -63,7 +63,7 @@ def test_train_programs_match_oracle_autograd(version, C, H, B, wide, dcr, defer
     plan = model._make_plan(B, H, H, True)
     if defer_all:
         kinds = [k for k, _ in plan.bwd.ops]
-        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD"))
+        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_BN_SUMS", "SE_FC_BWD"))
         assert kinds[:first_enc].count("WGRAD") <= 1 and kinds.count("WGRAD") > 20   # (the first deferred one sits at the boundary)
         segs = plan.bwd_param_marks
         assert segs[0][3] == plan.layout.n_params and segs[-1][2] == 0 and all(a[2] == b[3] for a, b in zip(segs, segs[1:]))

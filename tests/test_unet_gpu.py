@@ -265,7 +265,7 @@ def test_deferred_decoder_wgrads_give_the_same_gradients(monkeypatch):
         torch.cuda.synchronize()
         plan = next(iter(model._engines.values())).plan
         kinds = [k for k, _ in plan.bwd.ops]
-        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_FC_BWD"))
+        first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BWD_REDUCE", "SE_BN_SUMS", "SE_FC_BWD"))
         assert (kinds[:first_enc].count("WGRAD") <= 1) == (on == "1")
         grads.append(model._grad_buffer().clone())
     scale = grads[1].abs().max()
