@@ -448,13 +448,43 @@ __device__ __forceinline__ float patch_target(const PatchP& p, int b, int l, int
     return p.x[((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px];
 }
 
+// the same values in order f = 0, 1, 2, ... (c fastest, then px, py, tt) with incremental addressing: the loss kernels
+// spent most of their time in the five divisions of patch_target
+struct PatchWalk {
+    const float* q;      // element (tt, py, px, c = 0)
+    int cc, px, py;
+    int64_t cstride, row_skip, frame_skip;
+    __device__ __forceinline__ PatchWalk(const PatchP& p, int b, int l) {
+        const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
+        cstride = (int64_t)p.T * p.H * p.W;
+        q = p.x + (((int64_t)b * p.C * p.T + (int64_t)t * p.TUB) * p.H + (int64_t)h * p.P) * p.W + (int64_t)w * p.P;
+        cc = px = py = 0;
+        row_skip = p.W - p.P;                                   // from the end of a patch row to the start of the next
+        frame_skip = (int64_t)p.H * p.W - (int64_t)p.P * p.W;   // from below the patch to its first row in the next frame
+    }
+    __device__ __forceinline__ float next(const PatchP& p) {
+        const float v = q[(int64_t)cc * cstride];
+        if (++cc == p.C) {
+            cc = 0;
+            ++q;
+            if (++px == p.P) {
+                px = 0;
+                q += row_skip;
+                if (++py == p.P) { py = 0; q += frame_skip; }
+            }
+        }
+        return v;
+    }
+};
+
 __device__ __forceinline__ void patch_norm(const PatchP& p, int b, int l, float& mean, float& inv) {
     mean = 0.0f;
     inv = 1.0f;
     if (!p.norm_pix) return;
     double s = 0.0, q = 0.0;
+    PatchWalk pw(p, b, l);
     for (int f = 0; f < p.PD; ++f) {
-        const float v = patch_target(p, b, l, f);
+        const float v = pw.next(p);
         s += v;
         q += (double)v * v;
     }
@@ -477,8 +507,9 @@ __global__ void __launch_bounds__(NTHREADS) mae_loss_fwd_kernel(const PatchP p) 
             patch_norm(p, b, l, mean, inv);
             const float* pr = p.pred + (int64_t)b * p.PD * p.LP + l + p.L_OFF;
             float s = 0.0f;
-            for (int f = 0; f < p.PD; ++f) {
-                const float d = pr[(int64_t)f * p.LP] - (patch_target(p, b, l, f) - mean) * inv;
+            PatchWalk pw(p, b, l);
+            for (int f = 0; f < p.PD; ++f) {   // f = ((tt*P + py)*P + px)*C + c, walked without divisions
+                const float d = pr[(int64_t)f * p.LP] - (pw.next(p) - mean) * inv;
                 s = fmaf(d, d, s);
             }
             num = (double)(s / p.PD) * mk;
@@ -512,7 +543,8 @@ __global__ void __launch_bounds__(NTHREADS) mae_loss_bwd_kernel(const PatchP p) 
     const float go = p.gout ? p.gout[0] : 1.0f;
     const float k = 2.0f * mk * go / ((float)p.PD * (float)p.acc[1]);
     const float* pr = p.pred + (int64_t)b * p.PD * p.LP + col;
-    for (int f = 0; f < p.PD; ++f) dst[(int64_t)f * p.LP] = k * (pr[(int64_t)f * p.LP] - (patch_target(p, b, l, f) - mean) * inv);
+    PatchWalk pw(p, b, l);
+    for (int f = 0; f < p.PD; ++f) dst[(int64_t)f * p.LP] = k * (pr[(int64_t)f * p.LP] - (pw.next(p) - mean) * inv);
 }
 
 static int mae_loss_common(PatchP& p, const S2kOp& op) {
