@@ -647,6 +647,11 @@ def op_se_bn_combine(m: Mem, o):
     st[1] = (mul * ps[2] + add * ps[3]).sum(0)
 
 
+def op_space_to_depth(m: Mem, o):
+    B, C, H, W = o["B"], o["C"], o["H"], o["W"]
+    m.view(o["Y"], (B, 4 * C, H, W)).copy_(_unshuffle2(m.view(o["X"], (B, C, 2 * H, 2 * W))))
+
+
 def op_tile_prep(m: Mem, o):
     """crop -> flips -> normalise (two separately rounded fp32 steps, as numpy's `img -= mean; img *= denominator`) + label LUT"""
     B, C, H, W, S, N = o["B"], o["C"], o["H"], o["W"], o["S"], o["NSRC"]
@@ -688,7 +693,7 @@ DISPATCH = {
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
-    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
+    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
     "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }

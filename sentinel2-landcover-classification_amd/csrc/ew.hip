@@ -866,6 +866,51 @@ int launch_bn_residual(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
+// ---------------- space-to-depth (pixel unshuffle) of a ConvTranspose output gradient --------------------------------
+// one thread: 8 consecutive high-resolution pixels of one row (two float4 loads) -> float4 to channel (c, dy, 0) and
+// float4 to (c, dy, 1); lanes run along the row, reads and writes are full 16-byte vectors
+__global__ void __launch_bounds__(NTHREADS) space_to_depth_kernel(const float* x, float* y, int C, int H, int W, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x;   // over (b, c, dy, yy, xq), xq = groups of 4 low-res columns
+    if (i >= total) return;
+    const int wq = W >> 2;
+    const int xq = (int)(i % wq);
+    int64_t r = i / wq;
+    const int yy = (int)(r % H); r /= H;
+    const int dy = (int)(r & 1); r >>= 1;                     // r = b * C + c
+    const float* src = x + (r * 2 * H + 2 * yy + dy) * (int64_t)(2 * W) + 8 * xq;
+    const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+    float* dst = y + ((r * 4 + dy * 2) * H + yy) * (int64_t)W + 4 * xq;
+    *reinterpret_cast<float4*>(dst) = make_float4(a.x, a.z, b.x, b.z);
+    *reinterpret_cast<float4*>(dst + (int64_t)H * W) = make_float4(a.y, a.w, b.y, b.w);
+}
+
+__global__ void space_to_depth_scalar_kernel(const float* x, float* y, int C, int H, int W, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {   // over Y elements
+        const int xx = (int)(i % W);
+        int64_t r = i / W;
+        const int yy = (int)(r % H); r /= H;
+        const int k = (int)(r & 3); r >>= 2;
+        y[i] = x[(r * 2 * H + 2 * yy + (k >> 1)) * (int64_t)(2 * W) + 2 * xx + (k & 1)];
+    }
+}
+
+int launch_space_to_depth(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_SPACE_TO_DEPTH_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_SPACE_TO_DEPTH_T_Y]);
+    CHECK_PTRS("space_to_depth", x, y);
+    const int B = op.d[S2K_SPACE_TO_DEPTH_D_B], C = op.d[S2K_SPACE_TO_DEPTH_D_C], H = op.d[S2K_SPACE_TO_DEPTH_D_H], W = op.d[S2K_SPACE_TO_DEPTH_D_W];
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("space_to_depth: bad args"); return S2K_EINVAL; }
+    if ((W & 3) == 0) {
+        const int64_t total = (int64_t)B * C * 2 * H * (W >> 2);
+        hipLaunchKernelGGL(space_to_depth_kernel, dim3((unsigned)cdiv64(total, NTHREADS)), dim3(NTHREADS), 0, c.stream, x, y, C, H, W, total);
+    } else {
+        const int64_t total = (int64_t)B * C * 4 * H * W;
+        hipLaunchKernelGGL(space_to_depth_scalar_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65536)), dim3(256), 0, c.stream, x, y, C, H, W, total);
+    }
+    return S2K_OK;
+}
+
 // ---------------- fused Adam (L2-coupled weight decay; torch.optim.Adam semantics) -------------------------------
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                             float wd, float bc1, float bc2) {

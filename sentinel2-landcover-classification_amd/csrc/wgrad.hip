@@ -465,6 +465,12 @@ static int launch_wg(WgradP& p, hipStream_t st) {
             if (pp == S2K_PRO_NONE && pq == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_SILU>(p, st);
         if constexpr (MODE == WG_PIX)
             if (pp == S2K_PRO_NONE && pq == S2K_PRO_GELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_NONE, S2K_PRO_GELU>(p, st);
+        // ConvTranspose weight gradients as 1x1 contractions over the space-to-depth gradient: the prologue sits on P (the layer input)
+        if constexpr (MODE == WG_PIX) {
+            if (pq == S2K_PRO_NONE && pp == S2K_PRO_RELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
+            if (pq == S2K_PRO_NONE && pp == S2K_PRO_SILU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_SILU, S2K_PRO_NONE>(p, st);
+            if (pq == S2K_PRO_NONE && pp == S2K_PRO_GELU) return launch_wg2<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, S2K_PRO_GELU, S2K_PRO_NONE>(p, st);
+        }
     }
     set_error("wgrad: prologue combination (P %d, Q %d) is not instantiated for this mode", pp, pq);
     return S2K_EINVAL;

@@ -168,6 +168,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "SE_BN_SUMS": (["G", "Y", "BNV", "DGATE", "PS"], [], ["B", "C", "HW", "ACT"], []),
     # STATS2[0][c] = sum_b MULBC*PS[0] + ADDBC*ADDSCALE*PS[1];  STATS2[1][c] = sum_b MULBC*PS[2] + ADDBC*ADDSCALE*PS[3]   (f64 [2][C])
     "SE_BN_COMBINE": (["PS", "MULBC", "ADDBC", "STATS2"], [], ["B", "C"], ["ADDSCALE"]),
+    # Y[b][c*4 + dy*2 + dx][y][x] = X[b][c][2y + dy][2x + dx]   (H, W = the low-resolution size): the gradient of a
+    # ConvTranspose2d(k2, s2) output regrouped so that its weight / data gradients are plain 1x1 contractions over 4*C channels
+    "SPACE_TO_DEPTH": (["X", "Y"], [], ["B", "C", "H", "W"], []),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 

@@ -577,3 +577,24 @@ def test_se_bn_two_pass_stages(B, C, HW):
     dg, db = c3.t("dgamma", (C,)), c3.t("dbeta", (C,))
     c3.run("BN_BWD_APPLY", ["gp", "dgamma", "dbeta"], 2e-5, GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=gam, DGAMMA=dg, DBETA=db,
            MULBC=mul, ADDBC=add, COUNT=B * HW, B=B, C=C, HW=HW, NREP=1, ACT=D.ACT_SILU, ADDSCALE=1.0 / HW)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 5, 6, 8), (1, 3, 7, 5), (2, 16, 28, 28)])
+def test_space_to_depth_exact(B, C, H, W):
+    c = Case(24)
+    x = c.t("x", (B, C, 2 * H, 2 * W))
+    y = c.t("y", (B, 4 * C, H, W), "nan")
+    c.run("SPACE_TO_DEPTH", ["y"], 1e-30, X=x, Y=y, B=B, C=C, H=H, W=W)
+
+
+@pytest.mark.parametrize("pro", [D.PRO_NONE, D.PRO_RELU, D.PRO_SILU, D.PRO_GELU])
+@pytest.mark.parametrize("B,M,C,H", [(2, 48, 160, 8), (2, 130, 64, 6), (1, 24, 24, 16)])
+def test_wgrad_1x1_with_prologue_on_p(B, M, C, H, pro):
+    """the ConvTranspose weight gradient as a 1x1 contraction: P = the layer input with its BatchNorm / activation prologue,
+    Q = the space-to-depth output gradient"""
+    c = Case(25)
+    P, Q = c.t("p", (B, M, H, H)), c.t("q", (B, C, H, H))
+    bnv = c.bnv("bnv", M) if pro else None
+    wgs = c.t("wgs", (1, M, C), "zeros")
+    c.run("WGRAD", ["wgs"], 2e-4, P=P, BNVP=bnv, GATEP=None, Q=Q, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=H,
+          KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=pro, PROQ=D.PRO_NONE, MODE=D.MODE_CONV)
