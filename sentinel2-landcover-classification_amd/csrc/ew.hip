@@ -365,19 +365,26 @@ int launch_se_bn_sums(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
-__global__ void se_bn_combine_kernel(const float* ps, const float* mulbc, const float* addbc, double* st2, int B, int C, float addscale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel, lanes over the batch (a thread-per-channel loop over b was 32 dependent round trips: 29 us a launch)
+__global__ void __launch_bounds__(NTHREADS) se_bn_combine_kernel(const float* ps, const float* mulbc, const float* addbc, double* st2,
+                                                                 int B, int C, float addscale) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     const int64_t np = (int64_t)B * C;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = lane; b < B; b += 64) {
         const int64_t pl = (int64_t)b * C + c;
         const double mul = mulbc ? (double)mulbc[pl] : 1.0, add = addbc ? (double)addbc[pl] * (double)addscale : 0.0;
         s1 += mul * (double)ps[pl] + add * (double)ps[np + pl];
         s2 += mul * (double)ps[2 * np + pl] + add * (double)ps[3 * np + pl];
     }
-    st2[c] = s1;
-    st2[C + c] = s2;
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) {
+        st2[c] = s1;
+        st2[C + c] = s2;
+    }
 }
 
 int launch_se_bn_combine(const S2kOp& op, const Ctx& c) {
@@ -388,7 +395,7 @@ int launch_se_bn_combine(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("se_bn_combine", ps, mulbc, addbc, st2);
     const int B = op.d[S2K_SE_BN_COMBINE_D_B], C = op.d[S2K_SE_BN_COMBINE_D_C];
     if (!ps || !st2 || B <= 0 || C <= 0) { set_error("se_bn_combine: bad args"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(se_bn_combine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, c.stream, ps, mulbc, addbc, st2, B, C, op.f[S2K_SE_BN_COMBINE_F_ADDSCALE]);
+    hipLaunchKernelGGL(se_bn_combine_kernel, dim3(cdiv(C, 4)), dim3(NTHREADS), 0, c.stream, ps, mulbc, addbc, st2, B, C, op.f[S2K_SE_BN_COMBINE_F_ADDSCALE]);
     return S2K_OK;
 }
 
