@@ -522,7 +522,15 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         p.PSTR = p.NP + 1;
         p.CSQ = p.NP + 1;
         p.ntiles = (int)cdiv64(npix, p.NP);
-        if (p.M <= 32 && p.C <= 32) return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 64, 1>(p, st);
+        if (p.M <= 32 && p.C <= 32) {
+            // thin layers on large maps (the classifier, 24-channel blocks at 128x128): 256 pixels per stage, 4x fewer barriers per byte
+            static const int thin_np = [] { const char* e = getenv("S2K_WG_THIN_NP"); return e ? atoi(e) : 256; }();
+            if (thin_np == 256 && npix >= 262144) {
+                p.NP = 256; p.PSTR = p.NP + 1; p.CSQ = p.NP + 1; p.ntiles = (int)cdiv64(npix, p.NP);
+                return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 256, 1>(p, st);
+            }
+            return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 64, 1>(p, st);
+        }
         // tile edge per side: 128 unless it pads the side by more than 12 % (176 -> 256 wastes 45 %, 3 x 64 = 192 wastes 9 %)
         auto edge = [](int n) { return (n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64; };
         const int em = edge(p.M), ec = edge(p.C);

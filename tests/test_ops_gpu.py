@@ -598,3 +598,15 @@ def test_wgrad_1x1_with_prologue_on_p(B, M, C, H, pro):
     wgs = c.t("wgs", (1, M, C), "zeros")
     c.run("WGRAD", ["wgs"], 2e-4, P=P, BNVP=bnv, GATEP=None, Q=Q, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=H,
           KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=pro, PROQ=D.PRO_NONE, MODE=D.MODE_CONV)
+
+
+@pytest.mark.parametrize("M,C,pro", [(4, 32, D.PRO_RELU), (24, 24, D.PRO_NONE), (32, 13, D.PRO_SILU)])
+def test_wgrad_1x1_thin_large_map(M, C, pro):
+    """>= 262144 pixels and <= 32 channels on both sides: the 256-pixel-per-stage configuration (ragged last tile: 2 x 362 x 363)"""
+    c = Case(26)
+    B, H, W = 2, 362, 363
+    P, Q = c.t("p", (B, M, H, W)), c.t("q", (B, C, H, W))
+    bnv = c.bnv("bnv", C) if pro else None
+    wgs = c.t("wgs", (1, M, C), "zeros")
+    c.run("WGRAD", ["wgs"], 3e-4, P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bnv, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=W,
+          KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=W, PROP=D.PRO_NONE, PROQ=pro, MODE=D.MODE_CONV)
