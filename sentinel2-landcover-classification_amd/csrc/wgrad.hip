@@ -543,7 +543,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles; thin layers (few
     // channels, huge maps) take 128-pixel tiles, the rest 64 (two workgroups per CU by LDS)
     static const int wide = [] { const char* e = getenv("S2K_WG_WIDE"); return e ? atoi(e) : 0; }();
-    const bool thin = (p.M <= 32);
+    const bool thin = (p.M <= 32) || (p.M <= 64 && p.C <= 32);   // few channels on one side: 128-pixel tiles, waves split the pixels
     const int NPX = (thin || wide) ? 128 : 64;
     int XW = p.WO <= NPX ? p.WO : NPX;
     int R = NPX / ((XW + 1) & ~1);
@@ -566,8 +566,9 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.tiles_y = cdiv(p.HO, p.R);
     p.ntiles = p.B * p.tiles_x * p.tiles_y;
     p.NP = 0;
-    if (thin && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4, 128, 2>(p, st);
-    if (thin) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2, 128, 2>(p, st);
+    if (thin && p.M <= 32 && p.C <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 1, 4, 128, 2>(p, st);
+    if (thin && p.M <= 32) return launch_wg<WG_SPATIAL, 9, 1, 1, 1, 2, 2, 128, 2>(p, st);
+    if (thin) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 1, 2, 128, 2>(p, st);   // 64 x 32: the stem (48 x 13) and 64 x 24 skips no longer pad C to 64
     if (wide) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 128, 2>(p, st);
     if (p.IR * p.WS <= NTHREADS && p.WS == 66 && p.KW == 3) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1, 66>(p, st);   // 64-wide tiles
     if (p.IR * p.WS <= NTHREADS) return launch_wg<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, 1>(p, st);
