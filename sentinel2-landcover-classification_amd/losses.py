@@ -85,6 +85,19 @@ class _PixelLoss(torch.autograd.Function):
         return dlogits, None, None, None, None, None, None, None
 
 
+def _device_weights(owner, w, device):
+    """Class weights on the logits' device, uploaded once per (tensor version, device): a per-step host-to-device copy is a
+    synchronising call (and is not allowed while a HIP graph is being captured)."""
+    if w is None:
+        return None
+    key = (w.data_ptr(), w._version, str(device))
+    cached = getattr(owner, "_wcache", None)
+    if cached is None or cached[0] != key:
+        cached = (key, w.detach().to(device=device, dtype=torch.float32).contiguous())
+        owner._wcache = cached
+    return cached[1]
+
+
 @dataclass
 class FocalLoss:
     """alpha[y] * (1 - pt)^gamma * ce, pt = exp(-ce); `mean` is over ALL pixels, ignored ones
@@ -100,7 +113,7 @@ class FocalLoss:
             raise ValueError(f"Invalid reduction: {self.reduce_type}.")
         if self.gamma is None:
             raise TypeError("focal_loss_gamma must be set (the reference has no default either)")
-        return _PixelLoss.apply(y_hat, y, self.alpha, 1, int(self.ignore_index), self.reduce_type == "sum",
+        return _PixelLoss.apply(y_hat, y, _device_weights(self, self.alpha, y_hat.device), 1, int(self.ignore_index), self.reduce_type == "sum",
                                 float(self.gamma), float(self.label_smoothing))
 
 
@@ -113,7 +126,8 @@ class CrossEntropyLoss:
     ignore_index: int = -100
 
     def __call__(self, y_hat: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        return _PixelLoss.apply(y_hat, y, self.weight, 0, int(self.ignore_index), False, 0.0, float(self.label_smoothing))
+        return _PixelLoss.apply(y_hat, y, _device_weights(self, self.weight, y_hat.device), 0, int(self.ignore_index), False, 0.0,
+                                float(self.label_smoothing))
 
 
 def class_mask(logits: torch.Tensor) -> torch.Tensor:

@@ -270,3 +270,46 @@ def test_deferred_decoder_wgrads_give_the_same_gradients(monkeypatch):
         grads.append(model._grad_buffer().clone())
     scale = grads[1].abs().max()
     assert (grads[0] - grads[1]).abs().max() <= 1e-5 * scale
+
+
+def test_training_step_is_hip_graph_capturable():
+    """include/s2k.h promises that the library only enqueues work on the caller's stream (+ its event-forked side stream):
+    a whole step (forward, loss, backward) must capture into a HIP graph and replay to the same gradients."""
+    from s2lc_amd.losses import FocalLoss
+
+    dev = torch.device("cuda:0")
+    model, net, sd = _model("b0", 4, 4, seed=47)
+    model.to(dev).train()
+    x = detgen.normal("graph.x", (2, 4, 64, 64), seed=47).to(dev)
+    y = detgen.labels("graph.y", (2, 64, 64), 4, seed=47).to(dev)
+    model.drop_connect_noise = detgen.uniform("graph.dc", (len(net.blocks), 2), 0, 1, seed=47).to(dev)
+    loss_fn = FocalLoss(torch.ones(4), 2.0, 0.0, ignore_index=0)
+    bufs0 = model._flat_bufs.clone()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = loss_fn(model(x), y)
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):           # warm-up outside the capture: plans, the library's side stream, class weights
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    model._flat_bufs.copy_(bufs0)
+    eager_loss = step().item()
+    eager_grads = model._grad_buffer().clone()
+    model._flat_bufs.copy_(bufs0)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = step()
+    model._grad_buffer().zero_()
+    model._flat_bufs.copy_(bufs0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - eager_loss) <= 1e-6 * abs(eager_loss)
+    scale = eager_grads.abs().max()
+    assert (model._grad_buffer() - eager_grads).abs().max() <= 1e-5 * scale
