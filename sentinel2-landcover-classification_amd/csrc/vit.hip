@@ -50,7 +50,10 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_fwd_kernel(const LnP p) {
         for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {     // LN_U independent loads in flight per lane
             float v[LN_U];
 #pragma unroll
-            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? xb[(int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+            for (int u = 0; u < LN_U; ++u) v[u] = xb[(int64_t)min(c0 + LN_NW * u, p.C - 1) * p.HW];   // unconditional (clamped) loads:
+            // hipcc turns `cond ? load : 0` into a branch per load and waits for each one in turn
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? v[u] : 0.0f;
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) { s += v[u]; q += (double)v[u] * v[u]; }
         }
@@ -75,7 +78,10 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_fwd_kernel(const LnP p) {
         for (int c0 = wave; c0 < p.C; c0 += LN_NW * LN_U) {
             float v[LN_U];
 #pragma unroll
-            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? xb[(int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+            for (int u = 0; u < LN_U; ++u) v[u] = xb[(int64_t)min(c0 + LN_NW * u, p.C - 1) * p.HW];   // unconditional (clamped) loads:
+            // hipcc turns `cond ? load : 0` into a branch per load and waits for each one in turn
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) v[u] = (ok && c0 + LN_NW * u < p.C) ? v[u] : 0.0f;
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
                 const int c = c0 + LN_NW * u;
@@ -132,9 +138,15 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
             float dv[LN_U], xv[LN_U];
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
+                const int64_t off = base + (int64_t)min(c0 + LN_NW * u, p.C - 1) * p.HW;   // clamped: loads never sit under a condition
+                dv[u] = p.dy[off];
+                xv[u] = p.x[off];
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
                 const bool on = ok && c0 + LN_NW * u < p.C;
-                dv[u] = on ? p.dy[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
-                xv[u] = on ? p.x[base + (int64_t)(c0 + LN_NW * u) * p.HW] : mean;
+                dv[u] = on ? dv[u] : 0.0f;
+                xv[u] = on ? xv[u] : mean;
             }
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
@@ -156,10 +168,16 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
             float dv[LN_U], xv[LN_U], ov[LN_U];
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
+                const int64_t off = base + (int64_t)min(c0 + LN_NW * u, p.C - 1) * p.HW;
+                dv[u] = p.dy[off];
+                xv[u] = p.x[off];
+                ov[u] = p.accum ? p.dx[off] : 0.0f;      // kernel-uniform condition
+            }
+#pragma unroll
+            for (int u = 0; u < LN_U; ++u) {
                 const bool on = ok && c0 + LN_NW * u < p.C;
-                dv[u] = on ? p.dy[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
-                xv[u] = on ? p.x[base + (int64_t)(c0 + LN_NW * u) * p.HW] : mean;
-                ov[u] = (on && p.accum) ? p.dx[base + (int64_t)(c0 + LN_NW * u) * p.HW] : 0.0f;
+                dv[u] = on ? dv[u] : 0.0f;
+                xv[u] = on ? xv[u] : mean;
             }
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
