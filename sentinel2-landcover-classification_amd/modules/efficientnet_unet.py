@@ -222,7 +222,7 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
 
     # -- engine ---------------------------------------------------------------------------
     def _make_plan(self, B: int, H: int, W: int, training: bool):
-        return plan_unet(self.spec, B, H, W, training, self._layout)
+        return plan_unet(self.spec, B, H, W, training, self._layout, defer_wgrads=getattr(self, "_defer_wgrads", None))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..engine import run_unet

@@ -728,7 +728,10 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
             p.marks.append(len(p.bwd.ops))
         bwd_aux_end = p.aux.mark()
         import os
-        if os.environ.get("S2K_DEFER_WGRAD", "1") != "0":
+        defer = getattr(p, "defer_wgrads", None)
+        if defer is None:
+            defer = os.environ.get("S2K_DEFER_WGRAD", "1") != "0"
+        if defer:
             p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(os.environ.get("S2K_DEFER_MIN_GFLOP", "4")))
         pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
         if bwd_aux_end > fwd_aux_end:
@@ -758,11 +761,14 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
 
 
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
-              bucket_floats: int = 8 << 20) -> UnetPlan:
+              bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None) -> UnetPlan:
+    """defer_wgrads: None = the S2K_DEFER_WGRAD default (on); False keeps the decoder's weight gradients where the tape emits
+    them, so that gradient buckets become final progressively (what the data-parallel reducer wants, see ddp.py)."""
     if H % 32 or W % 32:
         raise ValueError(f"EfficientnetUnet needs H, W multiples of 32, got {H}x{W}")
     layout = layout or build_layout(spec)
     p = _P(spec, layout, B, H, W, training)
+    p.defer_wgrads = defer_wgrads
     eps, mom = spec.bn_eps, spec.bn_momentum
     x_in = Act(TRef(D.BASE["X"], 0, (B, spec.in_channels, H, W), "f32", "x"), spec.in_channels, H, W,
                needs_grad=False)

@@ -144,3 +144,22 @@ def test_forward_without_gpu_fails_loudly():
     m = EfficientnetUnet(EfficientNetConfig("b0", 6, 4, class_distribution=[.25] * 4))
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 6, 64, 64))
+
+
+def test_reducer_plans_keep_gradient_buckets_progressive():
+    """At the benchmark size the single-GPU plan defers the decoder's weight gradients, so every bucket is final only at the
+    end of the backward; a plan built for the data-parallel reducer (defer_wgrads=False, what FlatGradReducer sets) must
+    finish its first buckets early so their all-reduce overlaps the rest of the backward.  Planning only, nothing is run."""
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+    from s2lc_amd.plan.unet_plan import plan_unet
+
+    model = EfficientnetUnet(EfficientNetConfig("b5", 13, 4, class_distribution=[0.25] * 4))
+    single = plan_unet(model.spec, 32, 256, 256, True, model._layout)
+    ddp = plan_unet(model.spec, 32, 256, 256, True, model._layout, defer_wgrads=False)
+    n_ops = len(ddp.bwd.ops)
+    assert len(ddp.bwd_param_marks) >= 3
+    first_end = [seg[1] for seg in ddp.bwd_param_marks]
+    assert first_end[0] < 0.35 * n_ops and first_end[1] < 0.8 * n_ops, first_end
+    assert single.bwd_param_marks[0][1] > 0.9 * len(single.bwd.ops)      # deferred: the decoder bucket closes at the very end
+    covered = sorted((lo, hi) for _, _, lo, hi in ddp.bwd_param_marks)
+    assert covered[0][0] == 0 and covered[-1][1] == model._layout.n_params and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
