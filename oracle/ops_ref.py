@@ -282,12 +282,27 @@ def op_se_fc_bwd(m: Mem, o):
     W1, W2 = m.view(o["W1"], (Q, C)), m.view(o["W2"], (C, Q))
     dgp = dgate * gate * (1 - gate)
     h = F.silu(hpre)
-    m.view(o["DW2"], (C, Q)).add_(dgp.t() @ h)
-    m.view(o["DB2"], (C,)).add_(dgp.sum(0))
     dhp = (dgp @ W2) * _act_grad(hpre, 2)
+    if o["DW1"] >= 0:
+        m.view(o["DW2"], (C, Q)).add_(dgp.t() @ h)
+        m.view(o["DB2"], (C,)).add_(dgp.sum(0))
+        m.view(o["DW1"], (Q, C)).add_(dhp.t() @ pool)
+        m.view(o["DB1"], (Q,)).add_(dhp.sum(0))
+    m.view(o["DPOOL"], (B, C)).copy_(dhp @ W1)
+    # what the kernels leave behind for SE_FC_WGRAD
+    m.view(o["HS"], (B, Q)).copy_(h)
+    dgate.copy_(dgp)
+    hpre.copy_(dhp)
+
+
+def op_se_fc_wgrad(m: Mem, o):
+    B, C, Q = o["B"], o["C"], o["CSQ"]
+    dgp, hs = m.view(o["DGP"], (B, C)), m.view(o["HS"], (B, Q))
+    dhp, pool = m.view(o["DHP"], (B, Q)), m.view(o["POOL"], (B, C))
+    m.view(o["DW2"], (C, Q)).add_(dgp.t() @ hs)
+    m.view(o["DB2"], (C,)).add_(dgp.sum(0))
     m.view(o["DW1"], (Q, C)).add_(dhp.t() @ pool)
     m.view(o["DB1"], (Q,)).add_(dhp.sum(0))
-    m.view(o["DPOOL"], (B, C)).copy_(dhp @ W1)
 
 
 def op_se_bwd_reduce(m: Mem, o):
@@ -693,7 +708,7 @@ DISPATCH = {
     "BN_BWD_APPLY": op_bn_bwd_apply, "BN_RESIDUAL": op_bn_residual, "CHANNEL_SUM": op_channel_sum,
     "LOSS_FWD": op_loss_fwd, "LOSS_BWD": op_loss_bwd, "ARGMAX": op_argmax,
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
-    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
+    "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_FC_WGRAD": op_se_fc_wgrad, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
     "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }

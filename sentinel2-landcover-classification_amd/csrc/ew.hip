@@ -603,15 +603,34 @@ int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
     float* hs = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_HS]);
     CHECK_PTRS("se_fc_bwd", dgate, gate, hpre, pool, w1, w2, dw1, db1, dw2, db2, dpool, hs);
     const int B = op.d[S2K_SE_FC_BWD_D_B], C = op.d[S2K_SE_FC_BWD_D_C], Q = op.d[S2K_SE_FC_BWD_D_CSQ];
-    if (!dgate || !gate || !hpre || !pool || !w1 || !w2 || !dw1 || !db1 || !dw2 || !db2 || !dpool || !hs || B <= 0) {
+    const bool params = dw1 || db1 || dw2 || db2;        // none: SE_FC_WGRAD computes them (possibly on the side stream)
+    if (!dgate || !gate || !hpre || !pool || !w1 || !w2 || !dpool || !hs || B <= 0 || (params && (!dw1 || !db1 || !dw2 || !db2))) {
         set_error("se_fc_bwd: bad args"); return S2K_EINVAL;
     }
     if (Q > 8192 || B > 65535) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
     if ((size_t)(C + 1024) * 4 > 64000) { set_error("se_fc_bwd: C too large"); return S2K_EINVAL; }
     hipLaunchKernelGGL(se_fc_bwd_a1_kernel, dim3(cdiv(Q, 64), B), dim3(1024), (C + 1024) * sizeof(float), c.stream, dgate, gate, hpre, w2, hs, B, C, Q);
     hipLaunchKernelGGL(se_fc_bwd_a2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, dgate, gate, hpre, w1, dpool, B, C, Q);
+    if (!params) return S2K_OK;
     const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
     hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);
+    return S2K_OK;
+}
+
+int launch_se_fc_wgrad(const S2kOp& op, const Ctx& c) {
+    const float* dgp = ref_ptr<const float>(c, op.t[S2K_SE_FC_WGRAD_T_DGP]);
+    const float* hs = ref_ptr<const float>(c, op.t[S2K_SE_FC_WGRAD_T_HS]);
+    const float* dhp = ref_ptr<const float>(c, op.t[S2K_SE_FC_WGRAD_T_DHP]);
+    const float* pool = ref_ptr<const float>(c, op.t[S2K_SE_FC_WGRAD_T_POOL]);
+    float* dw1 = ref_ptr<float>(c, op.t[S2K_SE_FC_WGRAD_T_DW1]);
+    float* db1 = ref_ptr<float>(c, op.t[S2K_SE_FC_WGRAD_T_DB1]);
+    float* dw2 = ref_ptr<float>(c, op.t[S2K_SE_FC_WGRAD_T_DW2]);
+    float* db2 = ref_ptr<float>(c, op.t[S2K_SE_FC_WGRAD_T_DB2]);
+    CHECK_PTRS("se_fc_wgrad", dgp, hs, dhp, pool, dw1, db1, dw2, db2);
+    const int B = op.d[S2K_SE_FC_WGRAD_D_B], C = op.d[S2K_SE_FC_WGRAD_D_C], Q = op.d[S2K_SE_FC_WGRAD_D_CSQ];
+    if (!dgp || !hs || !dhp || !pool || !dw1 || !db1 || !dw2 || !db2 || B <= 0 || C <= 0 || Q <= 0) { set_error("se_fc_wgrad: bad args"); return S2K_EINVAL; }
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
+    hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgp, hs, dhp, pool, dw1, db1, dw2, db2, B, C, Q);
     return S2K_OK;
 }
 

@@ -62,6 +62,7 @@ int launch_tile_prep(const S2kOp&, const Ctx&);
 int launch_se_bn_sums(const S2kOp&, const Ctx&);
 int launch_se_bn_combine(const S2kOp&, const Ctx&);
 int launch_space_to_depth(const S2kOp&, const Ctx&);
+int launch_se_fc_wgrad(const S2kOp&, const Ctx&);
 int launch_adam(float*, const float*, float*, float*, int64_t, float, float, float, float, float, int, hipStream_t);
 int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
 
@@ -80,7 +81,7 @@ static const char* const kNames[S2K_N_KINDS + 1] = {
     nullptr, "MEMSET", "AXPY", "WEIGHT_PACK", "CONV", "WGRAD", "WGRAD_FINALIZE", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD", "BN_FINALIZE",
     "SE_POOL", "SE_FC", "SE_FC_BWD", "SE_BWD_REDUCE", "BN_BWD_REDUCE", "BN_BWD_FINALIZE", "BN_BWD_APPLY", "BN_RESIDUAL",
     "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ACT_FWD", "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX",
-    "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "CONFUSION", "DROP_GATE", "TILE_PREP", "SE_BN_SUMS", "SE_BN_COMBINE", "SPACE_TO_DEPTH"};
+    "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD", "MAE_LOSS_BWD", "TRANSPOSE_CL", "CONFUSION", "DROP_GATE", "TILE_PREP", "SE_BN_SUMS", "SE_BN_COMBINE", "SPACE_TO_DEPTH", "SE_FC_WGRAD"};
 
 static int dispatch(const S2kOp& op, const Ctx& c) {
     switch (op.kind) {
@@ -125,6 +126,7 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_SE_BN_SUMS: return launch_se_bn_sums(op, c);
         case S2K_OP_SE_BN_COMBINE: return launch_se_bn_combine(op, c);
         case S2K_OP_SPACE_TO_DEPTH: return launch_space_to_depth(op, c);
+        case S2K_OP_SE_FC_WGRAD: return launch_se_fc_wgrad(op, c);
         default: set_error("unknown stage kind %d", op.kind); return S2K_ENOSYS;
     }
 }

@@ -86,7 +86,8 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "SE_POOL": (["Y", "BNV", "POOL"], [], ["B", "C", "HW", "PRO"], []),
     # HPRE = W1 pool + B1; GATE = sigmoid(W2 silu(HPRE) + B2)
     "SE_FC": (["POOL", "W1", "B1", "W2", "B2", "HPRE", "GATE"], [], ["B", "C", "CSQ"], []),
-    # DGATE is overwritten with d(pre-sigmoid), HPRE with d(pre-SiLU); HS = scratch [B][CSQ] for silu(HPRE)
+    # DGATE is overwritten with d(pre-sigmoid), HPRE with d(pre-SiLU); HS = scratch [B][CSQ] for silu(HPRE).
+    # DW1 / DB1 / DW2 / DB2 null: the parameter gradients are left to SE_FC_WGRAD (which may run on the side stream)
     "SE_FC_BWD": (["DGATE", "GATE", "HPRE", "POOL", "W1", "W2", "DW1", "DB1", "DW2", "DB2", "DPOOL", "HS"], [],
                   ["B", "C", "CSQ"], []),
     # DGATE[b][c] = sum_hw G * act(scale*Y+shift)
@@ -171,6 +172,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # Y[b][c*4 + dy*2 + dx][y][x] = X[b][c][2y + dy][2x + dx]   (H, W = the low-resolution size): the gradient of a
     # ConvTranspose2d(k2, s2) output regrouped so that its weight / data gradients are plain 1x1 contractions over 4*C channels
     "SPACE_TO_DEPTH": (["X", "Y"], [], ["B", "C", "H", "W"], []),
+    # parameter gradients of the two SE Linears from what SE_FC_BWD left behind (DGP = its DGATE, DHP = its HPRE, HS):
+    #   DW2[c][j] += sum_b DGP[b][c]*HS[b][j];  DB2 += sum_b DGP;  DW1[j][c] += sum_b DHP[b][j]*POOL[b][c];  DB1 += sum_b DHP
+    "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 

@@ -437,9 +437,12 @@ def squeeze_excite(p: _P, prefix: str, a: Act, se: int) -> Act:
             p.bwd.add("SE_BN_SUMS", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, PS=a.se_sums, B=B, C=C, HW=HW, ACT=D.ACT_SILU)
         else:
             p.bwd.add("SE_BWD_REDUCE", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, B=B, C=C, HW=HW, PRO=a.pro)
+        # the data-gradient part stays on the critical chain; the parameter gradients (a third of the stage's time, nothing
+        # downstream reads them before the bucket is finalised) go to the side stream as their own stage
         p.bwd.add("SE_FC_BWD", DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=p.param(w1), W2=p.param(w2),
-                  DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2), DB2=p.pgrad(b2), DPOOL=dpool, HS=hs,
-                  B=B, C=C, CSQ=se)
+                  DW1=None, DB1=None, DW2=None, DB2=None, DPOOL=dpool, HS=hs, B=B, C=C, CSQ=se)
+        p.bwd.add("SE_FC_WGRAD", DGP=dgate, HS=hs, DHP=hpre, POOL=pool, DW1=p.pgrad(w1), DB1=p.pgrad(b1), DW2=p.pgrad(w2),
+                  DB2=p.pgrad(b2), B=B, C=C, CSQ=se)
         a.mulbc, a.addbc, a.addscale = gate, dpool, 1.0 / HW
 
     p.tape.append(backward)
@@ -746,7 +749,7 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         for kind, f in p.bwd.ops:
             if kind == "WGRAD" and 2.0 * f["M"] * f["C"] * f["KH"] * f["KW"] * f["B"] * f["HO"] * f["WO"] > side_max:
                 continue      # two large MFMA-bound kernels side by side only fight for the same units
-            if kind in ("WGRAD", "DWCONV_WGRAD", "CHANNEL_SUM"):
+            if kind in ("WGRAD", "DWCONV_WGRAD", "CHANNEL_SUM", "SE_FC_WGRAD"):
                 f["_flags"] = D.FLAG_SIDE
             elif kind == "WGRAD_FINALIZE":
                 f["_flags"] = D.FLAG_JOIN

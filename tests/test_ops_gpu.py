@@ -428,6 +428,17 @@ def test_se_fc_and_backward(B, C, Q):
     dpool, hs = c.t("dpool", (B, C), "nan"), c.t("hs", (B, Q), "nan")
     c.run("SE_FC_BWD", ["dw1", "db1", "dw2", "db2", "dpool"], 1e-4, DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=w1,
           W2=w2, DW1=dw1, DB1=db1, DW2=dw2, DB2=db2, DPOOL=dpool, HS=hs, B=B, C=C, CSQ=Q)
+    # split form (what the planner emits): data gradient first, parameter gradients as a stage of their own
+    c = Case(14)
+    dgate, gate = c.t("dgate", (B, C)), c.t("gate", (B, C), "rand")
+    hpre, pool = c.t("hpre", (B, Q)), c.t("pool", (B, C), "rand")
+    w1, w2 = c.t("w1", (Q, C), scale=C ** -0.5), c.t("w2", (C, Q), scale=Q ** -0.5)
+    dw1, db1, dw2, db2 = c.t("dw1", (Q, C)), c.t("db1", (Q,)), c.t("dw2", (C, Q)), c.t("db2", (C,))
+    dpool, hs = c.t("dpool", (B, C), "nan"), c.t("hs", (B, Q), "nan")
+    first = ("SE_FC_BWD", dict(DGATE=dgate, GATE=gate, HPRE=hpre, POOL=pool, W1=w1, W2=w2, DW1=None, DB1=None, DW2=None, DB2=None,
+                               DPOOL=dpool, HS=hs, B=B, C=C, CSQ=Q))
+    c.run("SE_FC_WGRAD", ["dw1", "db1", "dw2", "db2", "dpool", "hs", "dgate", "hpre"], 1e-4, pre=[first], DGP=dgate, HS=hs, DHP=hpre,
+          POOL=pool, DW1=dw1, DB1=db1, DW2=dw2, DB2=db2, B=B, C=C, CSQ=Q)
 
 
 def test_axpy_memset():
