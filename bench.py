@@ -252,6 +252,7 @@ def main() -> None:
         }
         print(json.dumps(line))
     if dist is not None:
+        dist.barrier()          # rank 0 profiles after the timed region: nobody tears the group down under it
         dist.destroy_process_group()
 
 
