@@ -265,11 +265,16 @@ def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: i
     B = p.B
     T = k * k
     Ctot = sum(s.C for s in srcs)
-    p.table_entry(wname, M, Ctot, T)
+    # 1x1: the scratch layout [tap][M][C] IS the parameter's layout [M][C][1], so the kernel accumulates straight into the
+    # (zeroed) gradient buffer: no scratch memset, no WGRAD_FINALIZE traffic for these weights (most of the encoder / every Linear)
+    direct = T == 1
+    if not direct:
+        p.table_entry(wname, M, Ctot, T)
+    wtarget = p.pgrad(wname) if direct else p.wgs(wname)
     c_off = 0
     for s in srcs:
         p.bwd.add("WGRAD", P=dY, BNVP=None, GATEP=None, Q=s.raw, BNVQ=s.bnv, GATEQ=s.gate,
-                  WGS=p.wgs(wname).at(c_off), B=B, M=M, C=s.C, CTOT=Ctot, H=s.H, W=s.W, KH=k, KW=k,
+                  WGS=wtarget.at(c_off), B=B, M=M, C=s.C, CTOT=Ctot, H=s.H, W=s.W, KH=k, KW=k,
                   STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=D.PRO_NONE, PROQ=s.pro,
                   MODE=D.MODE_CONV)
         c_off += s.C
@@ -470,8 +475,7 @@ def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
             # Prithvi segmentation step)
             G4 = p.alloc("s2d:" + wname, (B, 4 * Cout, H, W))
             p.bwd.add("SPACE_TO_DEPTH", X=G, Y=G4, B=B, C=Cout, H=H, W=W)
-            p.table_entry(wname, Cin, 4 * Cout, 1)
-            p.bwd.add("WGRAD", P=src.raw, BNVP=src.bnv, GATEP=src.gate, Q=G4, BNVQ=None, GATEQ=None, WGS=p.wgs(wname),
+            p.bwd.add("WGRAD", P=src.raw, BNVP=src.bnv, GATEP=src.gate, Q=G4, BNVQ=None, GATEQ=None, WGS=p.pgrad(wname),   # [Cin][(co,dy,dx)] = the weight's own layout
                       B=B, M=Cin, C=4 * Cout, CTOT=4 * Cout, H=H, W=W, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
                       HO=H, WO=W, PROP=src.pro, PROQ=D.PRO_NONE, MODE=D.MODE_CONV)
             p.bwd.add("CHANNEL_SUM", G=G, OUT=p.pgrad(bname), B=B, C=Cout, HW=4 * H * W)

@@ -210,9 +210,9 @@ class _V:
         """weight / bias gradients (when trainable) and, if `dx` is given, the input gradient w.r.t. pro(x)."""
         p, B = self.p, self.p.B
         if self.trainable(wname):
-            p.table_entry(wname, M, K, 1)
+            # [M][K] scratch layout = the Linear weight's layout: accumulate straight into the gradient buffer (no finalize pass)
             p.bwd.add("WGRAD", P=dy, BNVP=None, GATEP=None, Q=x, BNVQ=self.ident_bnv(K) if pro != D.PRO_NONE else None, GATEQ=None,
-                      WGS=p.wgs(wname), B=B, M=M, C=K, CTOT=K, H=1, W=N, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N,
+                      WGS=p.pgrad(wname), B=B, M=M, C=K, CTOT=K, H=1, W=N, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N,
                       PROP=D.PRO_NONE, PROQ=pro, MODE=D.MODE_CONV)
             if bname:
                 p.bwd.add("CHANNEL_SUM", G=dy, OUT=p.pgrad(bname), B=B, C=M, HW=N)

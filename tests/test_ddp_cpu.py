@@ -37,8 +37,10 @@ def test_backward_segments_cover_every_parameter_after_its_last_write():
     for kind, fields in plan.bwd.ops:
         if kind == "WGRAD_FINALIZE":
             folded += fields["N_ENTRIES"]
-    assert folded == sum(1 for k in plan.bwd.ops if k[0] == "WGRAD" and k[1]["WGS"].off // 4 in
+    # (1x1 weights accumulate straight into the gradient buffer: only the scratch-bound ones are folded)
+    assert folded == sum(1 for k in plan.bwd.ops if k[0] == "WGRAD" and k[1]["WGS"].base == D.BASE["WGS"] and k[1]["WGS"].off // 4 in
                          {off for off, _ in plan.layout.params.values()})
+    assert any(k[0] == "WGRAD" and k[1]["WGS"].base == D.BASE["GRADS"] for k in plan.bwd.ops)
 
 
 def _free_port():
