@@ -740,7 +740,13 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
             defer = os.environ.get("S2K_DEFER_WGRAD", "1") != "0"
         if defer:
             p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(os.environ.get("S2K_DEFER_MIN_GFLOP", "4")))
-        pre_ops = [("MEMSET", dict(DST=TRef(D.BASE["WGS"], 0, (layout.n_params,), "f32"), BYTES=layout.n_params * 4))]
+        # zero the weight-gradient scratch of the convs that go through WGRAD_FINALIZE (3x3, 2x2-gather): one range from the
+        # first to the last such weight (1x1 convs / Linears accumulate straight into the gradient buffer and need none)
+        pre_ops = []
+        if p.table:
+            lo = min(r[0] for r in p.table)
+            hi = max(r[0] + r[1] * r[2] * r[3] for r in p.table)
+            pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["WGS"], lo * 4, (hi - lo,), "f32"), BYTES=(hi - lo) * 4)))
         if bwd_aux_end > fwd_aux_end:
             pre_ops.append(("MEMSET", dict(DST=TRef(D.BASE["AUX"], fwd_aux_end, (1,), "f32"),
                                            BYTES=bwd_aux_end - fwd_aux_end)))
