@@ -400,29 +400,53 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
     }
 }
 
-// ---- data gradient, stride 2 (4 layers of a b5): per-pixel gather with parity tests --------------------
+// ---- data gradient, stride 2 (4 layers of a b5) ------------------------------------------------------
+// A lane computes a 2x2 block of input pixels.  Input pixel (iy, ix) only meets the taps with (iy + PT - ky) and
+// (ix + PL - kx) even, i.e. each of the K*K taps feeds exactly ONE of the block's four pixels, and which one depends only on
+// the parities QY = (iy0 + PT) & 1, QX = PL & 1 of the band: the kernel body is instantiated for the four (QY, QX) and every
+// tap -> pixel assignment and tile offset is a compile-time constant (K*K multiply-adds per block; the per-pixel gather it
+// replaces walked all K*K taps for every pixel and skipped three quarters of them behind a parity branch).
+// Tile: dY rows r0 .. r0 + IRt - 1 (r0 = floor((iy0 + PT - K + 1) / 2), may be negative), columns -1 .. LW - 2, zeros outside.
+template <int K, int QY, int QX>
+__device__ __forceinline__ void dgrad_s2_block(const float* tp, int LW, const float* wk, float (&acc)[2][2]) {
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int dyy = QY ^ (ky & 1), dxx = QX ^ (kx & 1);       // the block pixel this tap feeds
+            // row / column of dY relative to the lane's base (a + A0, b + B0): (QY + dyy - ky) / 2 and (QX + dxx - kx) / 2
+            const int cy = (QY + dyy - ky) >> 1, cx = (QX + dxx - kx) >> 1;   // arithmetic shift: exact, the sums are even
+            acc[dyy][dxx] = fmaf(wk[ky * K + kx], tp[cy * LW + cx], acc[dyy][dxx]);
+        }
+}
+
+template <int K>
 __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s2_kernel(const DwP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                               // [PPB][IRt][LW]  (dY rows, zero outside)
     float* wsm = smem + p.PPB * p.IRt * p.LW;         // [PPB][K*K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K2 = p.K * p.K;
+    constexpr int K2 = K * K;
     const int64_t nplanes = (int64_t)p.B * p.C;
     const int64_t pl0 = (int64_t)(blockIdx.x / p.bands) * p.PPB;
     const int band = blockIdx.x % p.bands;
     const int iy0 = band * p.RT;                 // first input row of the band
     const int rows = min(p.RT, p.H - iy0);
-    int yo_lo = iy0 + p.PT - (p.K - 1);
-    yo_lo = yo_lo >= 0 ? (yo_lo + 1) / 2 : 0;
-    stage_band<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, yo_lo, 0);
+    const int e = iy0 + p.PT, qy = e & 1, qx = p.PL & 1;
+    const int lo = e - (K - 1);
+    const int r0 = lo >= 0 ? lo >> 1 : -((1 - lo) >> 1);          // floor(lo / 2)
+    stage_band<S2K_PRO_NONE>(p, p.dy, p.HO, p.WO, tile, pl0, nplanes, p.IRt, r0, -1);
     for (int idx = tid; idx < p.PPB * K2; idx += NTHREADS) {
         const int pl = idx / K2;
         const int64_t plane = pl0 + pl;
-        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * K2 + (idx - pl * K2)] : 0.0f;
+        wsm[idx] = p.w[((plane < nplanes ? plane : 0) % p.C) * K2 + (idx - pl * K2)];
     }
     __syncthreads();
-    const int n_in = rows * p.W;
-    const int chunks_per_plane = (n_in + 63) >> 6;
+    const int A0 = ((e - qy) >> 1) - r0, B0 = ((p.PL - qx) >> 1) + 1;   // tile row / column of block (0, 0)'s reference tap
+    const int bw = (p.W + 1) >> 1, bh = (rows + 1) >> 1;               // 2x2 blocks of the band
+    const int n_blk = bw * bh;
+    const int chunks_per_plane = (n_blk + 63) >> 6;
     const int wpp = p.PPB >= 4 ? 1 : 4 / p.PPB;
     const int per_plane = p.IRt * p.LW;
     double* st = p.stats ? p.stats + (int64_t)(blockIdx.x % p.nrep) * 2 * p.C : nullptr;
@@ -433,37 +457,35 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s2_kernel(const DwP p) 
         float s1 = 0.0f, s2 = 0.0f;
         float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
         if (p.pro != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
-        const float* tp = tile + pl * per_plane;
         const float* wk = wsm + pl * K2;
         for (int chn = wave % wpp; chn < chunks_per_plane; chn += wpp) {
             const int o = chn * 64 + lane;
-            if (o < n_in) {
-                const int r = o / p.W, ix = o - r * p.W;
-                const int iy = iy0 + r;
-                float acc = 0.0f;
-                for (int ky = 0; ky < p.K; ++ky) {
-                    const int ty = iy + p.PT - ky;
-                    if (ty < 0 || (ty & 1)) continue;
-                    const int yo = ty >> 1;
-                    if (yo >= p.HO) continue;
-                    const int rr = yo - yo_lo;
-                    for (int kx = 0; kx < p.K; ++kx) {
-                        const int tx = ix + p.PL - kx;
-                        if (tx < 0 || (tx & 1)) continue;
-                        const int xo = tx >> 1;
-                        if (xo >= p.WO) continue;
-                        acc = fmaf(wk[ky * p.K + kx], tp[rr * p.LW + xo], acc);
+            if (o < n_blk) {
+                const int a = o / bw, b = o - a * bw;
+                const float* tp = tile + pl * per_plane + (a + A0) * p.LW + b + B0;
+                float acc[2][2];
+                if (qy == 0 && qx == 0) dgrad_s2_block<K, 0, 0>(tp, p.LW, wk, acc);
+                else if (qy == 0) dgrad_s2_block<K, 0, 1>(tp, p.LW, wk, acc);
+                else if (qx == 0) dgrad_s2_block<K, 1, 0>(tp, p.LW, wk, acc);
+                else dgrad_s2_block<K, 1, 1>(tp, p.LW, wk, acc);
+#pragma unroll
+                for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+                    for (int dxx = 0; dxx < 2; ++dxx) {
+                        const int r = 2 * a + dyy, ix = 2 * b + dxx;
+                        if (r < rows && ix < p.W) {
+                            const int64_t off = plane * p.H * p.W + (int64_t)(iy0 + r) * p.W + ix;
+                            float v = acc[dyy][dxx];
+                            if (p.pro != S2K_PRO_NONE) {
+                                const float xr = p.x[off];
+                                v *= act_grad(fmaf(xr, scale, shift), p.pro);
+                                s1 += v;
+                                s2 = fmaf(v, (xr - mean) * invstd, s2);
+                            }
+                            if (p.beta) v += p.out[off];
+                            p.out[off] = v;
+                        }
                     }
-                }
-                const int64_t off = plane * p.H * p.W + (int64_t)iy * p.W + ix;
-                if (p.pro != S2K_PRO_NONE) {
-                    const float xr = p.x[off];
-                    acc *= act_grad(fmaf(xr, scale, shift), p.pro);
-                    s1 += acc;
-                    s2 = fmaf(acc, (xr - mean) * invstd, s2);
-                }
-                if (p.beta) acc += p.out[off];
-                p.out[off] = acc;
             }
         }
         if (st) {
@@ -532,7 +554,7 @@ static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP
 
 static int irt_fwd(int rt, const DwP& p) { return (rt - 1) * p.S + p.K; }
 static int irt_dgrad1(int rt, const DwP& p) { return rt + p.K - 1; }
-static int irt_dgrad2(int rt, const DwP& p) { int v = (rt + p.K - 2) / 2 + 2; return v > p.HO ? p.HO : v; }
+static int irt_dgrad2(int rt, const DwP& p) { return (rt + p.K - 2) / 2 + 3; }   // dY rows a band of rt input rows reaches (+ slack for the floor / 2x2 blocks)
 
 template <typename KernT>
 static int launch_dw(KernT kern, const DwP& p, size_t lds, hipStream_t st) {
@@ -620,8 +642,8 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
         return pr == 0 ? DW_DG(5, 0) : pr == 1 ? DW_DG(5, 1) : DW_DG(5, 2);
 #undef DW_DG
     }
-    const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO, true, false);
-    return launch_dw(dwconv_dgrad_s2_kernel, p, lds, c.stream);
+    const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO + 2, true, false);   // one zero column on either side
+    return p.K == 3 ? launch_dw(dwconv_dgrad_s2_kernel<3>, p, lds, c.stream) : launch_dw(dwconv_dgrad_s2_kernel<5>, p, lds, c.stream);
 }
 
 }  // namespace s2k
