@@ -18,7 +18,14 @@
  *     all work is enqueued on the caller's stream (graph-capturable);
  *   - return 0 on success, a negative S2K_E* code on failure, never throw; the message for the
  *     last failure on the calling thread is `s2k_last_error()`;
- *   - re-entrant, no mutable global state.
+ *   - re-entrant: may be called concurrently from several host threads, on several streams and
+ *     on several devices of one process.  The device that owns `stream` is made current for the
+ *     duration of a call and restored afterwards (a NULL stream means the caller's current
+ *     device).  The only mutable global is a mutex-guarded pool of per-device side streams;
+ *     a side stream + event pair is leased for ONE s2k_program_run and returned when it ends,
+ *     by which time all of its work has been ordered back onto the caller's stream;
+ *   - no environment variable changes what the shipped library computes (tuning switches exist
+ *     only in builds made with -DS2K_TUNING).
  */
 #ifndef S2K_H
 #define S2K_H

@@ -74,9 +74,12 @@ class Bases:
     def __init__(self):
         self.arr = (ctypes.c_void_p * len(D.BASES))()
         self.keep = {}
+        self.device = None      # device of the tensors behind the bases: made current around every launch (run / profile)
 
     def set(self, name: str, tensor) -> "Bases":
         self.keep[name] = tensor
+        if tensor is not None and self.device is None and tensor.is_cuda:
+            self.device = tensor.device
         self.arr[D.BASE[name]] = None if tensor is None else tensor.data_ptr()
         return self
 
@@ -85,17 +88,28 @@ class Bases:
         return ctypes.cast(self.arr, ctypes.c_void_p)
 
 
+def _guard(bases: Bases):
+    """The default stream's handle is 0 on every device, so the library cannot tell the device from the stream alone:
+    make the device that owns the tensors current for the call (a module on cuda:1 with cuda:0 current otherwise launches
+    on the wrong device)."""
+    import contextlib
+
+    return torch.cuda.device(bases.device) if bases.device is not None else contextlib.nullcontext()
+
+
 def run(packed: np.ndarray, bases: Bases, stream: int, begin: int = 0, end: int | None = None) -> None:
     end = len(packed) if end is None else end
-    check(lib().s2k_program_run(packed.ctypes.data, begin, end, bases.ptr, len(D.BASES), stream))
+    with _guard(bases):
+        check(lib().s2k_program_run(packed.ctypes.data, begin, end, bases.ptr, len(D.BASES), stream))
 
 
 def profile(packed: np.ndarray, bases: Bases, stream: int):
     nk = len(D.OPS) + 1
     ms = np.zeros(nk, dtype=np.float32)
     cnt = np.zeros(nk, dtype=np.int32)
-    check(lib().s2k_program_profile(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream,
-                                    ms.ctypes.data, cnt.ctypes.data))
+    with _guard(bases):
+        check(lib().s2k_program_profile(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream,
+                                        ms.ctypes.data, cnt.ctypes.data))
     names = {v: k for k, v in D.KIND.items()}
     return {names[k]: (float(ms[k]), int(cnt[k])) for k in range(1, nk) if cnt[k]}
 
@@ -103,5 +117,6 @@ def profile(packed: np.ndarray, bases: Bases, stream: int):
 def profile_ops(packed: np.ndarray, bases: Bases, stream: int) -> np.ndarray:
     """Per-stage device milliseconds (HIP events on the launch stream)."""
     ms = np.zeros(len(packed), dtype=np.float32)
-    check(lib().s2k_program_profile_ops(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream, ms.ctypes.data))
+    with _guard(bases):
+        check(lib().s2k_program_profile_ops(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream, ms.ctypes.data))
     return ms

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -170,6 +171,30 @@ __device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p,
 
 // ---- host side --------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+
+// Tuning / A-B switches exist only in a build made with -DS2K_TUNING (tools/, never the shipped libs2k.so): in the product
+// library every switch is its compiled-in default, so a leaked environment variable cannot change kernels or results.
+inline int tune_int(const char* name, int dflt) {
+#ifdef S2K_TUNING
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
+// hipFuncSetAttribute acts on the current device: remember per device whether a kernel's attribute has been set.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
 
 struct Ctx {
     void* const* bases;

@@ -528,7 +528,7 @@ static int pow2ceil(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 // tiling over rows of the COMPUTED plane (ho x wo); src rows needed per band = irt, src columns = lw
 static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP&), int lw, bool with_w, bool vec) {
     // outputs per workgroup: enough loads in flight per CU to cover HBM latency, LDS small enough for ~6 workgroups / CU
-    static const int target0 = [] { const char* e = getenv("S2K_DW_TARGET"); return e ? atoi(e) : 4096; }();
+    static const int target0 = tune_int("S2K_DW_TARGET", 4096);
     const int hw = ho * wo;
     p.LW = vec ? (lw + 3) & ~3 : lw | 1;     // vector layout: float4 rows; scalar layout: odd stride
     p.XG = cdiv(wo, 4);

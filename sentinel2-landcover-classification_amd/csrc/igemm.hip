@@ -605,10 +605,9 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     const size_t lds = (A_FLOATS + b_floats + 2 * (size_t)p.Ctot) * sizeof(float);
     if (BMODE == BM_SPATIAL && p.gate1) { set_error("conv: SE gate is only supported on 1x1 convs"); return S2K_EINVAL; }
     auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW, BVEC>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     if (lds > 160 * 1024) { set_error("conv: LDS %zu too large", lds); return S2K_EINVAL; }
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
@@ -625,7 +624,7 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     p.splits = 1;
     p.chunks_per_split = nchunks;
     p.y_elems = (int64_t)p.B * p.YC * p.HO * p.WO;
-    static const int force_splits = [] { const char* e = getenv("S2K_SPLITS"); return e ? atoi(e) : 0; }();
+    static const int force_splits = tune_int("S2K_SPLITS", 0);
     if (force_splits > 1 && allow_splitk && p.scratch && p.mode == S2K_MODE_CONV && nchunks >= 2 * force_splits) {
         p.chunks_per_split = cdiv(nchunks, force_splits);
         p.splits = cdiv(nchunks, p.chunks_per_split);
@@ -733,14 +732,14 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);
-        static const int small_max = [] { const char* e = getenv("S2K_PIX_SMALL_TILES"); return e ? atoi(e) : 400; }();
-        static const int k16_max = [] { const char* e = getenv("S2K_PIX_K16_MAX"); return e ? atoi(e) : 192; }();
-        static const int novec = [] { const char* e = getenv("S2K_PIX_NOVEC"); return e ? atoi(e) : 0; }();
+        static const int small_max = tune_int("S2K_PIX_SMALL_TILES", 400);
+        static const int k16_max = tune_int("S2K_PIX_K16_MAX", 192);
+        static const int novec = tune_int("S2K_PIX_NOVEC", 0);
         const bool bvec = !novec && p.mode != S2K_MODE_GATHER2X2 && (p.HW & 3) == 0;
 #define PIX_CFG(WMv, WNv, WVMv, WVNv, KCHv, ntl, sk) \
     (bvec ? launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, true>(p, ntl, st, sk) \
           : launch_cfg<BM_PIX, 1, WMv, WNv, WVMv, WVNv, KCHv, 1, 2, false>(p, ntl, st, sk))
-        static const int force_cfg = [] { const char* e = getenv("S2K_PIX_FORCE"); return e ? atoi(e) : 0; }();
+        static const int force_cfg = tune_int("S2K_PIX_FORCE", 0);
         if (force_cfg == 1) return PIX_CFG(1, 1, 2, 2, 64, cdiv(p.Ntot, 64), true);
         if (force_cfg == 2) return PIX_CFG(2, 2, 2, 2, 64, cdiv(p.Ntot, 128), true);
         if (force_cfg == 3) return PIX_CFG(2, 2, 1, 4, 16, cdiv(p.Ntot, 256), false);
@@ -772,7 +771,7 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         return launch_cfg<BM_SPATIAL, 9, 1, 1, 2, 2, 8, 2>(p, (int)tiles, st);
     }
     // thin layers (M <= 32, full-resolution maps): 32 x 1024 tiles amortise the halo (6 rows per 4)
-    static const int thin_mode = [] { const char* e = getenv("S2K_THIN"); return e ? atoi(e) : 1; }();
+    static const int thin_mode = tune_int("S2K_THIN", 1);
     if (thin_mode == 1 && p.S == 1 && cdiv64(out_px, 512) >= 200 && geom(512, 5 * NTHREADS))
         return launch_cfg<BM_SPATIAL, 9, 1, 4, 1, 4, 8, 5>(p, (int)tiles, st);
     if (p.S == 1 && cdiv64(out_px, 1024) >= 200 && geom(1024, 7 * NTHREADS))

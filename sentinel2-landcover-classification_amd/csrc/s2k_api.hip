@@ -1,11 +1,15 @@
 // C-ABI entry points (include/s2k.h) and the native stage executor.
 //
 // The executor is the "runtime" of this path: a plain loop over POD stage records that enqueues
-// hand-written kernels on the caller's HIP stream.  No allocation, no synchronisation, no global
-// mutable state — so a whole forward or backward is graph-capturable and costs one FFI call.
+// hand-written kernels on the caller's HIP stream.  No device allocation, no synchronisation; the only
+// mutable global is a mutex-guarded pool of per-device side streams leased per call — so a whole
+// forward or backward is graph-capturable, costs one FFI call, and may be issued from several host
+// threads / streams / devices at once.
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include <stdlib.h>
 
@@ -163,50 +167,97 @@ const char* s2k_kind_name(int kind) { return (kind > 0 && kind <= S2K_N_KINDS) ?
 // HBM-bound BatchNorm / depthwise stages of the layers below.  Fork = event on the caller's stream the side stream waits
 // for (re-armed whenever main-stream work was issued since the last fork); join = the reverse, in front of every stage
 // flagged S2K_FLAG_JOIN and at the end of the call, so on return all work is ordered on the caller's stream again.
+//
+// Side queues are pooled PER DEVICE and leased for the duration of one s2k_program_run: two host threads, two caller
+// streams or two devices in one process never share a stream or an event pair (the pool, guarded by a mutex, is the only
+// mutable global of the library; a queue goes back to the pool when the call returns — by then every event it recorded has
+// been waited for by the caller's stream, so the next lessee may re-record them).
 struct SideQueue {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
 };
-static SideQueue& side_queue() {
-    static SideQueue q = [] {
-        SideQueue s;
-        const char* e = getenv("S2K_NO_SIDE_STREAM");
-        if (e && e[0] == '1') return s;
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return s;
-        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return s;
-        if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return s;
-        s.ok = true;
-        return s;
-    }();
+constexpr int kMaxDevices = 64;
+static std::mutex g_pool_mu;
+static std::vector<SideQueue*> g_pool[kMaxDevices];
+
+static bool side_streams_enabled() {
+    static const bool on = tune_int("S2K_NO_SIDE_STREAM", 0) == 0;
+    return on;
+}
+
+static SideQueue* lease_side_queue(int device) {
+    if (device < 0 || device >= kMaxDevices || !side_streams_enabled()) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool[device].empty()) {
+            SideQueue* q = g_pool[device].back();
+            g_pool[device].pop_back();
+            return q;
+        }
+    }
+    SideQueue* q = new SideQueue;   // created with `device` current (the caller holds the device guard)
+    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&q->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->join, hipEventDisableTiming) != hipSuccess) {
+        if (q->fork) (void)hipEventDestroy(q->fork);
+        if (q->stream) (void)hipStreamDestroy(q->stream);
+        delete q;
+        (void)hipGetLastError();
+        return nullptr;                   // no side stream: everything runs on the caller's stream (still correct)
+    }
     return q;
 }
+
+static void release_side_queue(int device, SideQueue* q) {
+    if (!q) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool[device].push_back(q);
+}
+
+// Makes the device that owns `stream` current for the duration of a call (kernel launches, event / stream creation and
+// hipFuncSetAttribute all act on the current device) and restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    bool switched = false;
+    explicit DeviceGuard(hipStream_t st) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        dev = prev;
+        int sd = -1;
+        if (st != nullptr && hipStreamGetDevice(st, &sd) == hipSuccess && sd >= 0) dev = sd;
+        (void)hipGetLastError();
+        if (dev != prev && dev >= 0) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 
 int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream) {
     if (!ops || !bases || begin < 0 || end < begin) { set_error("program_run: bad arguments"); return S2K_EINVAL; }
     hipStream_t main_st = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(main_st);
     Ctx c{bases, n_bases, main_st};
-    SideQueue& sq = side_queue();
+    bool any_side = false;
+    for (int i = begin; i < end && !any_side; ++i) any_side = (ops[i].flags & S2K_FLAG_SIDE) != 0;
+    SideQueue* sq = any_side ? lease_side_queue(guard.dev) : nullptr;
     bool side_busy = false;      // side work issued and not yet joined
     bool main_dirty = true;      // main-stream work issued since the last fork
     auto join = [&]() {
         if (!side_busy) return;
-        (void)hipEventRecord(sq.join, sq.stream);
-        (void)hipStreamWaitEvent(main_st, sq.join, 0);
+        (void)hipEventRecord(sq->join, sq->stream);
+        (void)hipStreamWaitEvent(main_st, sq->join, 0);
         side_busy = false;
     };
-    static const int skip_side = [] { const char* e = getenv("S2K_EXPERIMENT_SKIP_SIDE"); return e ? atoi(e) : 0; }();   // timing experiments only
+    int rc = S2K_OK;
     for (int i = begin; i < end; ++i) {
         const S2kOp& op = ops[i];
-        int rc;
-        if (skip_side && (op.flags & S2K_FLAG_SIDE)) continue;
-        if ((op.flags & S2K_FLAG_SIDE) && sq.ok) {
+        if ((op.flags & S2K_FLAG_SIDE) && sq) {
             if (main_dirty) {
-                (void)hipEventRecord(sq.fork, main_st);
-                (void)hipStreamWaitEvent(sq.stream, sq.fork, 0);
+                (void)hipEventRecord(sq->fork, main_st);
+                (void)hipStreamWaitEvent(sq->stream, sq->fork, 0);
                 main_dirty = false;
             }
-            Ctx cs{bases, n_bases, sq.stream};
+            Ctx cs{bases, n_bases, sq->stream};
             rc = check_launch(dispatch(op, cs), op, i);
             side_busy = true;
         } else {
@@ -214,14 +265,16 @@ int s2k_program_run(const S2kOp* ops, int begin, int end, void* const* bases, in
             rc = check_launch(dispatch(op, c), op, i);
             main_dirty = true;
         }
-        if (rc != S2K_OK) { join(); return rc; }
+        if (rc != S2K_OK) break;
     }
     join();
-    return S2K_OK;
+    release_side_queue(guard.dev, sq);
+    return rc;
 }
 
 int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream) {
     if (!op || !bases) { set_error("op_launch: bad arguments"); return S2K_EINVAL; }
+    DeviceGuard guard(static_cast<hipStream_t>(stream));
     Ctx c{bases, n_bases, static_cast<hipStream_t>(stream)};
     return check_launch(dispatch(*op, c), *op, 0);
 }
@@ -248,6 +301,7 @@ static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases
         return S2K_EINVAL;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(st);
     Ctx c{bases, n_bases, st};
     const int n = end - begin;
     hipEvent_t* ev = new hipEvent_t[n + 1];
@@ -279,6 +333,7 @@ static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases
 
 int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, void* stream) {
+    DeviceGuard guard(static_cast<hipStream_t>(stream));
     const int rc = launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, static_cast<hipStream_t>(stream));
     if (rc != S2K_OK) return rc;
     const hipError_t e = hipGetLastError();
@@ -288,6 +343,7 @@ int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 
 int s2k_selftest_mfma(const float* a, const float* b, float* d, void* stream) {
     if (!a || !b || !d) { set_error("selftest: null pointer"); return S2K_EINVAL; }
+    DeviceGuard guard(static_cast<hipStream_t>(stream));
     launch_mfma_selftest(a, b, d, static_cast<hipStream_t>(stream));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("selftest: %s", hipGetErrorString(e)); return S2K_EHIP; }

@@ -414,10 +414,9 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     auto kern = wgrad_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, EPT, PROP, PROQ, WSC>;
     if (MODE == WG_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("wgrad: halo exceeds EPT"); return S2K_EINVAL; }
     if (MODE == WG_SPATIAL && p.R * p.XWe > NPJ) { set_error("wgrad: tile exceeds pixel slots"); return S2K_EINVAL; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     // Pixel splits.  The 9-tap kernels hold 144 accumulator registers (one workgroup per CU), the 1x1 / 2x2 kernels run
     // ~3 per CU: pick the split count whose workgroup count fills whole rounds of those slots (288 workgroups on 256
@@ -524,7 +523,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         p.ntiles = (int)cdiv64(npix, p.NP);
         if (p.M <= 32 && p.C <= 32) {
             // thin layers on large maps (the classifier, 24-channel blocks at 128x128): 256 pixels per stage, 4x fewer barriers per byte
-            static const int thin_np = [] { const char* e = getenv("S2K_WG_THIN_NP"); return e ? atoi(e) : 256; }();
+            static const int thin_np = tune_int("S2K_WG_THIN_NP", 256);
             if (thin_np == 256 && npix >= 262144) {
                 p.NP = 256; p.PSTR = p.NP + 1; p.CSQ = p.NP + 1; p.ntiles = (int)cdiv64(npix, p.NP);
                 return launch_wg<WG_PIX, 1, 1, 1, 1, 1, 4, 256, 1>(p, st);
@@ -542,7 +541,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     if (p.T != 9) { set_error("wgrad: only 1x1, 3x3 and 2x2-transpose kernels are on this path"); return S2K_EINVAL; }
     // 3x3 (stride 1 pad 1, or the stride-2 TF-SAME stem): rectangular pixel tiles; thin layers (few
     // channels, huge maps) take 128-pixel tiles, the rest 64 (two workgroups per CU by LDS)
-    static const int wide = [] { const char* e = getenv("S2K_WG_WIDE"); return e ? atoi(e) : 0; }();
+    static const int wide = tune_int("S2K_WG_WIDE", 0);
     const bool thin = (p.M <= 32) || (p.M <= 64 && p.C <= 32);   // few channels on one side: 128-pixel tiles, waves split the pixels
     const int NPX = (thin || wide) ? 128 : 64;
     int XW = p.WO <= NPX ? p.WO : NPX;

@@ -13,6 +13,51 @@ import torch
 from . import _lib
 
 
+class Workspace:
+    """The per-forward device state of a planned network: activation arena + statistics accumulators.  A training
+    forward LEASES one until its backward has run (or its autograd node dies), so fwd, fwd, bwd, bwd — two micro-batches,
+    two losses, a logging forward between forward and backward — never overwrite each other's saved activations."""
+
+    def __init__(self, ws_bytes: int, aux_bytes: int, device: torch.device):
+        pad = 256
+        self.ws = torch.empty(ws_bytes + pad, dtype=torch.uint8, device=device)
+        self.aux = torch.zeros(max(aux_bytes, 8) + pad, dtype=torch.uint8, device=device)
+
+
+class WorkspaceLease:
+    """Returns the workspace to its engine's pool when released or garbage-collected with the autograd node."""
+
+    def __init__(self, pool: list, space: Workspace):
+        self.pool, self.space = pool, space
+
+    def release(self) -> None:
+        if self.space is not None:
+            self.pool.append(self.space)
+            self.space = None
+
+    def __del__(self):
+        self.release()
+
+
+class WorkspacePool:
+    def __init__(self, ws_bytes: int, aux_bytes: int, device: torch.device):
+        self.args = (ws_bytes, aux_bytes, device)
+        self.free: list[Workspace] = [Workspace(*self.args)]
+        self.allocated = 1
+
+    def lease(self) -> WorkspaceLease:
+        if not self.free:       # an earlier forward still owns the last one (its backward is outstanding)
+            self.free.append(Workspace(*self.args))
+            self.allocated += 1
+        return WorkspaceLease(self.free, self.free.pop())
+
+    def peek(self) -> Workspace:
+        if not self.free:
+            self.free.append(Workspace(*self.args))
+            self.allocated += 1
+        return self.free[-1]
+
+
 class UnetEngine:
     """Buffers + packed programs for one (B, H, W, training) shape of one module."""
 
@@ -22,9 +67,7 @@ class UnetEngine:
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
         self.device = device
-        pad = 256
-        self.ws = torch.empty(plan.ws_bytes + pad, dtype=torch.uint8, device=device)
-        self.aux = torch.zeros(max(plan.aux_bytes, 8) + pad, dtype=torch.uint8, device=device)
+        self.spaces = WorkspacePool(plan.ws_bytes, plan.aux_bytes, device)
         self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
         self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)  # + slack: A-tile loads may overrun
         self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
@@ -32,9 +75,23 @@ class UnetEngine:
         self.B = B
         self.bwd_marks = plan.bwd_param_marks
 
-    def bases(self, module, x, out, dout=None, noise=None, grads=None) -> _lib.Bases:
+    @property
+    def resident(self) -> Workspace:
+        """The workspace a fresh forward would take (tests / profilers that drive the programs by hand)."""
+        return self.spaces.peek()
+
+    @property
+    def ws(self) -> torch.Tensor:
+        return self.resident.ws
+
+    @property
+    def aux(self) -> torch.Tensor:
+        return self.resident.aux
+
+    def bases(self, module, x, out, dout=None, noise=None, grads=None, space: Workspace | None = None) -> _lib.Bases:
+        space = space or self.resident
         b = _lib.Bases()
-        b.set("WS", self.ws).set("AUX", self.aux).set("CONST", self.const).set("WPACK", self.wpack)
+        b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
         b.set("PARAMS", module._flat_params).set("BUFS", module._flat_bufs)
         b.set("X", x).set("OUT", out)
         if self.wgs is not None:
@@ -70,15 +127,19 @@ class _UnetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, module, eng, noise):
         out = torch.empty(eng.plan.logits_shape, dtype=torch.float32, device=x.device)
-        bases = eng.bases(module, x, out, noise=noise)
+        lease = eng.spaces.lease()
+        bases = eng.bases(module, x, out, noise=noise, space=lease.space)
         _lib.run(eng.fwd, bases, _stream(x.device))
-        ctx.module, ctx.eng, ctx.noise = module, eng, noise
+        ctx.module, ctx.eng, ctx.noise, ctx.lease = module, eng, noise, lease
         ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        module, eng = ctx.module, ctx.eng
+        module, eng, lease = ctx.module, ctx.eng, ctx.lease
+        if lease.space is None:
+            raise RuntimeError("backward through the same forward a second time: the saved activations have been released "
+                               "(the s2k engine keeps them for one backward, like autograd without retain_graph)")
         (x,) = ctx.saved_tensors
         dout = dout.contiguous()
         scale = getattr(module, "_grad_scale", 1.0)
@@ -89,17 +150,19 @@ class _UnetFunction(torch.autograd.Function):
         module._overwrite_next = False
         grads = module._grad_buffer() if not accumulate else module._grad_scratch()
         grads.zero_()
-        bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads)
+        bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads, space=lease.space)
         hook = getattr(module, "_bwd_segment_hook", None)
         st = _stream(x.device)
-        if hook is None:
-            _lib.run(eng.bwd, bases, st)
-        else:
-            if accumulate:
-                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
-            for (a, b, lo, hi) in eng.bwd_marks:
-                _lib.run(eng.bwd, bases, st, a, b)
-                hook(lo, hi, grads)
+        with torch.cuda.device(x.device):
+            if hook is None:
+                _lib.run(eng.bwd, bases, st)
+            else:
+                if accumulate:
+                    raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+                for (a, b, lo, hi) in eng.bwd_marks:
+                    _lib.run(eng.bwd, bases, st, a, b)
+                    hook(lo, hi, grads)
+        lease.release()     # stream-ordered: the next forward that takes this workspace is enqueued behind this backward
         if accumulate:
             module._grad_buffer().add_(grads)
         if not live:
@@ -133,5 +196,7 @@ def run_unet(module, x: torch.Tensor) -> torch.Tensor:
         anchor = module._anchor(x.device)
         return _UnetFunction.apply(x, anchor, module, eng, noise)
     out = torch.empty(eng.plan.logits_shape, dtype=torch.float32, device=x.device)
-    _lib.run(eng.fwd, eng.bases(module, x, out, noise=noise), _stream(x.device))
+    lease = eng.spaces.lease()
+    _lib.run(eng.fwd, eng.bases(module, x, out, noise=noise, space=lease.space), _stream(x.device))
+    lease.release()
     return out

@@ -55,6 +55,24 @@ class UnetSpec:
     drop_connect_rate: float | None
 
 
+_TUNE_WARNED = False
+
+
+def tune(name: str, default: str) -> str:
+    """Planner A-B switches (tools/ experiments).  Honoured only when S2K_TUNING=1 is set as well, and announced loudly:
+    a leaked variable can never silently change the product's plans."""
+    import os
+    import sys
+
+    global _TUNE_WARNED
+    if os.environ.get("S2K_TUNING") != "1" or name not in os.environ:
+        return default
+    if not _TUNE_WARNED:
+        print("s2k: S2K_TUNING=1 — planner tuning switches from the environment are ACTIVE (experiments only)", file=sys.stderr)
+        _TUNE_WARNED = True
+    return os.environ[name]
+
+
 def same_pads(size: int, k: int, s: int) -> tuple[int, int]:
     """TF 'SAME' (efficientnet_unet.py:288-297): returns (out, pad_before)."""
     out = math.ceil(size / s)
@@ -436,8 +454,7 @@ def squeeze_excite(p: _P, prefix: str, a: Act, se: int) -> Act:
         dgate = p.alloc("dgate:" + prefix, (B, C))
         dpool = p.alloc("dpool:" + prefix, (B, C))
         hs = p.alloc("hs:" + prefix, (B, se))
-        import os
-        if a.bn_silu_producer and a.pro == D.PRO_SILU and os.environ.get("S2K_SE_BN_TWO_PASS", "1") != "0":
+        if a.bn_silu_producer and a.pro == D.PRO_SILU and tune("S2K_SE_BN_TWO_PASS", "1") != "0":
             a.se_sums = p.alloc("se_sums:" + prefix, (4, B, C))
             p.bwd.add("SE_BN_SUMS", G=a.grad, Y=a.raw, BNV=a.bnv, DGATE=dgate, PS=a.se_sums, B=B, C=C, HW=HW, ACT=D.ACT_SILU)
         else:
@@ -467,8 +484,7 @@ def conv_transpose(p: _P, wname: str, bname: str, src: Act, Cout: int) -> Act:
 
     def backward():
         G = out.grad
-        import os
-        if os.environ.get("S2K_CONVT_S2D", "1") != "0":
+        if tune("S2K_CONVT_S2D", "1") != "0":
             # regroup the output gradient once (space-to-depth: [B][Cout][2H][2W] -> [B][(co,dy,dx)][H][W], one HBM pass), then the
             # weight gradient W[ci][(co,dy,dx)] and the data gradient are plain 1x1 contractions over 4*Cout channels on the fast
             # pixel kernels; the 2x2-gather wgrad keeps four accumulator tiles per wave and ran at ~37 TF/s (25 ms of the 158 ms
@@ -734,12 +750,11 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
             back()
             p.marks.append(len(p.bwd.ops))
         bwd_aux_end = p.aux.mark()
-        import os
         defer = getattr(p, "defer_wgrads", None)
         if defer is None:
-            defer = os.environ.get("S2K_DEFER_WGRAD", "1") != "0"
+            defer = tune("S2K_DEFER_WGRAD", "1") != "0"
         if defer:
-            p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(os.environ.get("S2K_DEFER_MIN_GFLOP", "4")))
+            p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(tune("S2K_DEFER_MIN_GFLOP", "4")))
         # zero the weight-gradient scratch of the convs that go through WGRAD_FINALIZE (3x3, 2x2-gather): one range from the
         # first to the last such weight (1x1 convs / Linears accumulate straight into the gradient buffer and need none)
         pre_ops = []
@@ -754,8 +769,7 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         segments = _bucket_backward(p, layout, table, bucket_floats)
         # weight / bias gradients feed nothing in the backward chain until the bucket's WGRAD_FINALIZE: the executor may run
         # them on its side stream, concurrently with the (mostly HBM-bound) BatchNorm / depthwise stages of the layers below
-        import os
-        side_max = float(os.environ.get("S2K_SIDE_MAX_GFLOP", "1e9")) * 1e9
+        side_max = float(tune("S2K_SIDE_MAX_GFLOP", "1e9")) * 1e9
         for kind, f in p.bwd.ops:
             if kind == "WGRAD" and 2.0 * f["M"] * f["C"] * f["KH"] * f["KW"] * f["B"] * f["HO"] * f["WO"] > side_max:
                 continue      # two large MFMA-bound kernels side by side only fight for the same units

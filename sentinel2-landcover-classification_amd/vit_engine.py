@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .engine import Workspace, WorkspacePool
 
 _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
 
@@ -17,17 +18,28 @@ class VitEngine:
         self.plan = plan
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
-        pad = 256
-        self.ws = torch.empty(plan.ws_bytes + pad, dtype=torch.uint8, device=device)
-        self.aux = torch.zeros(max(plan.aux_bytes, 8) + pad, dtype=torch.uint8, device=device)
+        self.spaces = WorkspacePool(plan.ws_bytes, plan.aux_bytes, device)
         self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
         self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)
         self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
         self.bwd_marks = plan.bwd_param_marks
 
-    def bases(self, module, x, out, noise, dout=None, grads=None) -> _lib.Bases:
+    @property
+    def resident(self) -> Workspace:
+        return self.spaces.peek()
+
+    @property
+    def ws(self) -> torch.Tensor:
+        return self.resident.ws
+
+    @property
+    def aux(self) -> torch.Tensor:
+        return self.resident.aux
+
+    def bases(self, module, x, out, noise, dout=None, grads=None, space: Workspace | None = None) -> _lib.Bases:
+        space = space or self.resident
         b = _lib.Bases()
-        b.set("WS", self.ws).set("AUX", self.aux).set("CONST", self.const).set("WPACK", self.wpack)
+        b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
         b.set("PARAMS", module._flat_params).set("BUFS", module._flat_bufs)
         b.set("X", x).set("OUT", out).set("NOISE", noise)
         if self.wgs is not None:
@@ -56,10 +68,11 @@ class _VitFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, module, eng, noise, primary):
         out = torch.empty(eng.plan.out_bytes + 256, dtype=torch.uint8, device=x.device)
-        _lib.run(eng.fwd, eng.bases(module, x, out, noise), _stream(x.device))
+        lease = eng.spaces.lease()     # held until the backward has run (engine.py, Workspace)
+        _lib.run(eng.fwd, eng.bases(module, x, out, noise, space=lease.space), _stream(x.device))
         v = eng.views(out)
         names = [primary] + [n for n in v if n != primary]
-        ctx.module, ctx.eng, ctx.noise, ctx.names, ctx.out = module, eng, noise, names, out
+        ctx.module, ctx.eng, ctx.noise, ctx.names, ctx.out, ctx.lease = module, eng, noise, names, out, lease
         ctx.save_for_backward(x)
         outs = tuple(v[n] for n in names)
         ctx.mark_non_differentiable(*outs[1:])
@@ -67,7 +80,9 @@ class _VitFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dprimary, *unused):
-        module, eng = ctx.module, ctx.eng
+        module, eng, lease = ctx.module, ctx.eng, ctx.lease
+        if lease.space is None:
+            raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
         (x,) = ctx.saved_tensors
         dout = dprimary.contiguous().reshape(eng.plan.dout_shape).to(torch.float32)
         scale = getattr(module, "_grad_scale", 1.0)
@@ -78,18 +93,20 @@ class _VitFunction(torch.autograd.Function):
         module._overwrite_next = False
         grads = module._grad_buffer() if not accumulate else module._grad_scratch()
         grads.zero_()
-        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads)
+        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads, space=lease.space)
         hook = getattr(module, "_bwd_segment_hook", None)
         st = _stream(x.device)
-        if hook is None:
-            _lib.run(eng.bwd, bases, st)
-        else:
-            if accumulate:
-                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
-            lo_min = eng.plan.trainable_lo
-            for (a, b, lo, hi) in eng.bwd_marks:
-                _lib.run(eng.bwd, bases, st, a, b)
-                hook(max(lo, lo_min), hi, grads)
+        with torch.cuda.device(x.device):
+            if hook is None:
+                _lib.run(eng.bwd, bases, st)
+            else:
+                if accumulate:
+                    raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+                lo_min = eng.plan.trainable_lo
+                for (a, b, lo, hi) in eng.bwd_marks:
+                    _lib.run(eng.bwd, bases, st, a, b)
+                    hook(max(lo, lo_min), hi, grads)
+        lease.release()
         if accumulate:
             module._grad_buffer().add_(grads)
         if not live:
@@ -142,5 +159,7 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
         names = [primary] + [n for n in plan.outputs if n != primary]
         return dict(zip(names, outs))
     out = torch.empty(plan.out_bytes + 256, dtype=torch.uint8, device=x.device)
-    _lib.run(eng.fwd, eng.bases(module, x, out, noise), _stream(x.device))
+    lease = eng.spaces.lease()
+    _lib.run(eng.fwd, eng.bases(module, x, out, noise, space=lease.space), _stream(x.device))
+    lease.release()
     return eng.views(out)

@@ -58,6 +58,7 @@ def test_train_programs_match_oracle_autograd(version, C, H, B, wide, dcr, defer
     still cover the whole gradient buffer."""
     ncls = 4
     if defer_all:
+        monkeypatch.setenv("S2K_TUNING", "1")          # planner switches are only honoured together with this one
         monkeypatch.setenv("S2K_DEFER_MIN_GFLOP", "0")
     model, net, sd, x, y, noise = _setup(version, C, H, B, ncls, seed=21, dcr=dcr)
     plan = model._make_plan(B, H, H, True)

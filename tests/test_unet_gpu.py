@@ -255,6 +255,7 @@ def test_deferred_decoder_wgrads_give_the_same_gradients(monkeypatch):
     x = detgen.normal("defer.x", (2, 6, 64, 64), seed=43).to(dev)
     y = detgen.labels("defer.y", (2, 64, 64), 4, seed=43).to(dev)
     grads = []
+    monkeypatch.setenv("S2K_TUNING", "1")       # planner switches are only honoured together with this one
     for min_gflop, on in (("0", "1"), ("4", "0")):
         monkeypatch.setenv("S2K_DEFER_MIN_GFLOP", min_gflop)
         monkeypatch.setenv("S2K_DEFER_WGRAD", on)
