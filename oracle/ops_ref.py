@@ -361,7 +361,7 @@ def op_bn_bwd_apply(m: Mem, o):
     if o["COEF"] >= 0:
         coef = m.view(o["COEF"], (3, C))
     else:   # fused form: BN_BWD_FINALIZE's arithmetic
-        n = float(o["COUNT"])
+        n = float("inf") if o.get("EVAL", 0) else float(o["COUNT"])   # eval-mode BatchNorm: statistics are constants
         st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
         m.view(o["DGAMMA"], (C,)).add_(st[1].to(m.fdtype))
         m.view(o["DBETA"], (C,)).add_(st[0].to(m.fdtype))

@@ -854,7 +854,7 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     fz.dgamma = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DGAMMA]);
     fz.dbeta = ref_ptr<float>(c, op.t[S2K_BN_BWD_APPLY_T_DBETA]);
     const double count = (double)op.n[S2K_BN_BWD_APPLY_N_COUNT];
-    fz.inv_count = count > 0 ? 1.0 / count : 0.0;
+    fz.inv_count = (count > 0 && !op.d[S2K_BN_BWD_APPLY_D_EVAL]) ? 1.0 / count : 0.0;   // EVAL: frozen statistics, Bq = Cq = 0
     fz.nrep = op.d[S2K_BN_BWD_APPLY_D_NREP] > 0 ? op.d[S2K_BN_BWD_APPLY_D_NREP] : 1;
     CHECK_PTRS("bn_bwd_apply", gp, y, bnv, coef, dy, fz.st2, fz.gamma, fz.dgamma, fz.dbeta);
     if (!gp || !y || !bnv || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
@@ -938,28 +938,62 @@ int launch_space_to_depth(const S2kOp& op, const Ctx& c) {
 }
 
 // ---------------- fused Adam (L2-coupled weight decay; torch.optim.Adam semantics) -------------------------------
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2) {
+// Same operation order as torch's single-tensor Adam (the optimiser the reference configures,
+// /root/reference/src/train_segmentation.py:109-115):  g' = g + wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'*g';
+// denom = sqrt(v)/sqrt(1-b2^t) + eps;  p -= (lr/(1-b1^t)) * m/denom.  The bias corrections are computed in double on the
+// host (Python does `1 - beta ** step` in double).  One float4 per lane: the pass streams 4 reads + 3 writes per parameter.
+struct AdamK {
+    float lr_c1;      // lr / (1 - b1^t)
+    float sq_c2;      // sqrt(1 - b2^t)
+    float b1w;        // 1 - b1
+    float b2, b2w;    // b2, 1 - b2
+    float eps, wd;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK k) {
+    if (k.wd != 0.0f) g = fmaf(k.wd, p, g);
+    m = fmaf(k.b1w, g - m, m);
+    v = fmaf(k.b2w * g, g, k.b2 * v);
+    const float denom = sqrtf(v) / k.sq_c2 + k.eps;
+    p = fmaf(-k.lr_c1, m / denom, p);
+}
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, const AdamK k) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float gi = g[i];
-        const float pi = p[i];
-        if (wd != 0.0f) gi = fmaf(wd, pi, gi);
-        const float mi = fmaf(b1, m[i], (1.0f - b1) * gi);
-        const float vi = fmaf(b2, v[i], (1.0f - b2) * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        adam_one(pv.x, gv.x, mv.x, vv.x, k); adam_one(pv.y, gv.y, mv.y, vv.y, k);
+        adam_one(pv.z, gv.z, mv.z, vv.z, k); adam_one(pv.w, gv.w, mv.w, vv.w, k);
+        reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
     }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
+}
+__global__ void adam_scalar_kernel(float* p, const float* g, float* m, float* v, int64_t n, const AdamK k) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                 int step, hipStream_t st) {
     if (!p || !g || !m || !v || n <= 0 || step <= 0) { set_error("adam: bad args"); return S2K_EINVAL; }
-    const float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
-    const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 4096);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
+    const double c1 = 1.0 - pow((double)b1, (double)step), c2 = 1.0 - pow((double)b2, (double)step);
+    AdamK k;
+    k.lr_c1 = (float)((double)lr / c1);
+    k.sq_c2 = (float)sqrt(c2);
+    k.b1w = (float)(1.0 - (double)b1);
+    k.b2 = b2;
+    k.b2w = (float)(1.0 - (double)b2);
+    k.eps = eps;
+    k.wd = wd;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (aligned) {
+        const int blocks = (int)std::min<int64_t>(cdiv64(cdiv64(n, 4), 256), 8192);
+        hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, k);
+    } else {
+        const int blocks = (int)std::min<int64_t>(cdiv64(n, 256), 8192);
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, k);
+    }
     return S2K_OK;
 }
 

@@ -61,8 +61,8 @@ class WorkspacePool:
 class UnetEngine:
     """Buffers + packed programs for one (B, H, W, training) shape of one module."""
 
-    def __init__(self, module, B: int, H: int, W: int, training: bool, device: torch.device):
-        plan = module._make_plan(B, H, W, training)
+    def __init__(self, module, B: int, H: int, W: int, training: bool, device: torch.device, want_bwd: bool | None = None):
+        plan = module._make_plan(B, H, W, training, want_bwd)
         self.plan = plan
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
@@ -70,7 +70,7 @@ class UnetEngine:
         self.spaces = WorkspacePool(plan.ws_bytes, plan.aux_bytes, device)
         self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
         self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)  # + slack: A-tile loads may overrun
-        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
+        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if plan.bwd is not None else None
         self.n_noise_rows = plan.n_noise_rows
         self.B = B
         self.bwd_marks = plan.bwd_param_marks
@@ -109,12 +109,12 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _engine(module, x: torch.Tensor, training: bool) -> UnetEngine:
-    key = (tuple(x.shape), training, x.device)
+def _engine(module, x: torch.Tensor, training: bool, want_bwd: bool) -> UnetEngine:
+    key = (tuple(x.shape), training, want_bwd, x.device)
     eng = module._engines.get(key)
     if eng is None:
         B, _, H, W = x.shape
-        eng = UnetEngine(module, B, H, W, training, x.device)
+        eng = UnetEngine(module, B, H, W, training, x.device, want_bwd)
         module._engines[key] = eng
     return eng
 
@@ -181,7 +181,11 @@ def run_unet(module, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("module and input are on different devices")
     x = x.contiguous()
     training = module.training
-    eng = _engine(module, x, training)
+    # train() plans always carry the backward program; eval() plans only when autograd wants one (torch differentiates an
+    # eval-mode module just the same: BatchNorm on its running statistics, no drop-connect)
+    differentiate = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+    want_bwd = training or differentiate
+    eng = _engine(module, x, training, want_bwd)
     noise = None
     if training:
         noise = module.drop_connect_noise
@@ -192,7 +196,7 @@ def run_unet(module, x: torch.Tensor) -> torch.Tensor:
             if tuple(noise.shape) != (eng.n_noise_rows, x.shape[0]):
                 raise ValueError(f"drop_connect_noise must be [{eng.n_noise_rows}, {x.shape[0]}]")
         module._flat_nbt += 1  # every BatchNorm's num_batches_tracked (one fused add over the flat view)
-    if training and torch.is_grad_enabled():
+    if differentiate:
         anchor = module._anchor(x.device)
         return _UnetFunction.apply(x, anchor, module, eng, noise)
     out = torch.empty(eng.plan.logits_shape, dtype=torch.float32, device=x.device)

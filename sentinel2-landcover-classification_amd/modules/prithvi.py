@@ -169,8 +169,9 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         return x.reshape(B, t, n, n, tub, p, p, C).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, C, t * tub, n * p, n * p)
 
     # -- engine -------------------------------------------------------------------------------------------
-    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.75):
-        return plan_mae(self.spec, B, mask_ratio, training, self._layout)
+    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.75, want_bwd: bool | None = None):
+        return plan_mae(self.spec, B, mask_ratio, training, self._layout,    # (no BatchNorm / dropout: training == want_bwd)
+                        bucket_floats=getattr(self, "_bucket_floats", 8 << 20))
 
     def _check(self, imgs):
         s = self.spec

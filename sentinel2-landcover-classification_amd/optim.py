@@ -1,9 +1,14 @@
 """Fused Adam over the flat parameter buffer.
 
 Same update as the reference's `torch.optim.Adam(lr, weight_decay)` (L2-coupled decay, betas
-(0.9, 0.999), eps 1e-8; /root/reference/src/train_segmentation.py:109-127) but one HIP launch per
-contiguous parameter range instead of ~900 per-tensor updates.  Parameters that never receive a
-gradient (`encoder.fc.*`) are skipped entirely, like torch skips `p.grad is None`.
+(0.9, 0.999), eps 1e-8; /root/reference/src/train_segmentation.py:109-127, train_mae_prithvi.py:98-116)
+but one HIP launch per contiguous parameter range instead of ~900 per-tensor updates.  Like torch, a
+parameter takes part in a step iff it `requires_grad` and holds a gradient (`p.grad is not None`):
+never-used parameters (`encoder.fc.*`), the fixed position tables and anything the user froze after
+construction are skipped entirely — no moment update, no weight decay.
+
+It IS a `torch.optim.Optimizer` (param_groups, state_dict / load_state_dict, add-on lr schedulers such
+as the reference's `get_lr_scheduler` wrap it unchanged); only `step` / `zero_grad` are replaced.
 """
 from __future__ import annotations
 
@@ -12,25 +17,31 @@ import torch
 from . import _lib
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        if not hasattr(module, "_flat_params"):
+            raise TypeError("FlatAdam optimises a module that keeps its parameters in one flat buffer (flat.FlatParamsMixin)")
         self.module = module
-        self.betas, self.eps = betas, eps
         self.step_count = 0
         self.m = None
         self.v = None
-        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas, "eps": eps}]
+        self._plist = None
+        super().__init__([p for p in module.parameters()], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
+    # -- which floats take part --------------------------------------------------------------------------
     def _ranges(self):
-        """Contiguous float ranges of the flat buffer that take part in the update."""
-        L = self.module._layout
-        skip = self.module._no_grad_params
+        """Contiguous float ranges of the flat buffer whose parameters currently hold a gradient."""
+        mod = self.module
+        if self._plist is None:
+            named = dict(mod.named_parameters())
+            skip = mod._no_grad_params
+            # every tensor starts on a 64-float boundary of the flat buffer; the padding floats (zeros, zero gradient) belong
+            # to the tensor in front of them, so neighbouring tensors form one contiguous range
+            self._plist = [(named[name], off, (named[name].numel() + 63) // 64 * 64, name in skip)
+                           for name, (off, shape) in mod._layout.params.items()]
         ranges, start, end = [], None, None
-        for name, (off, shape) in L.params.items():
-            n = 1
-            for s in shape:
-                n *= s
-            if name in skip:
+        for p, off, n, skipped in self._plist:
+            if skipped or not p.requires_grad or p.grad is None:
                 if start is not None:
                     ranges.append((start, end))
                     start = None
@@ -48,18 +59,44 @@ class FlatAdam:
         self.module._overwrite_next = True
 
     @torch.no_grad()
-    def step(self) -> None:
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         mod = self.module
         p, g = mod._flat_params, mod._grad_buffer()
         if not p.is_cuda:
             raise RuntimeError("FlatAdam runs on the GPU only")
         if self.m is None or self.m.device != p.device:
-            self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
+            self.m = torch.zeros_like(p) if self.m is None else self.m.to(p.device)
+            self.v = torch.zeros_like(p) if self.v is None else self.v.to(p.device)
         self.step_count += 1
         grp = self.param_groups[0]
+        b1, b2 = grp["betas"]
         st = torch.cuda.current_stream(p.device).cuda_stream
         L = _lib.lib()
-        for a, b in self._ranges():
-            _lib.check(L.s2k_adam_step(p.data_ptr() + 4 * a, g.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
-                                       self.v.data_ptr() + 4 * a, b - a, grp["lr"], self.betas[0], self.betas[1],
-                                       self.eps, grp["weight_decay"], self.step_count, st))
+        with torch.cuda.device(p.device):
+            for a, b in self._ranges():
+                _lib.check(L.s2k_adam_step(p.data_ptr() + 4 * a, g.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
+                                           self.v.data_ptr() + 4 * a, b - a, float(grp["lr"]), float(b1), float(b2),
+                                           float(grp["eps"]), float(grp["weight_decay"]), self.step_count, st))
+        return loss
+
+    # -- checkpointing -------------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        return {"state": {"step": self.step_count, "exp_avg": None if self.m is None else self.m.detach().clone(),
+                          "exp_avg_sq": None if self.v is None else self.v.detach().clone()},
+                "param_groups": groups, "layout_floats": int(self.module._flat_params.numel())}
+
+    def load_state_dict(self, state: dict) -> None:
+        if int(state.get("layout_floats", -1)) != int(self.module._flat_params.numel()):
+            raise ValueError("optimizer state belongs to a module with a different flat parameter layout")
+        st = state["state"]
+        self.step_count = int(st["step"])
+        dev = self.module._flat_params.device
+        self.m = None if st["exp_avg"] is None else st["exp_avg"].to(device=dev, dtype=torch.float32).clone()
+        self.v = None if st["exp_avg_sq"] is None else st["exp_avg_sq"].to(device=dev, dtype=torch.float32).clone()
+        for g, saved in zip(self.param_groups, state["param_groups"]):
+            g.update({k: v for k, v in saved.items() if k != "params"})

@@ -102,8 +102,10 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # COEF null: the FINALIZE arithmetic is done inside (from STATS2 / GAMMA / COUNT / NREP; DGAMMA, DBETA += the sums)
     # ACT / MULBC / ADDBC given (COEF null): GP is the raw upstream gradient and g' = (GP*MULBC + ADDBC*ADDSCALE) * act'(u) is
     # recomputed per element (the sums in STATS2 then come from SE_BN_SUMS / SE_BN_COMBINE instead of BN_BWD_REDUCE)
+    # EVAL: BatchNorm ran on its running statistics (module.eval()): mean / invstd are constants, so dY = A*g' only (the
+    # batch-statistics terms Bq, Cq vanish); DGAMMA / DBETA are the same sums
     "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC"], ["COUNT"],
-                     ["B", "C", "HW", "NREP", "ACT"], ["ADDSCALE"]),
+                     ["B", "C", "HW", "NREP", "ACT", "EVAL"], ["ADDSCALE"]),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"], [], ["B", "C", "HW"], ["KEEP"]),
     # OUT[c] += sum_{b,hw} G[b][c][hw]

@@ -154,8 +154,12 @@ class UnetPlan:
 class _P:
     """Planner state."""
 
-    def __init__(self, spec: UnetSpec, layout: ParamLayout, B: int, H: int, W: int, training: bool):
+    def __init__(self, spec: UnetSpec, layout: ParamLayout, B: int, H: int, W: int, training: bool, want_bwd: bool | None = None):
+        """training: BatchNorm on batch statistics (+ running-stat update), drop-connect / dropout active (module.train());
+        want_bwd: emit the backward program (default: iff training; eval-mode plans may carry one too: torch autograd
+        differentiates an eval()-mode module just the same)."""
         self.spec, self.layout, self.B, self.H, self.W, self.training = spec, layout, B, H, W, training
+        self.want_bwd = training if want_bwd is None else want_bwd
         self.ws = Arena(D.BASE["WS"])
         self.aux = Arena(D.BASE["AUX"])
         self.fwd = Program("unet_fwd")
@@ -264,7 +268,7 @@ def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: in
     # the FINALIZE step (replica sums -> coefficients, dgamma / dbeta) runs inside APPLY: one launch less per BatchNorm
     p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=p.param(prefix + ".weight"),
               DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COUNT=B * HW, B=B, C=C, HW=HW,
-              NREP=D.stats_replicas(C))
+              NREP=D.stats_replicas(C), EVAL=int(not p.training))
     return gp
 
 
@@ -341,9 +345,9 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
             raise RuntimeError(f"no gradient reached {wname}")
         dY = _bn_backward(p, bnprefix, out.grad, y, bnv, M, Ho * Wo, act,
                           out.mulbc, out.addbc, out.addscale, pre_stats=out.fused_stats2)
-        if bias:
-            pass  # a bias in front of BatchNorm has exactly zero gradient (sum of dY is 0); grads stay 0
-        _conv_dgrad_wgrad(p, wname, dY, srcs, M, k, stride, pt, pl, Ho, Wo, None)
+        # a bias in front of TRAIN-mode BatchNorm has exactly zero gradient (the batch mean absorbs it: sum of dY is 0), so no
+        # stage is spent on it; with eval-mode BatchNorm (constant statistics) it is sum(dY) like any other bias
+        _conv_dgrad_wgrad(p, wname, dY, srcs, M, k, stride, pt, pl, Ho, Wo, bias if (bias and not p.training) else None)
 
     p.tape.append(backward)
     return out
@@ -411,7 +415,7 @@ def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, e
             dY = out.grad
             p.bwd.add("BN_BWD_APPLY", GP=dY, Y=y, BNV=bnv, COEF=None, DY=dY, STATS2=st2, GAMMA=p.param(bnprefix + ".weight"),
                       DGAMMA=p.pgrad(bnprefix + ".weight"), DBETA=p.pgrad(bnprefix + ".bias"), MULBC=out.mulbc, ADDBC=out.addbc,
-                      COUNT=B * HWo, B=B, C=C, HW=HWo, NREP=1, ACT=D.ACT_SILU, ADDSCALE=out.addscale)
+                      COUNT=B * HWo, B=B, C=C, HW=HWo, NREP=1, ACT=D.ACT_SILU, ADDSCALE=out.addscale, EVAL=int(not p.training))
         else:
             dY = _bn_backward(p, bnprefix, out.grad, y, bnv, C, Ho * Wo, D.ACT_SILU, out.mulbc, out.addbc, out.addscale)
         p.bwd.add("DWCONV_WGRAD", DY=dY, X=src.raw, BNV=src.bnv, DW=p.pgrad(wname), **geo)
@@ -740,12 +744,12 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
                 f["SCRATCH"] = scratch
 
     fwd_aux_end = p.aux.mark()
-    if training and fwd_aux_end:
+    if fwd_aux_end:
         p.fwd.ops.insert(0, ("MEMSET", dict(DST=TRef(D.BASE["AUX"], 0, (fwd_aux_end,), "f32"), BYTES=fwd_aux_end)))
 
     bwd = None
     segments = []
-    if training:
+    if p.want_bwd:
         for back in reversed(p.tape):
             back()
             p.marks.append(len(p.bwd.ops))
@@ -788,13 +792,13 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
 
 
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
-              bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None) -> UnetPlan:
+              bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None, want_bwd: bool | None = None) -> UnetPlan:
     """defer_wgrads: None = the S2K_DEFER_WGRAD default (on); False keeps the decoder's weight gradients where the tape emits
     them, so that gradient buckets become final progressively (what the data-parallel reducer wants, see ddp.py)."""
     if H % 32 or W % 32:
         raise ValueError(f"EfficientnetUnet needs H, W multiples of 32, got {H}x{W}")
     layout = layout or build_layout(spec)
-    p = _P(spec, layout, B, H, W, training)
+    p = _P(spec, layout, B, H, W, training, want_bwd)
     p.defer_wgrads = defer_wgrads
     eps, mom = spec.bn_eps, spec.bn_momentum
     x_in = Act(TRef(D.BASE["X"], 0, (B, spec.in_channels, H, W), "f32", "x"), spec.in_channels, H, W,
@@ -852,4 +856,4 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
     segments, bwd = finish_plan(p, layout, training, bucket_floats)
 
     return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, n,
-                    segments if training else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())
+                    segments if p.want_bwd else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

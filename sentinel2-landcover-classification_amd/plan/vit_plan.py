@@ -395,14 +395,15 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
                    {"noise": noise}, B * Lp * 4, (1,), p.tensors, p.wpack.mark(), 0, x_shape)
 
 
-def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20) -> VitPlan:
+def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20,
+             want_bwd: bool | None = None) -> VitPlan:
     """PrithviSegmentationNet.forward (prithvi_segmentation.py:156-162)."""
     m = s.mae
     assert not m.decoder
     if m.img_size // m.patch_size * 16 != m.img_size:
         raise ValueError("the neck upsamples the patch grid x16: img_size must be 16 * (img_size // patch_size)")
     layout = layout or seg_layout(s)
-    p = _P(s, layout, B, m.img_size, m.img_size, training)
+    p = _P(s, layout, B, m.img_size, m.img_size, training, want_bwd)
     frozen = s.frozen_backbone
     v = _V(p, lambda name: not (frozen and name.startswith("backbone.")))
     Lp, Dm, E = m.num_patches, m.embed_dim, s.embed
@@ -426,7 +427,7 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
     NS = erec["NS"]
     p.fwd.add("TOKEN_GATHER", IN=latent, IDX=drop_idx, FILL=None, POS=None, OUT=t0, B=B, C=Dm, LIN=N, LOUT=Lp, POS_BY_SRC=0, POS_OFF=0,
               LIN_S=NS, LOUT_S=Lp)
-    a0 = Act(t0, Dm, g, g, needs_grad=(training and not frozen))
+    a0 = Act(t0, Dm, g, g, needs_grad=(p.want_bwd and not frozen))
     nk = "neck.feature_pyramid_net."
 
     def norm2d_gelu(prefix: str, src: Act) -> Act:
@@ -450,7 +451,7 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
         return out
 
     def encoder_tail_backward():
-        if not (training and not frozen):
+        if not (p.want_bwd and not frozen):
             return
         g_lat = p.alloc("g:latent", (B, Dm, NS))
         p.bwd.add("TOKEN_SCATTER", DOUT=a0.grad, IDX=drop_idx, DIN=g_lat, DFILL=None, B=B, C=Dm, LIN=N, LOUT=Lp, LIN_S=NS, LOUT_S=Lp)

@@ -60,3 +60,26 @@ def load_prithvi(num_frames: int, no_decoder: bool = True, weights: str | None =
 
         model._init_flat(mae_layout(model.spec))
     return model
+
+
+# ---- checkpoints written by the reference's trainers -------------------------------------------------------------
+_CKPT_PREFIXES = ("net._orig_mod.", "net.", "_orig_mod.")
+
+
+def strip_trainer_prefix(state: dict) -> dict:
+    """Keys of a Lightning checkpoint of the reference's modules: `self.net` is the model, and when `torch.compile` is on
+    (train_segmentation.py:70-75, train_mae_prithvi.py:59-64) the compiled wrapper adds `_orig_mod.`: `net._orig_mod.<name>`.
+    Returns the state with the model's own names; entries of other sub-modules (loss weights, metrics) are dropped."""
+    for pre in _CKPT_PREFIXES:
+        if any(k.startswith(pre) for k in state):
+            return {k[len(pre):]: v for k, v in state.items() if k.startswith(pre)}
+    return dict(state)
+
+
+def load_reference_checkpoint(model: nn.Module, path, strict: bool = True):
+    """Load a checkpoint saved by the reference (`ModelCheckpoint`, train_segmentation.py:247-255 — a dict with
+    `state_dict`) or a bare state dict into one of this package's modules; accepts the `net._orig_mod.` / `net.` prefixes.
+    The flat parameter buffer is kept (values are copied into the existing views)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False) if not isinstance(path, dict) else path
+    state = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    return model.load_state_dict(strip_trainer_prefix(state), strict=strict)

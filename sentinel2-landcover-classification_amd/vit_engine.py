@@ -13,15 +13,15 @@ _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
 
 
 class VitEngine:
-    def __init__(self, module, B: int, training: bool, mask_ratio: float, device: torch.device):
-        plan = module._make_plan(B, training, mask_ratio)
+    def __init__(self, module, B: int, training: bool, mask_ratio: float, device: torch.device, want_bwd: bool | None = None):
+        plan = module._make_plan(B, training, mask_ratio, want_bwd)
         self.plan = plan
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
         self.spaces = WorkspacePool(plan.ws_bytes, plan.aux_bytes, device)
         self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
         self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)
-        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if training else None
+        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if plan.bwd is not None else None
         self.bwd_marks = plan.bwd_param_marks
 
     @property
@@ -128,15 +128,17 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
     B = x.shape[0]
     trainable = any(p.requires_grad for p in module.parameters())
     is_seg = mask_ratio is None
-    # the segmentation head has BatchNorm / Dropout2d: its plan follows module.training; the MAE has neither, so a
-    # "training" plan (one that also carries the backward program) is only needed when a gradient is wanted
-    want_grad = torch.is_grad_enabled() and trainable and (module.training or not is_seg)
+    # the segmentation head has BatchNorm / Dropout2d: its plan follows module.training (train() plans always carry the
+    # backward program, eval() plans only when autograd wants one); the MAE has neither, so its plan carries a backward
+    # program iff a gradient is wanted
+    want_grad = torch.is_grad_enabled() and trainable
     training = module.training if is_seg else want_grad
+    want_bwd = (training or want_grad) if is_seg else want_grad
     mr = 0.0 if is_seg else float(mask_ratio)
-    key = (tuple(x.shape), training, mr, x.device)
+    key = (tuple(x.shape), training, want_bwd, mr, x.device)
     eng = module._engines.get(key)
     if eng is None:
-        eng = VitEngine(module, B, training, mr, x.device)
+        eng = VitEngine(module, B, training, mr, x.device, want_bwd)
         module._engines[key] = eng
     plan = eng.plan
     noise = torch.empty(max(plan.noise_bytes // 4, 1), dtype=torch.float32, device=x.device)
@@ -153,7 +155,7 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
     if is_seg and training:
         module._flat_nbt += 1
     primary = "logits" if is_seg else "loss"
-    if want_grad and (training or not is_seg):
+    if want_grad:
         anchor = module._anchor(x.device)
         outs = _VitFunction.apply(x, anchor, module, eng, noise, primary)
         names = [primary] + [n for n in plan.outputs if n != primary]

@@ -1,0 +1,104 @@
+"""One rank of the data-parallel rehearsal (tests/test_ddp_gpu.py): a fresh process per rank, all ranks on cuda:0,
+gradients reduced over gloo by the product's FlatGradReducer while the segmented backward runs.
+
+    python tests/ddp_worker.py RANK WORLD PORT OUTDIR CASE
+
+Mirrors what Lightning's implicit DDP does around the reference's training_step
+(/root/reference/src/train_segmentation.py:273-280): identical start weights (broadcast from rank 0), a shard of the
+global batch per rank, per-rank mean loss, gradients averaged over ranks, BatchNorm statistics per rank."""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def build_case(case: str, seed: int):
+    """(model on the CPU, global batch x, labels y or None, per-sample noise or None, loss function)."""
+    import torch
+
+    import s2lc_amd  # noqa: F401
+    from oracle import detgen
+    from oracle import efficientnet_unet_ref as R
+
+    if case.startswith("unet"):
+        from s2lc_amd.losses import FocalLoss
+        from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+        net = R.build("b0", 4, 4, drop_connect_rate=0.2)
+        sd = detgen.fill_state(R.state_shapes(net), seed=seed)
+        model = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.25] * 4, drop_connect_rate=0.2))
+        model.load_state_dict(sd)
+        model._bucket_floats = 1 << 20          # several gradient buckets even for a b0
+        x = detgen.normal("ddp.x", (4, 4, 64, 64), seed=77)
+        y = detgen.labels("ddp.y", (4, 64, 64), 4, seed=77)
+        noise = detgen.uniform("ddp.dc", (len(net.blocks), 4), 0.0, 1.0, seed=77)
+        loss_fn = FocalLoss(torch.ones(4), 2.0, 0.0, ignore_index=0)
+        return model, x, y, noise, loss_fn
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from tests.helpers import PRITHVI_SMALL
+
+    torch.manual_seed(seed)
+    model = MaskedAutoencoderViT(**PRITHVI_SMALL)
+    for p in model.parameters():
+        if p.requires_grad:
+            p.data.copy_(detgen.normal(f"ddp.mae.{seed}.{tuple(p.shape)}", tuple(p.shape), seed=seed) * 0.05)
+    model._bucket_floats = 4096
+    x = detgen.normal("ddp.mae.x", (4, 3, 1, 32, 32), seed=78)
+    noise = detgen.uniform("ddp.mae.noise", (4, 16), 0.0, 1.0, seed=78)
+    return model, x, None, noise, None
+
+
+def run_shard(model, case, x, y, noise, loss_fn, lo, hi, dev):
+    """forward + backward of samples [lo, hi) of the global batch; returns the loss."""
+    xs = x[lo:hi].to(dev)
+    if case.startswith("unet"):
+        model.train(case == "unet_train")
+        model.drop_connect_noise = noise[:, lo:hi].contiguous() if case == "unet_train" else None
+        loss = loss_fn(model(xs), y[lo:hi].to(dev))
+    else:
+        model.masking_noise = noise[lo:hi].contiguous()
+        loss, _, _ = model(xs, mask_ratio=0.75)
+    loss.backward()
+    return loss
+
+
+def main():
+    rank, world, port, outdir, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from s2lc_amd.ddp import FlatGradReducer
+
+        dev = torch.device("cuda:0")
+        model, x, y, noise, loss_fn = build_case(case, seed=5 + rank)      # different weights per rank: the broadcast must fix that
+        model.to(dev)
+        red = FlatGradReducer(model, dist)
+        red.broadcast_parameters(0)
+        torch.cuda.synchronize()
+        w0 = model._flat_params.detach().cpu().clone()
+        calls = []
+        inner = model._bwd_segment_hook
+
+        def hook(lo, hi, grads):
+            calls.append((lo, hi))
+            inner(lo, hi, grads)
+
+        model._bwd_segment_hook = hook
+        per = x.shape[0] // world
+        loss = run_shard(model, case, x, y, noise, loss_fn, rank * per, (rank + 1) * per, dev)
+        red.finish()
+        torch.cuda.synchronize()
+        torch.save(dict(rank=rank, grads=model._grad_buffer().detach().cpu(), w0=w0, loss=float(loss), calls=calls,
+                        bufs=model._flat_bufs.detach().cpu()), os.path.join(outdir, f"{case}.r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

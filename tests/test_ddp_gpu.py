@@ -1,0 +1,217 @@
+"""The data-parallel backward on a real GPU (reference: Lightning's implicit DDP around
+/root/reference/src/train_segmentation.py:273-280, train_mae_prithvi.py:236-243).
+
+  * the segmented backward program (one s2k_program_run per gradient bucket, a hook after each) gives the same
+    gradients as the unsegmented one, with tape-order (`_defer_wgrads=False`) plans, for the U-Net, the MAE and the
+    segmentation net; the data-parallel 1/world factor folded into the upstream gradient is exact;
+  * a 2-rank rehearsal on ONE GPU over gloo (fresh child processes, product FlatGradReducer): with BatchNorm in eval
+    mode the rank-averaged gradients equal the single-process gradients of the concatenated batch; in train mode they
+    equal the DDP-semantics oracle (mean over ranks of per-shard gradients, BatchNorm statistics per rank);
+    broadcast_parameters makes every rank start from rank 0's weights;
+  * fwd, fwd, bwd, bwd (two micro-batches in flight) equals fwd, bwd, fwd, bwd (per-forward workspace leases)."""
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import detgen
+from tests.helpers import PRITHVI_SEG_SMALL
+from tests.ddp_worker import build_case, run_shard
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+DEV = torch.device("cuda:0")
+
+
+def _flat_grads(model):
+    torch.cuda.synchronize()
+    return model._grad_buffer().detach().clone()
+
+
+def _close(a, b, rel):
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, (err, scale, err / max(scale, 1e-30))
+    return err / max(scale, 1e-30)
+
+
+@pytest.mark.parametrize("case", ["unet_train", "unet_eval", "mae"])
+def test_segmented_backward_equals_unsegmented(case):
+    model, x, y, noise, loss_fn = build_case(case, seed=5)
+    model.to(DEV)
+    model._defer_wgrads = False
+    run_shard(model, case, x, y, noise, loss_fn, 0, 4, DEV)
+    ref = _flat_grads(model)
+    assert ref.abs().max().item() > 0
+    bufs_ref = model._flat_bufs.clone()
+    # same model, same plan, now cut into segments with a hook after each
+    model2, *_ = build_case(case, seed=5)
+    model2.to(DEV)
+    model2._defer_wgrads = False
+    calls = []
+    model2._bwd_segment_hook = lambda lo, hi, grads: calls.append((lo, hi, grads.data_ptr()))
+    run_shard(model2, case, x, y, noise, loss_fn, 0, 4, DEV)
+    got = _flat_grads(model2)
+    eng = next(e for e in model2._engines.values() if e.bwd is not None)
+    assert len(eng.bwd_marks) >= 3, "the test must exercise several segments"
+    assert len(calls) == len(eng.bwd_marks)
+    # buckets arrive back to front and tile the flat gradient buffer exactly once
+    assert calls[0][1] == model2._layout.n_params and calls[-1][0] == 0
+    for (lo0, hi0, _), (lo1, hi1, _) in zip(calls, calls[1:]):
+        assert hi1 == lo0 and lo1 <= hi1
+    assert all(c[2] == model2._grad_buffer().data_ptr() for c in calls)
+    _close(got, ref, 2e-6)                      # float-atomic weight-gradient sums: order differs run to run
+    assert torch.allclose(model2._flat_bufs, bufs_ref, rtol=1e-6, atol=1e-7)
+    # the data-parallel mean is folded into the upstream gradient: grads scale exactly (powers of two)
+    model3, *_ = build_case(case, seed=5)
+    model3.to(DEV)
+    model3._defer_wgrads = False
+    model3._grad_scale = 0.5
+    model3._bwd_segment_hook = lambda lo, hi, grads: None
+    run_shard(model3, case, x, y, noise, loss_fn, 0, 4, DEV)
+    _close(_flat_grads(model3), 0.5 * ref, 2e-6)
+
+
+def test_segmented_backward_segmentation_net_frozen_and_unfrozen():
+    from s2lc_amd.losses import CrossEntropyLoss
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+
+    x = detgen.normal("ddp.seg.x", (2, 3, 1, 64, 64), seed=79).to(DEV)
+    y = detgen.labels("ddp.seg.y", (2, 64, 64), 4, seed=79).to(DEV)
+    for frozen in (True, False):
+        grads = []
+        for hooked in (False, True):
+            torch.manual_seed(3)
+            bb = MaskedAutoencoderViT(**PRITHVI_SEG_SMALL, _decoder=False, _flat=False)
+            cfg = PrithviSegmentationNetConfig(num_frames=1, num_classes=4, fcn_out_channels=8, fcn_num_convs=1, fcn_dropout=0.1,
+                                               frozen_backbone=frozen, embed_dim=32, patch_height=4, patch_width=4)
+            model = PrithviSegmentationNet(cfg, backbone=bb).to(DEV).train()
+            model._bucket_floats = 4096
+            model._defer_wgrads = False
+            model.masking_noise = detgen.uniform("ddp.seg.n", (2, 16), 0, 1, seed=79)
+            model.dropout_noise = detgen.uniform("ddp.seg.d", (2, 8), 0, 1, seed=79)
+            calls = []
+            if hooked:
+                model._bwd_segment_hook = lambda lo, hi, g: calls.append((lo, hi))
+            CrossEntropyLoss(ignore_index=0)(model(x), y).backward()
+            grads.append(_flat_grads(model))
+            if hooked:
+                eng = next(e for e in model._engines.values() if e.bwd is not None)
+                assert len(calls) == len(eng.bwd_marks) >= 2
+                lo_min = eng.plan.trainable_lo
+                assert min(c[0] for c in calls) == lo_min and (lo_min > 0) == frozen
+        _close(grads[1], grads[0], 2e-6)
+
+
+def test_two_forwards_in_flight_keep_their_own_activations():
+    """fwd(a), fwd(b), bwd(a), bwd(b) — the second forward must not overwrite what the first backward reads."""
+    model, x, y, noise, loss_fn = build_case("unet_train", seed=5)
+    model.to(DEV).train()
+    xa, xb = x[:2].to(DEV), x[2:].to(DEV)
+    ya, yb = y[:2].to(DEV), y[2:].to(DEV)
+
+    def fwd(xs, lo):
+        model.drop_connect_noise = noise[:, lo:lo + 2].contiguous()
+        return model(xs)
+
+    bufs0 = model._flat_bufs.clone()
+    la = loss_fn(fwd(xa, 0), ya)
+    la.backward()
+    ga = _flat_grads(model)
+    for p in model.parameters():
+        p.grad = None
+    lb = loss_fn(fwd(xb, 2), yb)
+    lb.backward()
+    gb = _flat_grads(model)
+    for p in model.parameters():
+        p.grad = None
+    model._flat_bufs.copy_(bufs0)
+    out_a = fwd(xa, 0)
+    out_b = fwd(xb, 2)                      # second forward before the first backward
+    eng = next(e for e in model._engines.values() if e.bwd is not None)
+    assert eng.spaces.allocated == 2        # it took a second workspace instead of overwriting the first
+    loss_fn(out_a, ya).backward()
+    _close(_flat_grads(model), ga, 2e-6)
+    for p in model.parameters():
+        p.grad = None
+    loss_fn(out_b, yb).backward()
+    _close(_flat_grads(model), gb, 2e-6)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss_fn(out_b, yb).backward()       # activations were released with the first backward (no retain_graph semantics)
+    # a no-grad logging forward between forward and backward does not disturb the pending backward either
+    for p in model.parameters():
+        p.grad = None
+    out_a = fwd(xa, 0)
+    with torch.no_grad():
+        fwd(xb, 2)
+    loss_fn(out_a, ya).backward()
+    _close(_flat_grads(model), ga, 2e-6)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rehearse(case, tmp_path, world=2):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "tests" / "ddp_worker.py"), str(r), str(world), str(port), str(tmp_path), case],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for p, out in zip(procs, outs):
+        assert p.returncode == 0, out[-3000:]
+    res = [torch.load(tmp_path / f"{case}.r{r}.pt") for r in range(world)]
+    return sorted(res, key=lambda d: d["rank"])
+
+
+@pytest.mark.parametrize("case", ["unet_eval", "unet_train", "mae"])
+def test_two_rank_rehearsal_matches_ddp_semantics(case, tmp_path):
+    world = 2
+    res = _rehearse(case, tmp_path, world)
+    # broadcast: every rank started from rank 0's weights (rank r was built from seed 5 + r)
+    model, x, y, noise, loss_fn = build_case(case, seed=5)
+    assert torch.equal(res[0]["w0"], res[1]["w0"])
+    assert torch.equal(res[0]["w0"], model._flat_params.detach().cpu())
+    # every rank holds the same, averaged gradients; buckets were reduced back to front
+    assert torch.equal(res[0]["grads"], res[1]["grads"])
+    for r in res:
+        assert len(r["calls"]) >= 3 and r["calls"][0][1] == model._layout.n_params and r["calls"][-1][0] == 0
+    model.to(DEV)
+    per = x.shape[0] // world
+    if case == "unet_train":
+        # DDP semantics with per-rank BatchNorm statistics: mean over ranks of the per-shard gradients
+        want = torch.zeros_like(model._flat_params)
+        bufs0 = model._flat_bufs.clone()
+        for r in range(world):
+            model._flat_bufs.copy_(bufs0)
+            for p in model.parameters():
+                p.grad = None
+            loss = run_shard(model, case, x, y, noise, loss_fn, r * per, (r + 1) * per, DEV)
+            want += _flat_grads(model) / world
+            assert abs(float(loss) - res[r]["loss"]) <= 1e-5 * abs(float(loss))
+            assert torch.allclose(model._flat_bufs.cpu(), res[r]["bufs"], rtol=1e-5, atol=1e-6)      # running statistics stay per rank
+    else:
+        # statistics-free networks (BatchNorm in eval mode / the MAE): rank-averaged gradients == the single-process
+        # gradients of the concatenated batch (per-rank mean losses over equal shards average to the global mean)
+        loss = run_shard(model, case, x, y, noise, loss_fn, 0, x.shape[0], DEV)
+        want = _flat_grads(model)
+        if case == "unet_eval":
+            assert abs(float(loss) - sum(r["loss"] for r in res) / world) <= 1e-5 * abs(float(loss))
+    rel = _close(res[0]["grads"].to(DEV), want, 5e-6 if case != "mae" else 2e-5)
+    print(f"{case}: 2-rank averaged gradients vs single-process reference: max rel err {rel:.2e}")

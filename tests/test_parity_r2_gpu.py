@@ -1,0 +1,263 @@
+"""GPU parity against fixtures generated from the imported reference (tests/golden/make_golden.py, make_golden_r2.py):
+
+  * Adam: two steps of the optimiser the reference configures (train_segmentation.py:109-115) — s2k_adam_step and the
+    product's FlatAdam fed with the reference's own gradients: parameters, exp_avg, exp_avg_sq to 1e-6;
+  * the reference's loss edge cases (losses.py:24-89: all-ignored batch, two classes, weighted alpha, label smoothing, sum
+    reduction) through the PRODUCT FocalLoss / CrossEntropyLoss on the GPU: values and gradients;
+  * the reference's Conv2dSamePadding geometries (efficientnet_unet.py:288-297; odd sizes, k5, stride 2) through the CONV and
+    DWCONV_FWD stages, and its _drop_connect (:390-398) through BN_RESIDUAL;
+  * a well-conditioned end-to-end gradient comparison with the reference: EfficientNet-UNet in EVAL mode (BatchNorm on its
+    running statistics), every parameter's gradient within 1e-3."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import detgen
+from oracle import efficientnet_unet_ref as R
+from s2lc_amd import _lib
+from s2lc_amd.plan import opdefs as D
+from s2lc_amd.plan.program import Program
+from tests.helpers import load, rel_err, sub
+from tests.test_ops_gpu import Case
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Adam
+# ---------------------------------------------------------------------------------------------------------------
+def _adam_setup():
+    g = load("adam_steps.npz")
+    lr, wd, b1, b2, eps = (float(v) for v in g["meta"])
+    net = R.build("b0", 6, 4)
+    sd = detgen.fill_state(R.state_shapes(net), seed=3)           # F2's deterministic weights = the fixture's p0
+    return g, (lr, wd, b1, b2, eps), sd
+
+
+def test_adam_kernel_two_steps_match_reference():
+    g, (lr, wd, b1, b2, eps), sd = _adam_setup()
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    worst = 0.0
+    for name in g["names"]:
+        name = str(name)
+        p = torch.from_numpy(sub(sd[name], 2048)).to(DEV)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for step in (1, 2):
+            gr = torch.from_numpy(g[f"g{step}:{name}"]).to(DEV)
+            _lib.check(L.s2k_adam_step(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, b1, b2, eps, wd, step, st))
+            torch.cuda.synchronize()
+            for got, key in ((p, "p"), (m, "m"), (v, "v")):
+                e = rel_err(got.cpu().numpy(), g[f"{key}{step}:{name}"])
+                worst = max(worst, e)
+                assert e < 1e-6, (name, step, key, e)
+    print(f"adam: worst relative error over params / exp_avg / exp_avg_sq, two steps: {worst:.2e}")
+
+
+def test_flat_adam_two_steps_match_reference():
+    """The product optimiser over the flat buffer: the reference's gradients are written into the flat gradient buffer (at the
+    fixture's strided positions of each chosen tensor), everything else keeps a zero gradient."""
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+    from s2lc_amd.optim import FlatAdam
+
+    g, (lr, wd, b1, b2, eps), sd = _adam_setup()
+    model = EfficientnetUnet(EfficientNetConfig("b0", 6, 4, class_distribution=[0.25] * 4))
+    model.load_state_dict(sd)
+    model.to(DEV)
+    fc_before = model.encoder.fc[3].weight.detach().clone()
+    opt = FlatAdam(model, lr=lr, weight_decay=wd)
+    named = dict(model.named_parameters())
+    idx = {}
+    for name in g["names"]:
+        name = str(name)
+        n = named[name].numel()
+        step_ = max(1, n // 2048)
+        idx[name] = torch.arange(0, n, step_)[:2048].to(DEV)
+    grads = model._grad_buffer()
+    model._publish_grads(model._no_grad_params)
+    for step in (1, 2):
+        grads.zero_()
+        for name, ix in idx.items():
+            off, shape = model._layout.params[name]
+            grads[off + ix] = torch.from_numpy(g[f"g{step}:{name}"]).to(DEV)
+        opt.step()
+        torch.cuda.synchronize()
+        for name, ix in idx.items():
+            off, _ = model._layout.params[name]
+            for buf, key in ((model._flat_params, "p"), (opt.m, "m"), (opt.v, "v")):
+                e = rel_err(buf[off + ix].cpu().numpy(), g[f"{key}{step}:{name}"])
+                assert e < 1e-6, (name, step, key, e)
+    # parameters that never receive a gradient are skipped like torch skips `grad is None` (no weight decay either)
+    assert torch.equal(model.encoder.fc[3].weight.detach(), fc_before) and float(g["fc_untouched"][0]) == 1.0
+    sdict = opt.state_dict()
+    opt2 = FlatAdam(model, lr=lr, weight_decay=wd)
+    opt2.load_state_dict(sdict)
+    assert opt2.step_count == 2 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference loss edge cases through the product losses
+# ---------------------------------------------------------------------------------------------------------------
+def _loss_inputs(C, which=""):
+    B, H = 2, 16
+    if C == 2:
+        return (detgen.normal("loss.logits2", (B, 2, H, H), std=2.0, seed=12), detgen.labels("loss.y2", (B, H, H), 2, p_zero=0.4, seed=12))
+    return (detgen.normal("loss.logits", (B, C, H, H), std=2.0, seed=11), detgen.labels("loss.y", (B, H, H), C, p_zero=0.2, seed=11))
+
+
+def test_product_losses_match_reference_edge_cases():
+    from s2lc_amd.losses import CrossEntropyLoss, FocalLoss
+
+    g = load("loss_cases.npz")
+    C = 4
+    alpha = torch.tensor([0.1, 0.9, 0.6, 0.7])
+    cases = {
+        "focal_g2": (FocalLoss(torch.ones(C), 2.0, 0.0, ignore_index=0), C),
+        "focal_g0p5_ls": (FocalLoss(torch.ones(C), 0.5, 0.1, ignore_index=0), C),
+        "focal_alpha": (FocalLoss(alpha, 2.0, 0.0, ignore_index=0), C),
+        "focal_noignore": (FocalLoss(torch.ones(C), 2.0, 0.0, ignore_index=-100), C),
+        "focal_sum": (FocalLoss(torch.ones(C), 2.0, 0.0, ignore_index=0, reduce_type="sum"), C),
+        "ce_masked": (CrossEntropyLoss(ignore_index=0), C),
+        "ce_plain": (CrossEntropyLoss(ignore_index=-100), C),
+        "ce_w_ls": (CrossEntropyLoss(weight=alpha, label_smoothing=0.1, ignore_index=0), C),
+        "focal_2class": (FocalLoss(torch.ones(2), 2.0, 0.0, ignore_index=0), 2),
+    }
+    for name, (fn, nc) in cases.items():
+        lg, y = _loss_inputs(nc)
+        l = lg.to(DEV).requires_grad_(True)
+        v = fn(l, y.to(DEV))
+        v.backward()
+        want = float(g["val:" + name][0])
+        assert abs(v.item() - want) <= 1e-5 * abs(want), (name, v.item(), want)
+        assert rel_err(l.grad.cpu().numpy(), g["grad:" + name]) < 1e-5, name
+    # all-ignored batch: focal = 0 with zero gradient, CE = NaN (0 / 0), exactly as torch
+    lg, y = _loss_inputs(4)
+    y0 = torch.zeros_like(y).to(DEV)
+    l = lg.to(DEV).requires_grad_(True)
+    v = FocalLoss(torch.ones(C), 2.0, 0.0, ignore_index=0)(l, y0)
+    v.backward()
+    assert v.item() == float(g["val:focal_allignored"][0]) == 0.0
+    assert np.array_equal(l.grad.cpu().numpy(), g["grad:focal_allignored"])
+    ce = CrossEntropyLoss(ignore_index=0)(lg.to(DEV), y0)
+    assert np.isnan(ce.item()) and np.isnan(g["val:ce_allignored"][0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference per-op geometries through the HIP stages
+# ---------------------------------------------------------------------------------------------------------------
+def _run_case(c, prog):
+    packed = prog.pack()
+    cpu = torch.zeros(c.arena.top + 256, dtype=torch.uint8)
+    for name, (ref, data) in c.items.items():
+        cpu[ref.off:ref.off + ref.nbytes] = data.contiguous().reshape(-1).view(torch.uint8)
+    gpu = cpu.cuda()
+    _lib.run(packed, _lib.Bases().set("WS", gpu), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return gpu.cpu()
+
+
+@pytest.mark.parametrize("name", ["same_k3s2_even", "same_k3s2_odd", "same_k5s2_even", "same_k5s2_odd", "same_k5s1", "same_k3s1"])
+def test_reference_same_padding_geometries(name):
+    from s2lc_amd.plan.unet_plan import same_pads
+
+    g = load("ops_cases.npz")
+    k, s, H, W, groups, cin, cout = (int(v) for v in g[name + ":cfg"])
+    want = g[name + ":y"]
+    B = 2
+    Ho, pt = same_pads(H, k, s)
+    Wo, pl = same_pads(W, k, s)
+    assert want.shape == (B, cout, Ho, Wo)
+    wshape = (cout, cin // groups, k, k)
+    w = detgen.uniform(name + ".w", wshape, -1, 1)
+    x = detgen.normal(name + ".x", (B, cin, H, W))
+    c = Case(0)
+    xr = c.t("x", (B, cin, H, W), x)
+    yr = c.t("y", (B, cout, Ho, Wo), "nan")
+    prog = Program()
+    if groups == 1:
+        T = k * k
+        wr = c.t("w", (cout, cin, T), w.reshape(cout, cin, T))
+        pre, wp, MP = c.pack(wr, cout, cin, T, cin * T, T, 1, 0)
+        prog.add(pre[0], **pre[1])
+        prog.add("CONV", X1=xr, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=yr, STATS=None, B=B, C1=cin, C2=0,
+                 H=H, W=W, M=cout, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PRO1=0, PRO2=0, MODE=0, W_SM=1,
+                 W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=cout, NREP=1)
+    else:
+        assert groups == cin == cout       # depthwise
+        wr = c.t("w", (cin, k, k), w.reshape(cin, k, k))
+        prog.add("DWCONV_FWD", X=xr, BNV=None, WT=wr, Y=yr, STATS=None, B=B, C=cin, H=H, W=W, K=k, STRIDE=s, PAD_T=pt, PAD_L=pl,
+                 HO=Ho, WO=Wo, PRO=0, NREP=1)
+    got = _run_case(c, prog)
+    y = got[yr.off:yr.off + yr.nbytes].view(torch.float32).reshape(want.shape).numpy()
+    assert rel_err(y, want) < 1e-5, name
+
+
+def test_reference_drop_connect_through_bn_residual():
+    """_drop_connect(x, 0.1, training=True) with injected uniforms == BN_RESIDUAL with an identity BatchNorm and no identity input."""
+    g = load("ops_cases.npz")
+    x = detgen.normal("dc.x", (4, 3, 2, 2))
+    u = torch.tensor([0.05, 0.5, 0.85, 0.95])
+    c = Case(0)
+    yr = c.t("y", (4, 3, 4), x.reshape(4, 3, 4))
+    bnv = c.t("bnv", (4, 3), torch.stack([torch.ones(3), torch.zeros(3), torch.zeros(3), torch.ones(3)]))
+    nz = c.t("noise", (4,), u)
+    out = c.t("xout", (4, 3, 4), "nan")
+    prog = Program()
+    prog.add("BN_RESIDUAL", Y=yr, BNV=bnv, IDENT=None, NOISE=nz, XOUT=out, B=4, C=3, HW=4, KEEP=0.9)
+    got = _run_case(c, prog)
+    y = got[out.off:out.off + out.nbytes].view(torch.float32).reshape(4, 3, 2, 2).numpy()
+    assert rel_err(y, g["dropconnect:y"]) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# well-conditioned end-to-end gradients vs the reference (eval-mode BatchNorm)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,version,C,H,B,seed", [("b0_128x4_evalgrad_bs2", "b0", 4, 128, 2, 31), ("b5_64x13_evalgrad_bs2", "b5", 13, 64, 2, 32)])
+def test_eval_mode_gradients_match_reference(tag, version, C, H, B, seed):
+    from s2lc_amd.losses import FocalLoss, class_mask
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+    g = load(f"unet_{tag}.npz")
+    ncls = 4
+    net = R.build(version, C, ncls)
+    sd = detgen.fill_state(R.state_shapes(net), seed=seed)
+    model = EfficientnetUnet(EfficientNetConfig(version, C, ncls, class_distribution=[1.0 / ncls] * ncls))
+    model.load_state_dict(sd)
+    model.to(DEV).eval()
+    x = detgen.normal(f"{tag}.x", (B, C, H, H), seed=seed).to(DEV)
+    y = detgen.labels(f"{tag}.y", (B, H, H), ncls, seed=seed).to(DEV)
+    bufs0 = model._flat_bufs.clone()
+    logits = model(x)                                  # grad mode on, module in eval(): torch differentiates this too
+    loss = FocalLoss(torch.ones(ncls), 2.0, 0.0, ignore_index=0)(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(sub(logits.detach().cpu(), 4096), g["logits_sub"]) < 1e-3
+    assert abs(loss.item() - float(g["loss_focal"][0])) <= 1e-4 * abs(float(g["loss_focal"][0]))
+    m = class_mask(logits.detach()).cpu().to(torch.uint8).numpy()
+    exact = np.array_equal(m, g["mask"])
+    print(f"{tag}: class mask bit-exact vs the reference: {exact} ({int((m != g['mask']).sum())} of {m.size} pixels differ)")
+    assert torch.equal(model._flat_bufs, bufs0) and float(g["bufs_unchanged"][0]) == 1.0      # eval: running statistics untouched
+    named = dict(model.named_parameters())
+    none = {str(k) for k in g["grad_none"]}
+    scale = max(float(g[k][2]) for k in g.files if k.startswith("gradck:"))
+    worst, tot = 0.0, 0.0
+    for name, p in named.items():
+        if name in none:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        ck = g["gradck:" + name]
+        tot += p.grad.double().pow(2).sum().item()
+        # relative to the tensor's own largest gradient (floored at 1e-4 of the model's largest: tensors with negligible
+        # gradients are judged against that floor)
+        denom = max(float(ck[2]), 1e-4 * scale)
+        e = float(np.abs(sub(p.grad, 48).astype(np.float64) - g["grad:" + name]).max()) / denom
+        worst = max(worst, e)
+        assert e < 1e-3, (name, e)
+        assert abs(p.grad.double().abs().sum().item() - float(ck[1])) <= 1e-3 * max(float(ck[1]), 1e-4 * scale * p.numel()), name
+    assert abs(tot - float(g["grad_total_sq"][0])) <= 1e-3 * float(g["grad_total_sq"][0])
+    print(f"{tag}: worst per-parameter gradient error vs the reference {worst:.2e} (bar 1e-3)")

@@ -164,3 +164,46 @@ def test_reducer_plans_keep_gradient_buckets_progressive():
     assert single.bwd_param_marks[0][1] > 0.9 * len(single.bwd.ops)      # deferred: the decoder bucket closes at the very end
     covered = sorted((lo, hi) for _, _, lo, hi in ddp.bwd_param_marks)
     assert covered[0][0] == 0 and covered[-1][1] == model._layout.n_params and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+def test_eval_mode_backward_program_matches_oracle_autograd():
+    """torch differentiates an eval()-mode module too (BatchNorm on its running statistics, no drop-connect): the eval plan
+    built with want_bwd carries a backward program whose BatchNorm backward has no batch-statistics terms.  float64, exact."""
+    ncls, B, H = 4, 2, 64
+    model, net, sd, x, y, noise = _setup("b0", 6, H, B, ncls, seed=23)
+    plan = model._make_plan(B, H, H, False, True)
+    assert plan.bwd is not None and not plan.training
+    bases = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H, True)
+    from s2lc_amd.plan import opdefs as D
+
+    bufs_before = bases[D.BASE["BUFS"]].clone()
+    emulate(plan.fwd.pack(), bases, True)
+    logits = fview(bases, "OUT", True).view(B, ncls, H, H).clone()
+    sdd = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            v = v.detach().double()
+            if not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        sdd[k] = v
+    ref = R.unet_forward(sdd, net, x.double(), training=False)
+    loss = losses_ref.focal(ref, y, torch.ones(ncls, dtype=torch.float64), 2.0, 0.0, ignore_index=0)
+    (dlogits,) = torch.autograd.grad(loss, ref, retain_graph=True)
+    loss.backward()
+    assert rel_err(logits.numpy(), ref.detach().numpy()) < 1e-9
+    fview(bases, "DOUT", True).copy_(dlogits.reshape(-1))
+    emulate(plan.bwd.pack(), bases, True)
+    assert torch.equal(bufs_before, bases[D.BASE["BUFS"]])      # eval never touches the running statistics
+    grads = fview(bases, "GRADS", True)
+    scale = max(v.grad.abs().max().item() for v in sdd.values() if v.requires_grad and v.grad is not None)
+    n = 0
+    for name, (off, shape) in plan.layout.params.items():
+        g = grads[off:off + int(np.prod(shape))].view(shape)
+        r = sdd[name].grad
+        if r is None:
+            assert name.startswith("encoder.fc.") and g.abs().max() == 0
+            continue
+        # (in eval mode a conv bias in front of BatchNorm DOES get a gradient: the planner must not drop it)
+        assert (g - r).abs().max().item() <= 1e-7 * max(r.abs().max().item(), 1e-6 * scale), name
+        n += 1
+    assert n > 200
