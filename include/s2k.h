@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define S2K_ABI_VERSION 1
+#define S2K_ABI_VERSION 2
 
 #define S2K_OK 0
 #define S2K_EINVAL (-22)   /* malformed stage record / unsupported geometry */
@@ -79,9 +79,11 @@ int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases
 int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
                             float* ms_per_op);
 
-/* fused Adam step (L2-coupled decay, train_segmentation.py:109-127): p, g, m, v flat fp32 [n]. */
-int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, void* stream);
+/* fused Adam step (L2-coupled decay, train_segmentation.py:109-127): p, g, m, v flat fp32 [n].  Hyper-parameters are
+ * doubles, as Python hands them to torch.optim.Adam: `1 - beta2` and `lr / (1 - beta1**step)` are formed in double and
+ * rounded to fp32 once, which is what makes the update bit-compatible with torch's (ABI 2; ABI 1 took floats). */
+int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, void* stream);
 
 /* Diagnostics for tests: run a 32x32x2 f32 MFMA on A[32x2], B[2x32] and return D[32x32]
  * (checks the lane maps the kernels rely on with exact integer data). */

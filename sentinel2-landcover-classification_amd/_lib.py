@@ -46,13 +46,13 @@ def lib() -> ctypes.CDLL:
     L.s2k_program_profile.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp]
     L.s2k_program_profile_ops.restype = i32
     L.s2k_program_profile_ops.argtypes = [vp, i32, i32, vp, i32, vp, vp]
-    f32 = ctypes.c_float
+    f64 = ctypes.c_double
     L.s2k_adam_step.restype = i32
-    L.s2k_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, f32, f32, f32, f32, f32, i32, vp]
+    L.s2k_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, f64, f64, f64, f64, f64, i32, vp]
     L.s2k_selftest_mfma.restype = i32
     L.s2k_selftest_mfma.argtypes = [vp, vp, vp, vp]
-    if L.s2k_abi_version() != 1:
-        raise S2kError(f"libs2k ABI {L.s2k_abi_version()} != 1")
+    if L.s2k_abi_version() != 2:
+        raise S2kError(f"libs2k ABI {L.s2k_abi_version()} != 2")
     if L.s2k_op_size() != D.OP_BYTES or OP_DTYPE.itemsize != D.OP_BYTES:
         raise S2kError("S2kOp layout mismatch between Python and libs2k")
     for name, kind in D.KIND.items():

@@ -973,18 +973,18 @@ __global__ void adam_scalar_kernel(float* p, const float* g, float* m, float* v,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], k);
 }
 
-int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, double wd,
                 int step, hipStream_t st) {
     if (!p || !g || !m || !v || n <= 0 || step <= 0) { set_error("adam: bad args"); return S2K_EINVAL; }
-    const double c1 = 1.0 - pow((double)b1, (double)step), c2 = 1.0 - pow((double)b2, (double)step);
+    const double c1 = 1.0 - pow(b1, (double)step), c2 = 1.0 - pow(b2, (double)step);
     AdamK k;
-    k.lr_c1 = (float)((double)lr / c1);
+    k.lr_c1 = (float)(lr / c1);
     k.sq_c2 = (float)sqrt(c2);
-    k.b1w = (float)(1.0 - (double)b1);
-    k.b2 = b2;
-    k.b2w = (float)(1.0 - (double)b2);
-    k.eps = eps;
-    k.wd = wd;
+    k.b1w = (float)(1.0 - b1);
+    k.b2 = (float)b2;
+    k.b2w = (float)(1.0 - b2);
+    k.eps = (float)eps;
+    k.wd = (float)wd;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                            reinterpret_cast<uintptr_t>(v)) & 15) == 0;
     if (aligned) {

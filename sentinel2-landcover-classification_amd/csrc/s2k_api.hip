@@ -67,7 +67,7 @@ int launch_se_bn_sums(const S2kOp&, const Ctx&);
 int launch_se_bn_combine(const S2kOp&, const Ctx&);
 int launch_space_to_depth(const S2kOp&, const Ctx&);
 int launch_se_fc_wgrad(const S2kOp&, const Ctx&);
-int launch_adam(float*, const float*, float*, float*, int64_t, float, float, float, float, float, int, hipStream_t);
+int launch_adam(float*, const float*, float*, float*, int64_t, double, double, double, double, double, int, hipStream_t);
 int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
 
 static int launch_memset(const S2kOp& op, const Ctx& c) {
@@ -331,8 +331,8 @@ static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases
     return rc;
 }
 
-int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, void* stream) {
+int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int step, void* stream) {
     DeviceGuard guard(static_cast<hipStream_t>(stream));
     const int rc = launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, static_cast<hipStream_t>(stream));
     if (rc != S2K_OK) return rc;

@@ -29,6 +29,7 @@ struct WgradP {
     int T, n_mtiles, n_ctiles, HWp, HWq, ntiles, tiles_per_split;
     int NP;                      // pixels per chunk (PIX / GATHER)
     int R, XW, XWe, tiles_x, tiles_y, IR, IC, WS, CSQ, PSTR;
+    int exp;                     // tuning builds only (S2K_WG_EXP): 1 = stage the first tile only, 2 = no combine, 4 = no MFMA loop
 };
 
 __device__ __forceinline__ float ld_pro(const float* x, const float* bnv, const float* gate, int pro, int C, int c,
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     __syncthreads();
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const bool more = tile + 1 < tile_end;
+        const bool more = tile + 1 < tile_end && !(p.exp & 1);
         if (more) fetch(tile + 1);
         // ---------------- MFMA over pixel pairs ----------------------------------------------------
         // SPATIAL: pair s = (row r, column pair xp); walk (r, xp) incrementally, WVK pairs at a time.
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             }
         };
         lds_operands(wk, a0, b0);
-        for (int s = wk; s < npairs; s += 2 * WVK) {
+        for (int s = wk; s < ((p.exp & 4) ? 0 : npairs); s += 2 * WVK) {
             __builtin_amdgcn_sched_barrier(0);
             lds_operands(s + WVK, a1, b1);
             mfmas(a0, b0);
@@ -370,6 +371,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
     }
 
     // ---------------- combine: wgs[t][m][c] += acc ------------------------------------------------
+    if (p.exp & 2) return;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -501,6 +503,8 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         set_error("wgrad: prologue without BNV"); return S2K_EINVAL;
     }
     p.R = p.XW = p.XWe = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = 0;
+    static const int wg_exp = tune_int("S2K_WG_EXP", 0);
+    p.exp = wg_exp;
     hipStream_t st = c.stream;
     const int64_t npix = (int64_t)p.B * p.HWp;
 

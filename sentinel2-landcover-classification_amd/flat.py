@@ -38,7 +38,7 @@ class FlatParamsMixin:
             flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = flat[off:off + n].view(shape)
             p.grad = None
-        bufs = torch.empty(max(L.n_bufs, 1), dtype=torch.float32, device=dev)
+        bufs = torch.zeros(max(L.n_bufs, 1), dtype=torch.float32, device=dev)
         nbt = torch.zeros(max(len(L.nbt), 1), dtype=torch.int64, device=dev)
         for name, (off, shape) in L.bufs.items():
             mod_name, attr = name.rsplit(".", 1)

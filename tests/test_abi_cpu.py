@@ -42,7 +42,7 @@ def test_binding_self_checks_and_error_path(built):
     from s2lc_amd.plan.program import OP_DTYPE, Program, TRef
 
     L = _lib.lib()
-    assert L.s2k_abi_version() == 1 and L.s2k_op_size() == 256 == OP_DTYPE.itemsize
+    assert L.s2k_abi_version() == 2 and L.s2k_op_size() == 256 == OP_DTYPE.itemsize
     assert L.s2k_kind_name(D.KIND["CONV"]).decode() == "CONV" and L.s2k_kind_name(999) is None
     # malformed records are rejected on the host before any launch (safe without a GPU)
     p = Program()
