@@ -85,6 +85,12 @@ int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* b
 int s2k_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, void* stream);
 
+/* Measured ceilings of the current device for roofline reporting (bench.py): sustained v_mfma_f32_32x32x2_f32 rate with every
+ * SIMD issuing back to back (TFLOP/s), the shader clock held meanwhile (MHz), and a float4 stream copy (GB/s, read + write).
+ * `scratch`: >= 64 MiB of device memory (size the copy past the caches: 1 GiB+).  Synchronises `stream`.  Not on the hot path. */
+int s2k_measure_peaks(void* scratch, size_t scratch_bytes, int waves_per_simd, double* mfma_tflops, double* mfma_clock_mhz,
+                      double* copy_gbps, void* stream);
+
 /* Diagnostics for tests: run a 32x32x2 f32 MFMA on A[32x2], B[2x32] and return D[32x32]
  * (checks the lane maps the kernels rely on with exact integer data). */
 int s2k_selftest_mfma(const float* a, const float* b, float* d, void* stream);

@@ -49,6 +49,8 @@ def lib() -> ctypes.CDLL:
     f64 = ctypes.c_double
     L.s2k_adam_step.restype = i32
     L.s2k_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, f64, f64, f64, f64, f64, i32, vp]
+    L.s2k_measure_peaks.restype = i32
+    L.s2k_measure_peaks.argtypes = [vp, ctypes.c_size_t, i32, vp, vp, vp, vp]
     L.s2k_selftest_mfma.restype = i32
     L.s2k_selftest_mfma.argtypes = [vp, vp, vp, vp]
     if L.s2k_abi_version() != 2:
@@ -120,3 +122,16 @@ def profile_ops(packed: np.ndarray, bases: Bases, stream: int) -> np.ndarray:
     with _guard(bases):
         check(lib().s2k_program_profile_ops(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream, ms.ctypes.data))
     return ms
+
+
+def measure_peaks(device=None, waves_per_simd: int = 1, scratch_gib: float = 2.0) -> dict:
+    """{"mfma_f32_tflops", "mfma_clock_mhz", "copy_gbps"} measured on `device` (include/s2k.h, s2k_measure_peaks)."""
+    dev = torch.device(device if device is not None else "cuda")
+    buf = torch.empty(int(scratch_gib * (1 << 30)), dtype=torch.uint8, device=dev)
+    buf.view(torch.float32)[: (1 << 22)].normal_()
+    out = (ctypes.c_double * 3)()
+    addr = ctypes.addressof(out)
+    with torch.cuda.device(dev):
+        check(lib().s2k_measure_peaks(buf.data_ptr(), buf.numel(), waves_per_simd, addr, addr + 8, addr + 16,
+                                      torch.cuda.current_stream(dev).cuda_stream))
+    return {"mfma_f32_tflops": out[0], "mfma_clock_mhz": out[1], "copy_gbps": out[2]}

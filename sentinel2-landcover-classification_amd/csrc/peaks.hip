@@ -1,0 +1,173 @@
+// Measured ceilings of THIS device, for bench.py's roofline line ("report roofline fractions against both
+// spec and measured peaks"): the sustained rate of v_mfma_f32_32x32x2_f32 with every SIMD issuing back to back (operands
+// in registers, 8 independent accumulators, 1 or 2 waves per SIMD), the shader clock the chip holds while doing so
+// (s_memtime / s_memrealtime), and a float4 stream copy.  Not part of the hot path.
+#include <algorithm>
+
+#include "common.h"
+
+namespace s2k {
+
+__global__ void __launch_bounds__(256) mfma_peak_kernel(float* sink, unsigned long long* stamps, int iters) {
+    f32x16 acc[8];
+    const float a = 1.0f + 0.001f * (float)(threadIdx.x & 63), b = 0.5f - 0.002f * (float)(threadIdx.x & 31);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    if (s == 12345.678f) sink[0] = s;                       // keeps the accumulators alive; never true
+    if (threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = c1 - c0;                   // shader-clock cycles
+        stamps[2 * blockIdx.x + 1] = r1 - r0;               // 100 MHz ticks
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_peak_kernel(const float4* src, float4* dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace s2k
+
+using namespace s2k;
+
+extern "C" int s2k_measure_peaks(void* scratch, size_t scratch_bytes, int waves_per_simd, double* mfma_tflops, double* mfma_clock_mhz,
+                                 double* copy_gbps, void* stream) {
+    if (!scratch || scratch_bytes < (64u << 20) || !mfma_tflops || !mfma_clock_mhz || !copy_gbps || waves_per_simd < 1 || waves_per_simd > 2) {
+        set_error("measure_peaks: need >= 64 MiB of device scratch and 1 or 2 waves per SIMD");
+        return S2K_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { set_error("measure_peaks: no device properties"); return S2K_EHIP; }
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * waves_per_simd;                 // 256 threads = one wave per SIMD of a CU
+    float* sink = static_cast<float*>(scratch);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + 4096);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 40000;                                 // 8 x 40000 MFMAs per wave: ~10 ms at full rate
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, sink, stamps, 2000);   // warm-up
+    hipEventRecord(e0, st);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, sink, stamps, iters);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4.0 * 8.0 * iters * 4096.0;
+    *mfma_tflops = flops / (ms * 1e-3) / 1e12;
+    unsigned long long h[2] = {0, 0};
+    (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    *mfma_clock_mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    // stream copy over half of the scratch each way (>= 32 MiB per direction; the caller sizes it past the caches)
+    const int64_t n4 = (int64_t)((scratch_bytes - (1u << 20)) / 2 / 16);
+    const float4* src = reinterpret_cast<const float4*>(static_cast<char*>(scratch) + (1u << 20));
+    float4* dst = const_cast<float4*>(src) + n4;
+    const int cblocks = (int)std::min<int64_t>(cdiv64(n4, 256), (int64_t)cus * 16);
+    hipLaunchKernelGGL(copy_peak_kernel, dim3(cblocks), dim3(256), 0, st, src, dst, n4);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(copy_peak_kernel, dim3(cblocks), dim3(256), 0, st, src, dst, n4);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    *copy_gbps = 5.0 * 2.0 * (double)n4 * 16.0 / (ms * 1e-3) / 1e9;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("measure_peaks: %s", hipGetErrorString(e)); return S2K_EHIP; }
+    return S2K_OK;
+}
+
+// ---- tuning builds only: what do LDS operand reads cost beside the f32 MFMA? -------------------------------------------
+#ifdef S2K_TUNING
+namespace s2k {
+// 9 accumulators (the 3x3 weight-gradient shape); READS ds_read_b32 per 9 MFMAs feed the B operands (software-pipelined one
+// group ahead, like the real kernels).  NW waves per SIMD all run the same stream.
+template <int READS>
+__global__ void __launch_bounds__(512) mfma_lds_kernel(float* sink, int iters) {
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+    f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const float* base = lds + (threadIdx.x & 31) * 65 + (threadIdx.x >> 5 & 1);
+    float b0[9], b1[9];
+    const float a = 1.0f + 0.001f * (float)(threadIdx.x & 63);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { b0[j] = base[j * 3]; b1[j] = base[j * 3 + 1]; }
+    for (int i = 0; i < iters; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j < READS) b1[j] = base[(j * 7 + ((i * 2) & 63)) ];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j < READS) b0[j] = base[(j * 7 + ((i * 2 + 1) & 63)) ];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[j][r];
+    if (s == 12345.678f) sink[0] = s;
+}
+}  // namespace s2k
+
+extern "C" int s2k_measure_mfma_lds(void* scratch, int reads, int waves_per_simd, double* tflops, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    const int blocks = prop.multiProcessorCount;
+    const int threads = 256 * waves_per_simd;
+    float* sink = static_cast<float*>(scratch);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int iters = 4000;
+    auto launch = [&](int it) {
+        if (reads == 0) hipLaunchKernelGGL(mfma_lds_kernel<0>, dim3(blocks), dim3(threads), 0, st, sink, it);
+        else if (reads == 3) hipLaunchKernelGGL(mfma_lds_kernel<3>, dim3(blocks), dim3(threads), 0, st, sink, it);
+        else if (reads == 5) hipLaunchKernelGGL(mfma_lds_kernel<5>, dim3(blocks), dim3(threads), 0, st, sink, it);
+        else hipLaunchKernelGGL(mfma_lds_kernel<9>, dim3(blocks), dim3(threads), 0, st, sink, it);
+    };
+    launch(100);
+    hipEventRecord(e0, st);
+    launch(iters);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *tflops = (double)blocks * 4.0 * waves_per_simd * 18.0 * iters * 4096.0 / (ms * 1e-3) / 1e12;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return S2K_OK;
+}
+#endif

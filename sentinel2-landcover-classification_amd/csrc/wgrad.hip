@@ -15,22 +15,9 @@
 #include <algorithm>
 
 #include "common.h"
+#include "wgrad.h"
 
 namespace s2k {
-
-constexpr int WG_EPT_MAX = 2;  // halo elements per thread per channel (tile <= 512 floats / channel)
-
-enum { WG_PIX = 0, WG_SPATIAL = 1, WG_GATHER = 2 };
-
-struct WgradP {
-    const float *p, *bnvp, *gatep, *q, *bnvq, *gateq;
-    float* wgs;
-    int B, M, C, CTOT, H, W, KH, KW, S, PT, PL, HO, WO, prop, proq;
-    int T, n_mtiles, n_ctiles, HWp, HWq, ntiles, tiles_per_split;
-    int NP;                      // pixels per chunk (PIX / GATHER)
-    int R, XW, XWe, tiles_x, tiles_y, IR, IC, WS, CSQ, PSTR;
-    int exp;                     // tuning builds only (S2K_WG_EXP): 1 = stage the first tile only, 2 = no combine, 4 = no MFMA loop
-};
 
 __device__ __forceinline__ float ld_pro(const float* x, const float* bnv, const float* gate, int pro, int C, int c,
                                         int64_t off, int gate_row) {
@@ -507,6 +494,10 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.exp = wg_exp;
     hipStream_t st = c.stream;
     const int64_t npix = (int64_t)p.B * p.HWp;
+    {   // the MFMA-bound shapes run on the producer / consumer kernels (wgrad_pc.hip); 1 = not one of theirs
+        const int rc = launch_wgrad_pc(p, mode, st);
+        if (rc != 1) return rc;
+    }
 
     if (mode == S2K_MODE_GATHER2X2) {
         if (p.T != 4 || p.H != 2 * p.HO || p.W != 2 * p.WO || p.proq != S2K_PRO_NONE || p.gateq) {

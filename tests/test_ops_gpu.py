@@ -236,6 +236,34 @@ def test_wgrad_3x3(B, M, C, CT, c_off, H, W, proq):
     _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False)
 
 
+@pytest.mark.parametrize("B,M,C,CT,c_off,H,W,proq", [
+    (2, 64, 64, 64, 0, 6, 64, 3),        # (R, XWE) = (1, 64): one row per tile
+    (1, 128, 88, 88, 0, 10, 112, 0),     # (1, 64) with a ragged second x tile (48 valid columns), C not a tile multiple
+    (2, 72, 40, 104, 64, 12, 32, 3),     # (2, 32), channel slice of a concat conv (CTOT > C), M / C with ragged tiles
+    (2, 256, 64, 64, 0, 16, 16, 0),      # (4, 16): 4 m-tiles
+    (3, 64, 128, 128, 0, 10, 15, 3),     # (4, 16) with 15 valid columns and H not a multiple of R
+    (4, 64, 64, 64, 0, 8, 8, 3),         # (8, 8)
+    (1, 64, 96, 96, 0, 9, 56, 0),        # (1, 56)   (224-pixel inputs: 56 / 28 / 14 maps)
+    (2, 96, 64, 64, 0, 28, 28, 3),       # (2, 28)
+    (3, 512, 64, 64, 0, 14, 14, 3),      # (4, 14): pixel splits over 8 m-tiles
+])
+def test_wgrad_3x3_producer_consumer_tiles(B, M, C, CT, c_off, H, W, proq):
+    """the shapes that take the producer / consumer kernels (csrc/wgrad_pc.hip), one case per compiled tile geometry"""
+    _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False)
+
+
+@pytest.mark.parametrize("B,M,C,H,W,prop,proq,gate", [
+    (5, 240, 250, 16, 16, 0, 0, False),      # 128 x 128 tiles, ragged on both sides
+    (22, 240, 72, 7, 7, 0, 2, True),         # 128 x 64, SiLU + SE gate on Q, pixel count not a multiple of 64 (images straddle tiles)
+    (4, 40, 144, 16, 20, 0, 3, False),       # 64 x 128... (M = 40: one ragged 64-row tile), ReLU on Q
+    (3, 64, 64, 20, 20, 2, 0, False),        # 64 x 64, SiLU prologue on P (ConvTranspose weight gradient)
+    (2, 768, 384, 1, 520, 0, 0, False),      # a Linear over feature-major tokens: H = 1, W = tokens
+    (4, 130, 130, 16, 16, 3, 0, False),      # 64-row tiles x 3, ReLU on P
+])
+def test_wgrad_1x1_producer_consumer_tiles(B, M, C, H, W, prop, proq, gate):
+    _wgrad_case(B, M, C, C, 0, H, W, 1, 1, 0, 0, H, W, prop, proq, gate)
+
+
 def test_wgrad_stem_stride2():
     from s2lc_amd.plan.unet_plan import same_pads
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--nostats", action="store_true")
     ap.add_argument("--scratch", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS check: the chip holds a higher clock on trivial data)")
     ap.add_argument("--N", type=int, default=0, help="conv1: tokens per image (H=1, W=N) instead of an HxH map")
     a = ap.parse_args()
     B, M, C, H = a.B, a.M, a.C, a.H
@@ -78,7 +79,7 @@ def main():
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
         flops = 2.0 * M * C * T * B * H * Wd
-    buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * 0.5).view(torch.uint8)
+    buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * (0.0 if a.zeros else 0.5)).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)
     packed = prog.pack()
     st_ = torch.cuda.current_stream().cuda_stream
@@ -91,6 +92,14 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
     print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s")
+    L = _lib.lib()
+    if hasattr(L, "s2k_debug_wg_counters"):        # tuning build: in-kernel stamps of the producer / consumer wgrad
+        import ctypes
+        out = (ctypes.c_ulonglong * 8)()
+        L.s2k_debug_wg_counters(out, 1)
+        n = max(out[2], 1)
+        print(f"   per consumer wave-tile: barrier wait {out[0] / n:.0f} cyc, compute {out[1] / n:.0f} cyc; "
+              f"per producer wave-tile: work {out[4] / n:.0f} cyc, barrier wait {out[3] / n:.0f} cyc  ({n} wave-tiles)")
 
 
 if __name__ == "__main__":
