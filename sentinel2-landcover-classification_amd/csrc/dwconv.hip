@@ -27,6 +27,7 @@ struct DwP {
     int PPB, RT, bands, IRt, LW;     // tiling: planes per workgroup, rows per band, LDS rows / row stride
     int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
     int vps_shift;                   // log2(pow2ceil(LW / 4)) capped at 6 (vector stager)
+    int bloop, cgroups;              // wgrad on small planes: images per workgroup (0 = off), channel groups
 };
 
 // Scalar stager (any width / column origin): rows [row0, row0 + nrows) x LW columns of PPB planes of `src` into
@@ -221,13 +222,73 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT);
-    __syncthreads();
     const rsrc_t rdy = make_rsrc(p.dy, nplanes * p.HO * p.WO * 4);
     const int items = rows * p.XG;
     const int lpp = p.LPP, ppw = 64 / lpp;
     const int li = lane & (lpp - 1), lp = lane / lpp;
     const bool vec4 = (p.WO & 3) == 0;
+    if (p.bloop > 0) {
+        // Small planes (8x8 ... 32x32 maps with hundreds of channels): a workgroup owns PPB CHANNELS and walks over a range
+        // of images with the tap sums kept in registers, then adds each (channel, tap) once.  One atomic per (image, channel,
+        // tap) — what the plane-per-workgroup form below does — is 1.5 M nearly empty atomic instructions on a
+        // 1824-channel 8x8 layer, and atomics execute at the memory side at one wave-instruction per ~50 ns per CU whatever
+        // their lane count: that, not the arithmetic, was 90 % of such a layer's time.
+        const int cg = blockIdx.x % p.cgroups, bs = blockIdx.x / p.cgroups;
+        const int c0 = cg * p.PPB;
+        const int b0 = bs * p.bloop, b1 = min(p.B, b0 + p.bloop);
+        const int pl = wave * ppw + lp;                  // PPB == 4 * ppw: exactly one plane group per wave
+        const bool cok = pl < p.PPB && c0 + pl < p.C;
+        float acc[K * K];
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) acc[i] = 0.0f;
+        for (int b = b0; b < b1; ++b) {
+            const int64_t plb = (int64_t)b * p.C + c0;
+            stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, plb, (int64_t)(b + 1) * p.C, p.IRt, -p.PT);
+            __syncthreads();
+            if (cok) {
+                const int64_t plane = plb + pl;
+                const float* tp = tile + pl * p.IRt * p.LW;
+                for (int it = li; it < items; it += lpp) {
+                    const int r = it / p.XG, xg = it - r * p.XG;
+                    const int xo = xg * 4;
+                    const uint32_t goff = (uint32_t)(plane * p.HO * p.WO + (int64_t)r * p.WO + xo) * 4u;
+                    float g[4];
+                    if (vec4) {
+                        const f32x4 gv = bload4(rdy, goff);
+                        g[0] = gv[0]; g[1] = gv[1]; g[2] = gv[2]; g[3] = gv[3];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) g[j] = bload(rdy, xo + j < p.WO ? goff + 4u * j : BUF_OOB);
+                    }
+                    const float* t0 = tp + (r * S) * p.LW + xo * S;
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky) {
+                        float v[4 * NV];
+                        read_window<NV>(t0 + ky * p.LW, v);
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(g[j], v[O0 + j * S + kx], acc[ky * K + kx]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* redc = smem + p.PPB * p.IRt * p.LW;       // [PPB][K*K]
+#pragma unroll
+        for (int i = 0; i < K * K; ++i) {
+            const float v = group_sum(acc[i], lpp);
+            if (li == 0 && pl < p.PPB) redc[pl * (K * K) + i] = cok ? v : 0.0f;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < p.PPB * K * K; idx += NTHREADS) {
+            const int q = idx / (K * K);
+            if (c0 + q < p.C) atomicAdd(p.out + (int64_t)(c0 + q) * (K * K) + (idx - q * (K * K)), redc[idx]);
+        }
+        return;
+    }
+    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT);
+    __syncthreads();
     // big planes (fewer than 4 per workgroup): wpp waves share one plane and interleave its items
     const int wpp = (lpp == 64 && p.PPB < 4) ? 4 / p.PPB : 1;
     const int it0 = li + lpp * (wave % wpp), itstep = lpp * wpp;
@@ -602,7 +663,34 @@ int launch_dwconv_wgrad(const S2kOp& op, const Ctx& c) {
     if (!p.x || !p.dy || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_wgrad: missing tensor"); return S2K_EINVAL; }
     const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
     if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
-    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false, true);
+    size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false, true);
+    static const int bloop_on = tune_int("S2K_DW_WG_BLOOP", 1);
+    if (bloop_on && p.bands == 1 && p.HO * p.WO <= 1024 && p.B > 1) {
+        // small planes: channels per workgroup = 4 waves x (64 / LPP) planes per wave; images are walked inside the kernel
+        const int ppb = 4 * (64 / p.LPP);
+        const size_t lds2 = ((size_t)ppb * p.IRt * p.LW + (size_t)ppb * p.K * p.K) * sizeof(float);
+        if (lds2 <= 64 * 1024) {
+            p.PPB = ppb;
+            lds = lds2;
+            p.cgroups = cdiv(p.C, ppb);
+            int bsplits = cdiv(768, p.cgroups);           // ~3 workgroups per CU
+            if (bsplits > p.B) bsplits = p.B;
+            if (bsplits < 1) bsplits = 1;
+            p.bloop = cdiv(p.B, bsplits);
+            bsplits = cdiv(p.B, p.bloop);
+            const bool silu_b = p.pro == S2K_PRO_SILU;
+            const dim3 grid((unsigned)(p.cgroups * bsplits));
+#define DW_WGB(KK, SS, PP) do { if (silu_b) hipLaunchKernelGGL((dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_SILU>), grid, dim3(NTHREADS), lds, c.stream, p); \
+                                else hipLaunchKernelGGL((dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_NONE>), grid, dim3(NTHREADS), lds, c.stream, p); return S2K_OK; } while (0)
+#define DW_WGB_PL(KK, SS) do { if (p.PL == 0) DW_WGB(KK, SS, 0); else if (p.PL == 1) DW_WGB(KK, SS, 1); else DW_WGB(KK, SS, 2); } while (0)
+            if (p.K == 3 && p.S == 1) DW_WGB_PL(3, 1);
+            if (p.K == 3 && p.S == 2) DW_WGB_PL(3, 2);
+            if (p.K == 5 && p.S == 1) DW_WGB_PL(5, 1);
+            DW_WGB_PL(5, 2);
+#undef DW_WGB_PL
+#undef DW_WGB
+        }
+    }
     const bool silu = p.pro == S2K_PRO_SILU;
 #define DW_WG(KK, SS, PP) (silu ? launch_dw(dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_SILU>, p, lds, c.stream) \
                                 : launch_dw(dwconv_wgrad_kernel<KK, SS, PP, S2K_PRO_NONE>, p, lds, c.stream))

@@ -48,20 +48,27 @@ __device__ __forceinline__ float pro_masked(float v, float sc, float sh, float b
     return apply_pro_c<PRO>(v, sc, sh) * keep;
 }
 
-template <int MODE, int T, int WM, int WN, int R, int XWE, int PROP, int PROQ>
+// Consumer waves are arranged WVM x WVN x WVK: WVK > 1 splits the pixel pairs of a tile over waves (thin layers: a 32-channel side
+// leaves only one 32 x 32 tile per tap, so the four waves share it and add their partial sums at the end).
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int R, int XWE, int PROP, int PROQ>
 __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
     constexpr int NT = 256;                      // threads per role
-    constexpr int BM = WM * 64, BC = WN * 64;    // waves 2 x 2, each WM x WN tiles of 32 x 32
-    constexpr int NPJ = 64;                      // pixel slots per tile
+    constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
+    constexpr int PK = NPJ / 64;                 // pixel slots per producer lane
     constexpr int NPAIRS = (MODE == WG_SPATIAL) ? (R * XWE) / 2 : NPJ / 2;
+    constexpr int CH = NPAIRS / WVK;             // pixel pairs per consumer wave and tile
+    constexpr int HX = XWE / 2;                  // pixel pairs per tile row
+    static_assert(WVM * WVN * WVK == 4 && NPJ % 64 == 0 && NPAIRS % WVK == 0, "4 consumer waves");
+    static_assert(MODE != WG_SPATIAL || WVK == 1 || (HX % CH == 0) || (CH % HX == 0), "a wave's pairs: part of a row or whole rows");
     constexpr int WS = XWE + 2, IR = R + 2;      // halo of a 3x3 stride-1 tile
     constexpr int USED = (MODE == WG_SPATIAL) ? IR * WS : NPJ;     // Q elements (halo positions / pixels) per channel
     constexpr int NK = (USED + 63) / 64;         // 64-element groups of the Q image
-    static_assert(MODE == WG_PIX || (T == 9 && USED <= NT && R * XWE <= NPJ && XWE % 2 == 0), "3x3 tile geometry");
+    static_assert(MODE == WG_PIX || (T == 9 && R * XWE <= NPJ && XWE % 2 == 0), "3x3 tile geometry");
     static_assert(MODE == WG_SPATIAL || T == 1, "1x1: one tap");
     static_assert(MODE != WG_SPATIAL || PROP == S2K_PRO_NONE, "3x3 wgrad: P (= dY) carries no prologue");
     constexpr int BMP = BM + 4, BCP = BC + 4;    // row strides (floats): 16-byte aligned rows, stride = 4 mod 32 banks
-    constexpr int NMQ = BM / 16, NCQ = BC / 16;  // channel quads per producer thread (a producer wave owns quads g, g+4, ...)
+    constexpr int NMQ = (BM + 15) / 16, NCQ = (BC + 15) / 16;  // channel quads per producer thread (a producer wave owns quads g, g+4, ...)
+    static_assert(BM % 16 == 0 && BC % 16 == 0, "channel quads per producer wave");
     constexpr int PIMG = NPJ * BMP;
     constexpr int BUF = PIMG + USED * BCP;       // floats of one LDS image {P, Q}
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -85,7 +92,6 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
         // PRODUCER wave g (0..3): pixel / halo slot = lane, channel quads g, g + 4, g + 8, ...
         // =================================================================================================================
         const int g = __builtin_amdgcn_readfirstlane(wave);
-        const int pr = (MODE == WG_SPATIAL) ? lane / XWE : 0, pxx = (MODE == WG_SPATIAL) ? lane % XWE : 0;
         const bool img_local = (MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0;
         rsrc_t rp = make_rsrc(p.p, (int64_t)p.B * p.M * p.HWp * 4);
         rsrc_t rq = make_rsrc(p.q, (int64_t)p.B * p.C * p.HWq * 4);
@@ -107,23 +113,29 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
                 qsc[j][q] = PROQ != S2K_PRO_NONE ? p.bnvq[gc] : 1.0f;
                 qsh[j][q] = PROQ != S2K_PRO_NONE ? p.bnvq[p.C + gc] : 0.0f;
             }
-        float preg[NMQ][4], qreg[NK][NCQ][4];
-        bool f_pok = false;
+        float preg[PK][NMQ][4], qreg[NK][NCQ][4];
+        unsigned f_pok = 0;          // bit k: pixel slot lane + 64 k is a real output pixel
         unsigned f_qok = 0;          // bit k: Q element lane + 64 k is inside the image (SPATIAL) / the pixel exists (PIX)
         const uint32_t p_rstep = (uint32_t)p.HWp * 4u, q_cstep = (uint32_t)p.HWq * 4u;
 
         auto fetch = [&](int tile) {
-            uint32_t pvoff, qvoff[NK];
+            uint32_t pvoff[PK], qvoff[NK];
             if (MODE == WG_SPATIAL) {
                 const int tx = tile % p.tiles_x;
                 const int ty = (tile / p.tiles_x) % p.tiles_y;
                 const int b = tile / (p.tiles_x * p.tiles_y);
                 const int y0 = ty * R, x0 = tx * p.XW;
-                const int yo = y0 + pr, xo = x0 + pxx;
                 rp = make_rsrc(p.p + (int64_t)b * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
                 rq = make_rsrc(p.q + (int64_t)b * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
-                f_pok = lane < R * XWE && pxx < p.XW && yo < p.HO && xo < p.WO;
-                pvoff = f_pok ? (uint32_t)(yo * p.WO + xo) * 4u : BUF_OOB;
+                f_pok = 0;
+#pragma unroll
+                for (int k = 0; k < PK; ++k) {
+                    const int pj = lane + 64 * k;
+                    const int yo = y0 + pj / XWE, xo = x0 + pj % XWE;
+                    const bool ok = pj < R * XWE && pj % XWE < p.XW && yo < p.HO && xo < p.WO;
+                    pvoff[k] = ok ? (uint32_t)(yo * p.WO + xo) * 4u : BUF_OOB;
+                    f_pok |= ok ? (1u << k) : 0u;
+                }
                 f_qok = 0;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
@@ -134,9 +146,10 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
                     f_qok |= ok ? (1u << k) : 0u;
                 }
             } else {
+                static_assert(MODE == WG_SPATIAL || PK == 1, "1x1: 64 pixels per tile");
                 const int64_t ntot = (int64_t)p.B * p.HWp;
                 const int64_t n = (int64_t)tile * NPJ + lane;
-                f_pok = n < ntot;
+                f_pok = n < ntot ? 1u : 0u;
                 const int64_t nn = f_pok ? n : 0;
                 const int b = (int)(nn / p.HWp);
                 const int pp = (int)(nn - (int64_t)b * p.HWp);
@@ -147,17 +160,20 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
                     rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
                     brel = b - bt;
                 }
-                pvoff = f_pok ? (uint32_t)((int64_t)brel * p.M * p.HWp + pp) * 4u : BUF_OOB;
+                pvoff[0] = f_pok ? (uint32_t)((int64_t)brel * p.M * p.HWp + pp) * 4u : BUF_OOB;
                 qvoff[0] = f_pok ? (uint32_t)((int64_t)brel * p.C * p.HWq + pp) * 4u : BUF_OOB;
-                f_qok = f_pok ? 1u : 0u;
+                f_qok = f_pok;
             }
             // rows past M / channels past C re-read the last valid one (they only feed discarded outputs); the row / channel part
             // of every address is a scalar offset
 #pragma unroll
             for (int i = 0; i < NMQ; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    preg[i][q] = bload_s(rp, pvoff, (uint32_t)min(m0 + (g + 4 * i) * 4 + q, p.M - 1) * p_rstep);
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t so = (uint32_t)min(m0 + (g + 4 * i) * 4 + q, p.M - 1) * p_rstep;
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) preg[k][i][q] = bload_s(rp, pvoff[k], so);
+                }
 #pragma unroll
             for (int j = 0; j < NCQ; ++j)
 #pragma unroll
@@ -169,15 +185,17 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
         };
 
         auto commit = [&](float* Pt, float* Qt) {
-            {
-                const float bound = f_pok ? __builtin_inff() : 0.0f, keep = f_pok ? 1.0f : 0.0f;
-                if (MODE != WG_SPATIAL || lane < R * XWE) {
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                const bool ok = (f_pok >> k) & 1u;
+                const float bound = ok ? __builtin_inff() : 0.0f, keep = ok ? 1.0f : 0.0f;
+                if (MODE != WG_SPATIAL || lane + 64 * k < R * XWE) {
 #pragma unroll
                     for (int i = 0; i < NMQ; ++i) {
                         f32x4 o;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = pro_masked<PROP>(preg[i][q], psc[i][q], psh[i][q], bound, keep);
-                        *reinterpret_cast<f32x4*>(Pt + lane * BMP + (g + 4 * i) * 4) = o;
+                        for (int q = 0; q < 4; ++q) o[q] = pro_masked<PROP>(preg[k][i][q], psc[i][q], psh[i][q], bound, keep);
+                        *reinterpret_cast<f32x4*>(Pt + (lane + 64 * k) * BMP + (g + 4 * i) * 4) = o;
                     }
                 }
             }
@@ -216,7 +234,8 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
     // CONSUMER: LDS reads + MFMAs, nothing else.
     // =====================================================================================================================
     __builtin_amdgcn_s_setprio(2);     // the MFMA stream wins issue arbitration against the staging wave of its SIMD
-    const int wm0 = (wave >> 1) * (WM * 32), wc0 = (wave & 1) * (WN * 32);
+    const int wk = wave % WVK, wmn = wave / WVK;
+    const int wm0 = (wmn / WVN) * (WM * 32), wc0 = (wmn % WVN) * (WN * 32);
     f32x16 acc[T][WM][WN];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -227,8 +246,11 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
 
-    const int a_off = lh * BMP + wm0 + l31;                    // + (2 s) * BMP + rm * 32
-    const int b_off = PIMG + lh * BCP + wc0 + l31;             // + (element of pair / tap) * BCP + rn * 32   (all compile-time)
+    // this wave's pairs: [wk * CH, (wk + 1) * CH) — a run inside one tile row, or whole rows
+    const int s_base = wk * CH;
+    const int qp_base = (MODE == WG_SPATIAL) ? (s_base / HX) * WS + 2 * (s_base % HX) : 2 * s_base;
+    const int a_off = (lh + 2 * s_base) * BMP + wm0 + l31;               // + (2 s') * BMP + rm * 32
+    const int b_off = PIMG + (lh + qp_base) * BCP + wc0 + l31;           // + (element of pair s' / tap) * BCP + rn * 32   (all compile-time)
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         const unsigned long long s0 = WG_STAMP();
@@ -243,7 +265,7 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
         auto lds_operands = [&](int s, float (&a)[WM], float (&bq)[T][WN]) {   // s is a compile-time constant after unrolling
 #pragma unroll
             for (int rm = 0; rm < WM; ++rm) a[rm] = Pa[2 * s * BMP + rm * 32];
-            const int qp = (MODE == WG_SPATIAL) ? (s / (XWE / 2)) * WS + 2 * (s % (XWE / 2)) : 2 * s;
+            const int qp = (MODE == WG_SPATIAL && CH > HX) ? (s / HX) * WS + 2 * (s % HX) : 2 * s;   // relative to the wave's first pair
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const int toff = (MODE == WG_SPATIAL) ? (t / 3) * WS + (t % 3) : 0;
@@ -270,14 +292,14 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
         float a0[WM], a1[WM], b0[T][WN], b1[T][WN];
         lds_operands(0, a0, b0);
 #pragma unroll
-        for (int s = 0; s < NPAIRS; s += 2) {
+        for (int s = 0; s < CH; s += 2) {
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < NPAIRS) lds_operands(s + 1, a1, b1);
+            if (s + 1 < CH) lds_operands(s + 1, a1, b1);
             mfmas(a0, b0);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < NPAIRS) {
-                if (s + 2 < NPAIRS) lds_operands(s + 2, a0, b0);
+            if (s + 1 < CH) {
+                if (s + 2 < CH) lds_operands(s + 2, a0, b0);
                 mfmas(a1, b1);
                 interleave();
             }
@@ -306,9 +328,9 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int MODE, int T, int WM, int WN, int R, int XWE, int PROP, int PROQ>
+template <int MODE, int T, int WM, int WN, int WVM, int WVN, int WVK, int NPJ, int R, int XWE, int PROP, int PROQ>
 static int launch_pc2(WgradP& p, hipStream_t st) {
-    constexpr int BM = WM * 64, BC = WN * 64, NPJ = 64;
+    constexpr int BM = WM * WVM * 32, BC = WN * WVN * 32;
     constexpr int USED = (MODE == WG_SPATIAL) ? (R + 2) * (XWE + 2) : NPJ;
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
@@ -319,8 +341,9 @@ static int launch_pc2(WgradP& p, hipStream_t st) {
     }
     if (p.gatep || p.gateq) { set_error("wgrad (pc): SE gates stay on the generic kernels"); return S2K_EINVAL; }
     const size_t lds = (size_t)2 * (NPJ * (BM + 4) + USED * (BC + 4)) * sizeof(float);
+    static_assert(2 * (NPJ * (BM + 4) + USED * (BC + 4)) * sizeof(float) <= 160 * 1024, "LDS image");
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
-    auto kern = wgrad_pc_kernel<MODE, T, WM, WN, R, XWE, PROP, PROQ>;
+    auto kern = wgrad_pc_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, R, XWE, PROP, PROQ>;
     static PerDeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -347,17 +370,25 @@ static int launch_pc2(WgradP& p, hipStream_t st) {
 
 template <int R, int XWE>
 static int launch_pc_spatial(WgradP& p, hipStream_t st) {
-    if (p.proq == S2K_PRO_NONE) return launch_pc2<WG_SPATIAL, 9, 1, 1, R, XWE, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
-    if (p.proq == S2K_PRO_RELU) return launch_pc2<WG_SPATIAL, 9, 1, 1, R, XWE, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
+    if (p.proq == S2K_PRO_NONE) return launch_pc2<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, R, XWE, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+    if (p.proq == S2K_PRO_RELU) return launch_pc2<WG_SPATIAL, 9, 1, 1, 2, 2, 1, 64, R, XWE, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
+    return 1;
+}
+
+// thin layers (a 32-channel side): 128-pixel tiles (2 rows x 64), the four consumer waves split the pixel pairs
+template <int WVM>
+static int launch_pc_spatial_thin(WgradP& p, hipStream_t st) {
+    if (p.proq == S2K_PRO_NONE) return launch_pc2<WG_SPATIAL, 9, 1, 1, WVM, 1, 4 / WVM, 128, 2, 64, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+    if (p.proq == S2K_PRO_RELU) return launch_pc2<WG_SPATIAL, 9, 1, 1, WVM, 1, 4 / WVM, 128, 2, 64, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
     return 1;
 }
 
 template <int WM, int WN>
 static int launch_pc_pix(WgradP& p, hipStream_t st) {
     const int pp = p.prop, pq = p.proq;
-    if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_pc2<WG_PIX, 1, WM, WN, 1, 64, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
-    if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_pc2<WG_PIX, 1, WM, WN, 1, 64, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
-    if (pp == S2K_PRO_RELU && pq == S2K_PRO_NONE) return launch_pc2<WG_PIX, 1, WM, WN, 1, 64, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
+    if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_pc2<WG_PIX, 1, WM, WN, 2, 2, 1, 64, 1, 64, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
+    if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_pc2<WG_PIX, 1, WM, WN, 2, 2, 1, 64, 1, 64, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
+    if (pp == S2K_PRO_RELU && pq == S2K_PRO_NONE) return launch_pc2<WG_PIX, 1, WM, WN, 2, 2, 1, 64, 1, 64, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
     return 1;      // SiLU / GELU prologues cost a producer too many instructions per tile: generic kernels
 }
 
@@ -379,8 +410,16 @@ int launch_wgrad_pc(WgradP& p, int mode, hipStream_t st) {
     const int64_t npix = (int64_t)p.B * p.HWp;
     if (p.gatep || p.gateq) return 1;
     if ((enabled & 1) && mode == S2K_MODE_CONV && p.T == 9 && p.S == 1 && p.KH == 3 && p.KW == 3 && p.H == p.HO && p.W == p.WO) {
-        const bool thin = (p.M <= 32) || (p.M <= 64 && p.C <= 32);     // few channels on one side: the 128-pixel kernels of wgrad.hip
-        if (thin) return 1;
+        const bool thin = (p.M <= 32) || (p.M <= 64 && p.C <= 32);     // few channels on one side
+        if (thin) {
+            if (p.C > 32 || p.WO < 64 || p.HO < 2) return 1;           // (the 128-pixel kernels of wgrad.hip)
+            p.R = 2; p.XW = 64; p.XWe = 64; p.IR = 4; p.IC = 66; p.WS = 66;
+            p.tiles_x = cdiv(p.WO, 64);
+            p.tiles_y = cdiv(p.HO, 2);
+            p.ntiles = p.B * p.tiles_x * p.tiles_y;
+            p.NP = 0;
+            return p.M <= 32 ? launch_pc_spatial_thin<1>(p, st) : launch_pc_spatial_thin<2>(p, st);
+        }
         const int XW = p.WO <= 64 ? p.WO : 64;
         const int XWe = (XW + 1) & ~1;
         int R = 64 / XWe;

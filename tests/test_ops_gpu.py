@@ -246,6 +246,10 @@ def test_wgrad_3x3(B, M, C, CT, c_off, H, W, proq):
     (1, 64, 96, 96, 0, 9, 56, 0),        # (1, 56)   (224-pixel inputs: 56 / 28 / 14 maps)
     (2, 96, 64, 64, 0, 28, 28, 3),       # (2, 28)
     (3, 512, 64, 64, 0, 14, 14, 3),      # (4, 14): pixel splits over 8 m-tiles
+    (2, 32, 32, 32, 0, 6, 64, 3),        # thin (a 32-channel side): 128-pixel tiles, the four consumer waves split the pixel pairs
+    (1, 32, 13, 45, 32, 10, 130, 0),     # thin, 13 of 32 columns used, channel slice of a concat conv, ragged x tiles (130 = 2 x 64 + 2)
+    (2, 64, 24, 24, 0, 5, 128, 0),       # thin with two m-tiles (waves 2 x 1 x 2), odd height (last tile has one row)
+    (1, 24, 32, 32, 0, 4, 64, 3),        # thin, M below one tile
 ])
 def test_wgrad_3x3_producer_consumer_tiles(B, M, C, CT, c_off, H, W, proq):
     """the shapes that take the producer / consumer kernels (csrc/wgrad_pc.hip), one case per compiled tile geometry"""
