@@ -1,0 +1,33 @@
+// Shared declarations of the implicit-GEMM convolution kernels (igemm.hip: generic 4-wave kernels; igemm_pc.hip: the
+// producer / consumer kernels for the prologue-light, MFMA-bound shapes).
+#pragma once
+#include "common.h"
+
+namespace s2k {
+
+enum { BM_PIX = 0, BM_SPATIAL = 1 };
+
+struct ConvP {
+    const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
+    float* y;
+    float* scratch;      // split-K partial tiles [splits][Y layout] (deep, short-N layers), or null
+    int splits, chunks_per_split;
+    int64_t y_elems;
+    double* stats;
+    int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
+    int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC, nrep;
+    int Ctot, n_mtiles, n_tiles, HW, Ntot, a_mfast, b_floats;
+    int R, XW, tiles_x, tiles_y, IR, IC, WS, CS;
+};
+
+// bijective remap: consecutive logical tiles land on the same XCD (hardware deals blocks round-robin
+// over the 8 XCDs; which XCD is irrelevant, only that ids congruent mod 8 share one)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// igemm_pc.hip: S2K_OK = launched, 1 = not one of its shapes (the caller takes the generic kernels), < 0 = error
+int launch_conv_pc(ConvP& p, hipStream_t st);
+
+}  // namespace s2k

@@ -24,30 +24,9 @@
 #include <algorithm>
 
 #include "common.h"
+#include "igemm.h"
 
 namespace s2k {
-
-enum { BM_PIX = 0, BM_SPATIAL = 1 };
-
-struct ConvP {
-    const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
-    float* y;
-    float* scratch;      // split-K partial tiles [splits][Y layout] (deep, short-N layers), or null
-    int splits, chunks_per_split;
-    int64_t y_elems;
-    double* stats;
-    int B, C1, C2, H, W, M, KH, KW, S, PT, PL, HO, WO;
-    int pro1, pro2, mode, w_sm, w_sk, w_st, flip, beta, YC, nrep;
-    int Ctot, n_mtiles, n_tiles, HW, Ntot, a_mfast, b_floats;
-    int R, XW, tiles_x, tiles_y, IR, IC, WS, CS;
-};
-
-// bijective remap: consecutive logical tiles land on the same XCD (hardware deals blocks round-robin
-// over the 8 XCDs; which XCD is irrelevant, only that ids congruent mod 8 share one)
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // BVEC (1x1 stager only): a lane moves 4 consecutive pixels of one channel (one 16-byte load, one ds_write_b128, one
 // gate load) instead of one: the per-element address / validity / LDS-store work of the prologue-heavy 1x1 convs drops 4x.
@@ -727,8 +706,14 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (ntot > 0x7fffffff) { set_error("conv: too many pixels"); return S2K_EINVAL; }
     p.Ntot = (int)ntot;
 
-    const int bm = pick_bm(p.M);
     hipStream_t st = c.stream;
+    {   // the prologue-light, MFMA-bound shapes run on the producer / consumer kernels (igemm_pc.hip); 1 = not one of theirs
+        const int rc = launch_conv_pc(p, st);
+        if (rc != 1) return rc;
+        p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
+        p.n_tiles = p.n_mtiles = 0;
+    }
+    const int bm = pick_bm(p.M);
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy
         const int64_t tiles_big = (int64_t)cdiv(p.M, bm) * cdiv(p.Ntot, bm == 128 ? 128 : 256);

@@ -170,6 +170,30 @@ def test_conv3x3(B, C1, C2, H, W, M, pro1, pro2):
     _conv_case(B, C1, C2, H, W, M, 3, 1, 1, 1, H, W, pro1, pro2, False, bias=True, stats=True)
 
 
+@pytest.mark.parametrize("B,C1,H,W,M,pro,bias,stats,beta", [
+    (4, 256, 64, 64, 256, 0, False, True, 0),    # 128 x 128 tiles, BatchNorm statistics epilogue
+    (4, 264, 64, 64, 200, 3, True, True, 0),     # 64-row tiles (M = 200 pads 128-row tiles by 28 %), ReLU prologue, bias, K tail (264 = 8 x 32 + 8)
+    (6, 288, 1, 200, 320, 0, True, False, 1),    # a Linear over feature-major tokens (H = 1), accumulate into Y (beta)
+    (3, 256, 100, 100, 176, 0, False, True, 0),  # pixel count not a multiple of the tile: tiles straddle images, ragged last tile
+])
+def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
+    """shapes that take the producer / consumer kernels (csrc/igemm_pc.hip): >= 192 tiles of 128 pixels"""
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, pro, 0, False, bias=bias, stats=stats, beta=beta)
+
+
+@pytest.mark.parametrize("B,C1,C2,H,W,M,pro,beta", [
+    (4, 40, 24, 64, 128, 64, 0, 0),      # (R, XW) = (2, 64): decoder concat conv, two x tiles per row
+    (8, 64, 0, 32, 32, 128, 3, 0),       # (4, 32): BatchNorm + ReLU prologue, zero padding after the activation
+    (20, 72, 0, 16, 16, 192, 3, 1),      # (8, 16): 64-row tiles x 3, accumulate (a data gradient on top of an existing one)
+    (4, 16, 8, 30, 56, 72, 0, 0),        # (2, 56) (224-pixel inputs), odd row count, K tail (24 channels = 3 chunks)
+    (12, 32, 0, 28, 28, 64, 3, 0),       # (4, 28)
+    (40, 64, 0, 14, 14, 128, 0, 0),      # (8, 14)
+])
+def test_conv3x3_producer_consumer(B, C1, C2, H, W, M, pro, beta):
+    # (statistics + accumulate never occur together in a plan; the oracle takes the statistics before the accumulate)
+    _conv_case(B, C1, C2, H, W, M, 3, 1, 1, 1, H, W, pro, pro if C2 else 0, False, bias=True, stats=(beta == 0), beta=beta)
+
+
 @pytest.mark.parametrize("C,H,W", [(13, 32, 32), (6, 30, 26), (4, 64, 64)])
 def test_stem_conv_tf_same_stride2(C, H, W):
     from s2lc_amd.plan.unet_plan import same_pads
