@@ -625,7 +625,20 @@ def op_mae_loss_bwd(m: Mem, o):
 def op_transpose_cl(m: Mem, o):
     B, C, L, LO, Lout = o["B"], o["C"], o["L"], o["L_OFF"], o["LOUT"]
     x = m.view(o["X"], (B, C, L))
-    m.view(o["Y"], (B, Lout, C)).copy_(x[:, :, LO:LO + Lout].permute(0, 2, 1))
+    ys, yo = o.get("YS", 0), o.get("Y_OFF", 0)
+    if ys <= 0:
+        ys, yo = C, 0
+    y = m.view(o["Y"], (B, Lout, ys))
+    y.zero_()
+    y[:, :, yo:yo + C] = x[:, :, LO:LO + Lout].permute(0, 2, 1)
+
+
+def op_ids_to_dec_idx(m: Mem, o):
+    B, L, keep = o["B"], o["L"], o["KEEP"]
+    ids = m.view(o["IDS"], (B, L), "i64")
+    dec = m.view(o["DEC_IDX"], (B, 1 + L), "i32")
+    dec[:, 0] = 0
+    dec[:, 1:] = torch.where((ids >= 0) & (ids < keep), ids + 1, torch.full_like(ids, -1)).to(torch.int32)
 
 
 def op_confusion(m: Mem, o):
@@ -710,7 +723,7 @@ DISPATCH = {
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
     "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_FC_WGRAD": op_se_fc_wgrad, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
-    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
+    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "IDS_TO_DEC_IDX": op_ids_to_dec_idx, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }
 
 

@@ -604,18 +604,20 @@ int launch_mae_loss_bwd(const S2kOp& op, const Ctx& c) {
 }
 
 // ---------------- [B][C][L] -> [B][LOUT][C] through a 64x64 LDS tile -------------------------------------------
-__global__ void __launch_bounds__(NTHREADS) transpose_cl_kernel(const float* x, float* y, int B, int C, int L, int l_off, int Lout) {
+__global__ void __launch_bounds__(NTHREADS) transpose_cl_kernel(const float* x, float* y, int B, int C, int L, int l_off, int Lout, int ys,
+                                                                int y_off) {
     __shared__ float tile[64][65];
     const int ct = blockIdx.x, lt = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // column tile ct covers Y columns [64 ct, 64 ct + 64) = source channels shifted by y_off
     for (int r = wave; r < 64; r += 4) {   // r = channel inside the tile, lanes along tokens
-        const int cc = ct * 64 + r, j = lt * 64 + lane;
-        tile[r][lane] = (cc < C && j < Lout) ? x[((int64_t)b * C + cc) * L + j + l_off] : 0.0f;
+        const int cc = ct * 64 + r - y_off, j = lt * 64 + lane;
+        tile[r][lane] = (cc >= 0 && cc < C && j < Lout) ? x[((int64_t)b * C + cc) * L + j + l_off] : 0.0f;
     }
     __syncthreads();
     for (int r = wave; r < 64; r += 4) {   // r = token inside the tile, lanes along channels
-        const int j = lt * 64 + r, cc = ct * 64 + lane;
-        if (j < Lout && cc < C) y[((int64_t)b * Lout + j) * C + cc] = tile[lane][r];
+        const int j = lt * 64 + r, col = ct * 64 + lane;
+        if (j < Lout && col < ys) y[((int64_t)b * Lout + j) * ys + col] = tile[lane][r];
     }
 }
 
@@ -625,8 +627,37 @@ int launch_transpose_cl(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("transpose_cl", x, y);
     const int B = op.d[S2K_TRANSPOSE_CL_D_B], C = op.d[S2K_TRANSPOSE_CL_D_C], L = op.d[S2K_TRANSPOSE_CL_D_L];
     const int l_off = op.d[S2K_TRANSPOSE_CL_D_L_OFF], Lout = op.d[S2K_TRANSPOSE_CL_D_LOUT];
-    if (!x || !y || B <= 0 || C <= 0 || L <= 0 || l_off < 0 || Lout <= 0 || l_off + Lout > L || B > 65535) { set_error("transpose_cl: bad args"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(transpose_cl_kernel, dim3(cdiv(C, 64), cdiv(Lout, 64), B), dim3(NTHREADS), 0, c.stream, x, y, B, C, L, l_off, Lout);
+    int ys = op.d[S2K_TRANSPOSE_CL_D_YS], y_off = op.d[S2K_TRANSPOSE_CL_D_Y_OFF];
+    if (ys <= 0) { ys = C; y_off = 0; }
+    if (!x || !y || B <= 0 || C <= 0 || L <= 0 || l_off < 0 || Lout <= 0 || l_off + Lout > L || B > 65535 || y_off < 0 || y_off + C > ys) {
+        set_error("transpose_cl: bad args"); return S2K_EINVAL;
+    }
+    hipLaunchKernelGGL(transpose_cl_kernel, dim3(cdiv(ys, 64), cdiv(Lout, 64), B), dim3(NTHREADS), 0, c.stream, x, y, B, C, L, l_off, Lout, ys, y_off);
+    return S2K_OK;
+}
+
+// ---------------- decoder gather table from a caller-supplied ids_restore ------------------------------------------
+__global__ void ids_to_dec_idx_kernel(const int64_t* ids, int* dec, int B, int L, int keep) {
+    const int64_t n = (int64_t)B * (1 + L);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % (1 + L)), b = (int)(i / (1 + L));
+        int v = 0;
+        if (j > 0) {
+            const int64_t r = ids[(int64_t)b * L + j - 1];
+            v = (r >= 0 && r < keep) ? 1 + (int)r : -1;
+        }
+        dec[i] = v;
+    }
+}
+
+int launch_ids_to_dec_idx(const S2kOp& op, const Ctx& c) {
+    const int64_t* ids = ref_ptr<const int64_t>(c, op.t[S2K_IDS_TO_DEC_IDX_T_IDS]);
+    int* dec = ref_ptr<int>(c, op.t[S2K_IDS_TO_DEC_IDX_T_DEC_IDX]);
+    CHECK_PTRS("ids_to_dec_idx", ids, dec);
+    const int B = op.d[S2K_IDS_TO_DEC_IDX_D_B], L = op.d[S2K_IDS_TO_DEC_IDX_D_L], keep = op.d[S2K_IDS_TO_DEC_IDX_D_KEEP];
+    if (!ids || !dec || B <= 0 || L <= 0 || keep < 0) { set_error("ids_to_dec_idx: bad args"); return S2K_EINVAL; }
+    const int64_t n = (int64_t)B * (1 + L);
+    hipLaunchKernelGGL(ids_to_dec_idx_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 4096)), dim3(256), 0, c.stream, ids, dec, B, L, keep);
     return S2K_OK;
 }
 

@@ -173,11 +173,14 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         return plan_mae(self.spec, B, mask_ratio, training, self._layout,    # (no BatchNorm / dropout: training == want_bwd)
                         bucket_floats=getattr(self, "_bucket_floats", 8 << 20))
 
-    def _check(self, imgs):
+    def _check_imgs(self, imgs):
         s = self.spec
         want = (s.in_chans, s.num_frames, s.img_size, s.img_size)
         if imgs.dim() != 5 or tuple(imgs.shape[1:]) != want:
             raise ValueError(f"expected [B,{want[0]},{want[1]},{want[2]},{want[3]}], got {tuple(imgs.shape)}")
+
+    def _check(self, imgs):
+        self._check_imgs(imgs)
         if not self.spec.decoder:
             raise RuntimeError("this MaskedAutoencoderViT was loaded without its decoder (load_prithvi(no_decoder=True))")
 
@@ -189,19 +192,58 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         return out["loss"].reshape(()), out["pred"], out["mask"]
 
     def forward_encoder(self, x: torch.Tensor, mask_ratio: float):
-        """(latent [B, 1+keep, D], mask, ids_restore) — forward only (gradients flow through forward())."""
-        from ..vit_engine import run_vit
+        """(latent [B, 1 + keep, D], mask [B, L], ids_restore [B, L])   (reference prithvi.py:285-305); differentiable: the
+        gradient of `latent` flows into the encoder's parameters.  Also runs on a decoder-less backbone (load_prithvi with
+        no_decoder=True — the configuration in which the reference calls it, prithvi_segmentation.py:159)."""
+        from ..plan.vit_plan import plan_mae_encoder
+        from ..vit_engine import run_method
 
-        self._check(x)
-        with torch.no_grad():
-            out = run_vit(self, x, dict(noise=self.masking_noise), mask_ratio=mask_ratio)
+        self._check_imgs(x)
+        mr = float(mask_ratio)
+        out = run_method(self, ("encoder", tuple(x.shape), mr), lambda bwd: plan_mae_encoder(self.spec, x.shape[0], mr, bwd, self._layout),
+                         {"x": x.contiguous()}, {"noise": self.masking_noise})
         return out["latent"], out["mask"], out["ids_restore"]
 
-    def forward_decoder(self, x, ids_restore):
-        raise NotImplementedError("the decoder runs fused inside forward(); call forward(imgs, mask_ratio)")
+    def forward_decoder(self, x: torch.Tensor, ids_restore: torch.Tensor):
+        """pred [B, L, tubelet * p * p * C] from the encoder's latent x [B, 1 + keep, D] and ids_restore [B, L]
+        (reference prithvi.py:307-331); differentiable w.r.t. x and the decoder's parameters."""
+        from ..plan.vit_plan import plan_mae_decoder
+        from ..vit_engine import run_method
 
-    def forward_loss(self, imgs, pred, mask):
-        raise NotImplementedError("the loss runs fused inside forward(); call forward(imgs, mask_ratio)")
+        if not self.spec.decoder:
+            raise RuntimeError("this MaskedAutoencoderViT was loaded without its decoder (load_prithvi(no_decoder=True))")
+        s = self.spec
+        if x.dim() != 3 or x.shape[2] != s.embed_dim or tuple(ids_restore.shape) != (x.shape[0], s.num_patches):
+            raise ValueError(f"expected x [B, 1 + keep, {s.embed_dim}] and ids_restore [B, {s.num_patches}], got {tuple(x.shape)}, {tuple(ids_restore.shape)}")
+        B, N = x.shape[0], x.shape[1]
+        out = run_method(self, ("decoder", B, N), lambda bwd: plan_mae_decoder(s, B, N, bwd, self._layout),
+                         {"x": x.contiguous(), "ids_restore": ids_restore.contiguous()})
+        return out["pred"]
 
-    def random_masking(self, x, mask_ratio):
-        raise NotImplementedError("masking runs fused inside forward(); inject noise through `masking_noise`")
+    def forward_loss(self, imgs: torch.Tensor, pred: torch.Tensor, mask: torch.Tensor):
+        """Masked mean squared error per patch (reference prithvi.py:333-350); differentiable w.r.t. pred."""
+        from ..plan.vit_plan import plan_mae_loss
+        from ..vit_engine import run_method
+
+        self._check_imgs(imgs)
+        s = self.spec
+        B = imgs.shape[0]
+        if tuple(pred.shape) != (B, s.num_patches, s.patch_dim) or tuple(mask.shape) != (B, s.num_patches):
+            raise ValueError(f"expected pred [B, {s.num_patches}, {s.patch_dim}] and mask [B, {s.num_patches}]")
+        out = run_method(self, ("loss", B), lambda bwd: plan_mae_loss(s, B, bwd, self._layout),
+                         {"imgs": imgs.contiguous(), "pred": pred.contiguous(), "mask": mask.contiguous()})
+        return out["loss"].reshape(())
+
+    def random_masking(self, x: torch.Tensor, mask_ratio: float):
+        """Per-sample random masking by argsort of uniform noise (reference prithvi.py:258-283): (x_masked [N, keep, D],
+        mask [N, L] with 1 = removed, ids_restore [N, L]).  The noise is `self.masking_noise` if set, else drawn on the device."""
+        from ..plan.vit_plan import plan_random_masking
+        from ..vit_engine import run_method
+
+        if x.dim() != 3:
+            raise ValueError(f"expected x [N, L, D], got {tuple(x.shape)}")
+        N, L, Dm = x.shape
+        mr = float(mask_ratio)
+        out = run_method(self, ("masking", N, L, Dm, mr), lambda bwd: plan_random_masking(self.spec, N, L, Dm, mr, bwd, self._layout),
+                         {"x": x.contiguous()}, {"noise": self.masking_noise})
+        return out["x_masked"], out["mask"], out["ids_restore"]

@@ -18,7 +18,7 @@ OP_BYTES = 8 + 8 * N_T + 8 * N_N + 4 * N_D + 4 * N_F
 assert OP_BYTES == 256
 
 # ---- bases -------------------------------------------------------------------------------
-BASES = ["WS", "PARAMS", "GRADS", "BUFS", "X", "OUT", "DOUT", "NOISE", "WGS", "CONST", "Y", "AUX", "WPACK"]
+BASES = ["WS", "PARAMS", "GRADS", "BUFS", "X", "OUT", "DOUT", "NOISE", "WGS", "CONST", "Y", "AUX", "WPACK", "DX"]
 BASE = {n: i for i, n in enumerate(BASES)}
 
 # ---- statistics replicas -------------------------------------------------------------------------
@@ -138,6 +138,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # MASK[b][l] = r >= KEEP (f32);  gather tables (int32): ENC_IDX[b] = {-1 (cls), index of rank 0 .. KEEP-1},
     # DEC_IDX[b] = {0, (r_l < KEEP ? 1 + r_l : -1) for l < L}
     "MAE_MASK_INDEX": (["NOISE", "IDS_RESTORE", "MASK", "ENC_IDX", "DEC_IDX"], [], ["B", "L", "KEEP"], []),
+    # the decoder's gather table from a caller-supplied IDS_RESTORE (forward_decoder(x, ids_restore), prithvi.py:307-316):
+    # DEC_IDX[b][0] = 0 (cls);  DEC_IDX[b][1 + l] = IDS[b][l] < KEEP ? 1 + IDS[b][l] : -1 (mask token)
+    "IDS_TO_DEC_IDX": (["IDS", "DEC_IDX"], [], ["B", "L", "KEEP"], []),
     # OUT[b][c][j] = (i = IDX[b][j]) >= 0 ? IN[b][c][i] : FILL[c];  then + POS[(POS_BY_SRC ? i + POS_OFF : j) * C + c]
     # (POS is token-major, as the reference's pos_embed parameters)
     "TOKEN_GATHER": (["IN", "IDX", "FILL", "POS", "OUT"], [], ["B", "C", "LIN", "LOUT", "POS_BY_SRC", "POS_OFF", "LIN_S", "LOUT_S"], []),
@@ -153,7 +156,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "MAE_LOSS_BWD": (["PRED", "IMGS", "MASK", "ACC", "GOUT", "DPRED"], [],
                      ["B", "C", "T", "H", "W", "P", "TUB", "LP", "L_OFF", "NORM_PIX"], []),
     # Y[b][j][c] = X[b][c][j + L_OFF], j < LOUT   (feature-major -> the reference's token-major tensors at the API boundary)
-    "TRANSPOSE_CL": (["X", "Y"], [], ["B", "C", "L", "L_OFF", "LOUT"], []),
+    # YS > 0: rows of Y have stride YS floats and the C values go to columns Y_OFF .. Y_OFF + C - 1, every other column of the row
+    # is written as zero (token-major API tensors -> feature-major rows padded to a multiple of 4 with zero padding columns)
+    "TRANSPOSE_CL": (["X", "Y"], [], ["B", "C", "L", "L_OFF", "LOUT", "YS", "Y_OFF"], []),
     # HIST[t*C + p] += #{i : LABELS[i] == t, PRED[i] == p}  (int64; labels / predictions outside [0, C) are skipped):
     # the one accumulator behind confusion matrix, IoU, accuracy and F1 (train_segmentation.py:53-63,145-159) — no host sync
     "CONFUSION": (["PRED", "LABELS", "HIST"], ["COUNT"], ["C"], []),

@@ -497,3 +497,201 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
     noise_bytes = drop_off + B * s.fcn_out_channels * 4
     return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
                    {"noise": noise, "drop_u": drop_u}, noise_bytes, (B, s.num_classes, Hh, Hh), p.tensors, p.wpack.mark(), lo, x_shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Separately callable methods of MaskedAutoencoderViT (prithvi.py:258-350): each is its own small plan over the SAME flat
+# parameter buffer and the same stage kernels as the fused forward; tensors cross the API boundary token-major, as in the
+# reference, and are re-laid out feature-major by TRANSPOSE_CL stages at either end.
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class MethodPlan:
+    """A VitPlan with several inputs / differentiable outputs (engine: vit_engine.run_method)."""
+    spec: object
+    B: int
+    training: bool
+    fwd: Program
+    bwd: Program | None
+    ws_bytes: int
+    aux_bytes: int
+    const_table: list
+    layout: ParamLayout
+    bwd_param_marks: list
+    inputs: dict             # name -> TRef in the X base (packed input buffer)
+    x_bytes: int
+    outputs: dict            # name -> TRef in the OUT base
+    out_bytes: int
+    noise: dict
+    noise_bytes: int
+    douts: dict              # differentiable output name -> TRef in the DOUT base (upstream gradients, packed)
+    dout_bytes: int
+    dins: dict               # differentiable input name -> TRef in the DX base (gradients w.r.t. inputs)
+    dx_bytes: int
+    tensors: dict
+    wpack_bytes: int = 0
+    trainable_lo: int = 0
+
+
+class _Packer:
+    def __init__(self, base: str):
+        self.base, self.off, self.refs = base, 0, {}
+
+    def add(self, name: str, shape: tuple, dtype: str = "f32") -> TRef:
+        isz = {"f32": 4, "i64": 8, "i32": 4}[dtype]
+        t = TRef(D.BASE[self.base], self.off, tuple(shape), dtype, name)
+        self.refs[name] = t
+        self.off += (_numel(shape) * isz + 255) // 256 * 256
+        return t
+
+
+def _method_plan(p: _P, s, B, want_bwd, layout, xin: _Packer, outs: _Packer, noise: _Packer, douts: _Packer, dins: _Packer,
+                 bucket_floats: int) -> MethodPlan:
+    segments, bwd = finish_plan(p, layout, want_bwd, bucket_floats)
+    return MethodPlan(s, B, want_bwd, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, xin.refs, max(xin.off, 256),
+                      outs.refs, max(outs.off, 256), noise.refs, max(noise.off, 4), douts.refs, max(douts.off, 256), dins.refs,
+                      max(dins.off, 256), p.tensors, p.wpack.mark(), 0)
+
+
+def plan_mae_encoder(s: MaeSpec, B: int, mask_ratio: float, want_bwd: bool, layout: ParamLayout, want_dx: bool = False,
+                     bucket_floats: int = 8 << 20) -> MethodPlan:
+    """forward_encoder(x, mask_ratio) -> (latent [B, 1 + keep, D], mask, ids_restore)   (prithvi.py:285-305)."""
+    p = _P(s, layout, B, s.img_size, s.img_size, want_bwd)
+    v = _V(p, lambda name: True)
+    Lp, Dm = s.num_patches, s.embed_dim
+    keep = int(Lp * (1 - mask_ratio))
+    xin, outs, nz, douts, dins = _Packer("X"), _Packer("OUT"), _Packer("NOISE"), _Packer("DOUT"), _Packer("DX")
+    x_img = xin.add("x", (B, s.in_chans, s.num_frames, s.img_size, s.img_size))
+    noise = nz.add("noise", (B, Lp))
+    N = 1 + keep
+    out_lat = outs.add("latent", (B, N, Dm))
+    o = {"mask": outs.add("mask", (B, Lp)), "ids_restore": outs.add("ids_restore", (B, Lp), "i64")}
+    latent, N2, erec = _encoder(v, s, "", x_img, noise, keep, o, True)
+    assert N2 == N
+    NS = erec["NS"]
+    p.fwd.add("TRANSPOSE_CL", X=latent, Y=out_lat, B=B, C=Dm, L=NS, L_OFF=0, LOUT=N)
+    d_lat = douts.add("latent", (B, N, Dm))
+
+    def backward():
+        g_lat = p.alloc("g:latent", (B, Dm, NS))
+        # token-major gradient [B][N][Dm] -> feature-major rows of NS floats with zero padding columns
+        p.bwd.add("TRANSPOSE_CL", X=d_lat, Y=g_lat, B=B, C=N, L=Dm, L_OFF=0, LOUT=Dm, YS=NS, Y_OFF=0)
+        _encoder_bwd(v, s, erec, g_lat)
+
+    p.tape.append(backward)
+    return _method_plan(p, s, B, want_bwd, layout, xin, outs, nz, douts, dins, bucket_floats)
+
+
+def plan_mae_decoder(s: MaeSpec, B: int, N: int, want_bwd: bool, layout: ParamLayout, bucket_floats: int = 8 << 20) -> MethodPlan:
+    """forward_decoder(x [B, N, D], ids_restore [B, L]) -> pred [B, L, patch_dim]   (prithvi.py:307-331)."""
+    assert s.decoder
+    p = _P(s, layout, B, s.img_size, s.img_size, want_bwd)
+    v = _V(p, lambda name: True)
+    Lp, Dm, Dd, PD = s.num_patches, s.embed_dim, s.decoder_embed_dim, s.patch_dim
+    keep = N - 1
+    xin, outs, nz, douts, dins = _Packer("X"), _Packer("OUT"), _Packer("NOISE"), _Packer("DOUT"), _Packer("DX")
+    x_tm = xin.add("x", (B, N, Dm))
+    ids = xin.add("ids_restore", (B, Lp), "i64")
+    out_pred = outs.add("pred", (B, Lp, PD))
+    NS, ND = row_stride(N), Lp + 1
+    NDS = row_stride(ND)
+    latent = p.alloc("latent_fm", (B, Dm, NS))
+    p.fwd.add("TRANSPOSE_CL", X=x_tm, Y=latent, B=B, C=N, L=Dm, L_OFF=0, LOUT=Dm, YS=NS, Y_OFF=0)
+    dec_idx = p.alloc("dec_idx", (B, 1 + Lp), "i32")
+    p.fwd.add("IDS_TO_DEC_IDX", IDS=ids, DEC_IDX=dec_idx, B=B, L=Lp, KEEP=keep)
+    dx = v.linear_fwd("decoder_embed.weight", "decoder_embed.bias", latent, Dm, Dd, NS)
+    y0 = p.alloc("y0", (B, Dd, NDS))
+    p.fwd.add("TOKEN_GATHER", IN=dx, IDX=dec_idx, FILL=p.param("mask_token"), POS=p.param("decoder_pos_embed"), OUT=y0,
+              B=B, C=Dd, LIN=N, LOUT=ND, POS_BY_SRC=0, POS_OFF=0, LIN_S=NS, LOUT_S=NDS)
+    drecs = []
+    y = y0
+    for i in range(s.decoder_depth):
+        y, r = v.block_fwd(f"decoder_blocks.{i}", y, Dd, s.decoder_num_heads, int(Dd * s.mlp_ratio), ND)
+        drecs.append(r)
+    yn, mrd = v.ln_fwd("decoder_norm", y, Dd, NDS, 1e-5)
+    pred_fm = v.linear_fwd("decoder_pred.weight", "decoder_pred.bias", yn, Dd, PD, NDS)
+    p.fwd.add("TRANSPOSE_CL", X=pred_fm, Y=out_pred, B=B, C=PD, L=NDS, L_OFF=1, LOUT=Lp)
+    d_pred = douts.add("pred", (B, Lp, PD))
+    d_x = dins.add("x", (B, N, Dm))
+
+    def backward():
+        g_pred = p.alloc("g:pred", (B, PD, NDS))
+        # [B][Lp][PD] -> [B][PD][NDS]: tokens land in columns 1 .. Lp, the cls column and the padding stay zero
+        p.bwd.add("TRANSPOSE_CL", X=d_pred, Y=g_pred, B=B, C=Lp, L=PD, L_OFF=0, LOUT=PD, YS=NDS, Y_OFF=1)
+        g_yn = p.alloc("g:yn", (B, Dd, NDS))
+        v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, NDS, dx=g_yn)
+        g = p.alloc("g:dec", (B, Dd, NDS))
+        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0)
+        for r in reversed(drecs):
+            v.block_bwd(r, g)
+        g_dx = p.alloc("g:dx", (B, Dd, NS))
+        p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=dec_idx, DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND,
+                  LIN_S=NS, LOUT_S=NDS)
+        g_lat = p.alloc("g:latent", (B, Dm, NS))
+        v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, NS, dx=g_lat)
+        p.bwd.add("TRANSPOSE_CL", X=g_lat, Y=d_x, B=B, C=Dm, L=NS, L_OFF=0, LOUT=N)
+
+    p.tape.append(backward)
+    return _method_plan(p, s, B, want_bwd, layout, xin, outs, nz, douts, dins, bucket_floats)
+
+
+def plan_mae_loss(s: MaeSpec, B: int, want_bwd: bool, layout: ParamLayout) -> MethodPlan:
+    """forward_loss(imgs, pred [B, L, patch_dim], mask [B, L]) -> loss   (prithvi.py:333-350)."""
+    p = _P(s, layout, B, s.img_size, s.img_size, want_bwd)
+    Lp, PD = s.num_patches, s.patch_dim
+    LS = row_stride(Lp)
+    xin, outs, nz, douts, dins = _Packer("X"), _Packer("OUT"), _Packer("NOISE"), _Packer("DOUT"), _Packer("DX")
+    imgs = xin.add("imgs", (B, s.in_chans, s.num_frames, s.img_size, s.img_size))
+    pred = xin.add("pred", (B, Lp, PD))
+    mask = xin.add("mask", (B, Lp))
+    loss = outs.add("loss", (1,))
+    pred_fm = p.alloc("pred_fm", (B, PD, LS))
+    p.fwd.add("TRANSPOSE_CL", X=pred, Y=pred_fm, B=B, C=Lp, L=PD, L_OFF=0, LOUT=PD, YS=LS, Y_OFF=0)
+    acc = p.aux.alloc("mae_acc", (2,), "f64")
+    geo = dict(B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size, TUB=s.tubelet_size, LP=LS, L_OFF=0,
+               NORM_PIX=int(s.norm_pix_loss))
+    p.fwd.add("MAE_LOSS_FWD", PRED=pred_fm, IMGS=imgs, MASK=mask, LOSS=loss, ACC=acc, **geo)
+    gout = douts.add("loss", (1,))
+    d_pred = dins.add("pred", (B, Lp, PD))
+
+    def backward():
+        g = p.alloc("g:pred", (B, PD, LS))
+        p.bwd.add("MAE_LOSS_BWD", PRED=pred_fm, IMGS=imgs, MASK=mask, ACC=acc, GOUT=gout, DPRED=g, **geo)
+        p.bwd.add("TRANSPOSE_CL", X=g, Y=d_pred, B=B, C=PD, L=LS, L_OFF=0, LOUT=Lp)
+
+    p.tape.append(backward)
+    return _method_plan(p, s, B, want_bwd, layout, xin, outs, nz, douts, dins, 8 << 20)
+
+
+def plan_random_masking(s: MaeSpec, B: int, L: int, Dm: int, mask_ratio: float, want_bwd: bool, layout: ParamLayout) -> MethodPlan:
+    """random_masking(x [B, L, D], mask_ratio) -> (x_masked [B, keep, D], mask, ids_restore)   (prithvi.py:258-283)."""
+    p = _P(s, layout, B, s.img_size, s.img_size, want_bwd)
+    keep = int(L * (1 - mask_ratio))
+    if keep < 1:
+        raise ValueError("random_masking: nothing would be kept")
+    xin, outs, nz, douts, dins = _Packer("X"), _Packer("OUT"), _Packer("NOISE"), _Packer("DOUT"), _Packer("DX")
+    x_tm = xin.add("x", (B, L, Dm))
+    noise = nz.add("noise", (B, L))
+    out_xm = outs.add("x_masked", (B, keep, Dm))
+    out_mask = outs.add("mask", (B, L))
+    out_ids = outs.add("ids_restore", (B, L), "i64")
+    x_fm = p.alloc("x_fm", (B, Dm, L))
+    p.fwd.add("TRANSPOSE_CL", X=x_tm, Y=x_fm, B=B, C=L, L=Dm, L_OFF=0, LOUT=Dm)
+    enc_idx = p.alloc("enc_idx", (B, 1 + keep), "i32")
+    dec_idx = p.alloc("dec_idx", (B, 1 + L), "i32")
+    p.fwd.add("MAE_MASK_INDEX", NOISE=noise, IDS_RESTORE=out_ids, MASK=out_mask, ENC_IDX=enc_idx, DEC_IDX=dec_idx, B=B, L=L, KEEP=keep)
+    xm_fm = p.alloc("xm_fm", (B, Dm, 1 + keep))      # column 0 = the (absent) cls slot of the index table, dropped below
+    p.fwd.add("TOKEN_GATHER", IN=x_fm, IDX=enc_idx, FILL=None, POS=None, OUT=xm_fm, B=B, C=Dm, LIN=L, LOUT=1 + keep, POS_BY_SRC=0,
+              POS_OFF=0, LIN_S=L, LOUT_S=1 + keep)
+    p.fwd.add("TRANSPOSE_CL", X=xm_fm, Y=out_xm, B=B, C=Dm, L=1 + keep, L_OFF=1, LOUT=keep)
+    d_xm = douts.add("x_masked", (B, keep, Dm))
+    d_x = dins.add("x", (B, L, Dm))
+
+    def backward():
+        g_fm = p.alloc("g:xm", (B, Dm, 1 + keep))
+        p.bwd.add("TRANSPOSE_CL", X=d_xm, Y=g_fm, B=B, C=keep, L=Dm, L_OFF=0, LOUT=Dm, YS=1 + keep, Y_OFF=1)
+        gx_fm = p.alloc("g:x", (B, Dm, L))
+        p.bwd.add("TOKEN_SCATTER", DOUT=g_fm, IDX=enc_idx, DIN=gx_fm, DFILL=None, B=B, C=Dm, LIN=L, LOUT=1 + keep, LIN_S=L, LOUT_S=1 + keep)
+        p.bwd.add("TRANSPOSE_CL", X=gx_fm, Y=d_x, B=B, C=Dm, L=L, L_OFF=0, LOUT=L)
+
+    p.tape.append(backward)
+    return _method_plan(p, s, B, want_bwd, layout, xin, outs, nz, douts, dins, 8 << 20)

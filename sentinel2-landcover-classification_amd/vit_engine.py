@@ -165,3 +165,138 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
     _lib.run(eng.fwd, eng.bases(module, x, out, noise, space=lease.space), _stream(x.device))
     lease.release()
     return eng.views(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Separately callable methods (MaskedAutoencoderViT.forward_encoder / forward_decoder / forward_loss / random_masking):
+# plans with several inputs and differentiable outputs (plan/vit_plan.py, MethodPlan).  Inputs are packed into one X
+# buffer, upstream gradients into one DOUT buffer, input gradients come back in a DX buffer; parameter gradients are
+# ADDED to the module's flat gradient buffer (several method nodes run in one backward pass: encoder, decoder, loss).
+# ---------------------------------------------------------------------------------------------------------------------
+class MethodEngine:
+    def __init__(self, plan, device: torch.device):
+        self.plan = plan
+        self.fwd = plan.fwd.pack()
+        self.bwd = plan.bwd.pack() if plan.bwd is not None else None
+        self.spaces = WorkspacePool(plan.ws_bytes, plan.aux_bytes, device)
+        self.const = torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32, device=device)
+        self.wpack = torch.zeros(plan.wpack_bytes // 4 + 65536, dtype=torch.float32, device=device)
+        self.wgs = torch.empty(plan.layout.n_params, dtype=torch.float32, device=device) if plan.bwd is not None else None
+        self.bwd_marks = plan.bwd_param_marks
+
+    def bases(self, module, space, xbuf, out, noise, dout=None, grads=None, dx=None) -> _lib.Bases:
+        b = _lib.Bases()
+        b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
+        b.set("PARAMS", module._flat_params).set("BUFS", module._flat_bufs)
+        b.set("X", xbuf).set("OUT", out).set("NOISE", noise)
+        if self.wgs is not None:
+            b.set("WGS", self.wgs)
+        if dout is not None:
+            b.set("DOUT", dout)
+        if grads is not None:
+            b.set("GRADS", grads)
+        if dx is not None:
+            b.set("DX", dx)
+        return b
+
+
+def _view(buf: torch.Tensor, t) -> torch.Tensor:
+    return buf[t.off:t.off + t.nbytes].view(_TORCH_DT[t.dtype]).view(t.shape)
+
+
+class _MethodFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, module, eng, noise, names, *tensors):
+        plan = eng.plan
+        dev = module._flat_params.device
+        xbuf = torch.empty(plan.x_bytes + 256, dtype=torch.uint8, device=dev)
+        for name, t in zip(names, tensors):
+            ref = plan.inputs[name]
+            _view(xbuf, ref).copy_(t.to(device=dev, dtype=_TORCH_DT[ref.dtype]).reshape(ref.shape))
+        out = torch.empty(plan.out_bytes + 256, dtype=torch.uint8, device=dev)
+        lease = eng.spaces.lease()
+        _lib.run(eng.fwd, eng.bases(module, lease.space, xbuf, out, noise), _stream(dev))
+        outs = tuple(_view(out, plan.outputs[n]) for n in plan.outputs)
+        ctx.module, ctx.eng, ctx.noise, ctx.names, ctx.xbuf, ctx.out, ctx.lease = module, eng, noise, names, xbuf, out, lease
+        ctx.mark_non_differentiable(*[o for n, o in zip(plan.outputs, outs) if n not in plan.douts])
+        if eng.bwd is None:
+            lease.release()
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        module, eng, lease, plan = ctx.module, ctx.eng, ctx.lease, ctx.eng.plan
+        if eng.bwd is None:
+            raise RuntimeError("this method was planned without a backward program")
+        if lease.space is None:
+            raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
+        dev = module._flat_params.device
+        dout = torch.zeros(plan.dout_bytes + 256, dtype=torch.uint8, device=dev)
+        for name, g in zip(plan.outputs, gouts):
+            if g is not None and name in plan.douts:
+                ref = plan.douts[name]
+                _view(dout, ref).copy_(g.to(torch.float32).reshape(ref.shape))
+        dx = torch.zeros(plan.dx_bytes + 256, dtype=torch.uint8, device=dev)
+        main = module._grad_buffer()
+        live = module._grads_live()
+        if not live or getattr(module, "_overwrite_next", False):
+            main.zero_()
+        module._overwrite_next = False
+        scratch = module._grad_scratch()
+        scratch.zero_()
+        _lib.run(eng.bwd, eng.bases(module, lease.space, ctx.xbuf, ctx.out, ctx.noise, dout=dout, grads=scratch, dx=dx), _stream(dev))
+        lease.release()
+        main.add_(scratch)
+        if not live:
+            module._publish_grads(module._no_grad_params)
+        grads_in = tuple(_view(dx, plan.dins[n]).clone() if n in plan.dins else None for n in ctx.names)
+        return (None, None, None, None, None) + grads_in
+
+
+def run_method(module, key, make_plan, inputs: dict, injected: dict | None = None) -> dict:
+    """Runs one separately callable method.  `key`: cache key of the plan (shapes, ratios); `make_plan(want_bwd)` builds the
+    MethodPlan; `inputs`: name -> tensor (device tensors; moved / cast as the plan asks).  Returns {output name: tensor}."""
+    dev = module._flat_params.device
+    if dev.type != "cuda":
+        raise RuntimeError(f"{type(module).__name__} runs on the HIP engine only: move the module to the GPU "
+                           "(there is no CPU fallback; the CPU restatement lives under oracle/ for tests)")
+    _lib.lib()
+    for name, t in inputs.items():
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}: the HIP engine takes GPU tensors")
+    needs = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs.values() if t.dtype.is_floating_point)
+                                         or any(p.requires_grad for p in module.parameters()))
+    ckey = ("method",) + tuple(key) + (needs, dev)
+    eng = module._engines.get(ckey)
+    if eng is None:
+        eng = MethodEngine(make_plan(needs), dev)
+        module._engines[ckey] = eng
+    plan = eng.plan
+    noise = torch.empty(max(plan.noise_bytes // 4, 1), dtype=torch.float32, device=dev)
+    for name, t in plan.noise.items():
+        n = int(np.prod(t.shape))
+        dst = noise[t.off // 4:t.off // 4 + n]
+        src = (injected or {}).get(name)
+        if src is None:
+            dst.uniform_(0.0, 1.0)
+        else:
+            if tuple(src.shape) != tuple(t.shape):
+                raise ValueError(f"{name} must have shape {tuple(t.shape)}, got {tuple(src.shape)}")
+            dst.copy_(src.to(device=dev, dtype=torch.float32).reshape(-1))
+    names = tuple(plan.inputs)
+    for n in names:
+        if tuple(inputs[n].shape) != tuple(plan.inputs[n].shape):
+            raise ValueError(f"{n} must have shape {tuple(plan.inputs[n].shape)}, got {tuple(inputs[n].shape)}")
+    if needs:
+        outs = _MethodFunction.apply(module._anchor(dev), module, eng, noise, names, *[inputs[n] for n in names])
+    else:
+        with torch.no_grad():
+            outs = _MethodFunction.forward(_NoCtx(), None, module, eng, noise, names, *[inputs[n] for n in names])
+    return dict(zip(plan.outputs, outs))
+
+
+class _NoCtx:
+    """Stand-in context for a forward that needs no autograd node."""
+
+    def mark_non_differentiable(self, *a):
+        pass

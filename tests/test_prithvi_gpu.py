@@ -142,3 +142,102 @@ def test_mae_default_noise_and_optimizer_step():
     assert torch.equal(model.pos_embed, pos0)
     assert not torch.equal(model.blocks[0].attn.qkv.weight, w0)
     assert all(np.isfinite(losses))
+
+
+# ---- the separately callable methods of the reference's surface (prithvi.py:258-350) -------------------------------------
+def test_random_masking_matches_reference_fixture_exactly():
+    """MaskedAutoencoderViT.random_masking on the reference's injected noise: kept rows, mask and ids_restore bit-exact."""
+    from oracle import detgen
+    from tests.helpers import PRITHVI_SMALL
+
+    g = load("prithvi_misc.npz")
+    model = MaskedAutoencoderViT(**PRITHVI_SMALL).to(DEV)
+    for tag in "abcd":
+        N, L, Dm = (int(v) for v in g[f"rm:{tag}:shape"])
+        r = float(g[f"rm:{tag}:ratio"][0])
+        x = detgen.normal(f"rm.{tag}.x", (N, L, Dm), seed=5)
+        model.masking_noise = detgen.uniform(f"rm.{tag}.n", (N, L), 0.0, 1.0, seed=5)
+        xm, mask, ids = model.random_masking(x.to(DEV), r)
+        assert np.array_equal(xm.cpu().numpy(), g[f"rm:{tag}:xm"]), tag
+        assert np.array_equal(mask.cpu().to(torch.uint8).numpy(), g[f"rm:{tag}:mask"]), tag
+        assert np.array_equal(ids.cpu().to(torch.int32).numpy(), g[f"rm:{tag}:ids"]), tag
+    # differentiable like the reference's gather: d(sum x_masked * w) / dx scatters w back to the kept rows
+    xg = x.to(DEV).requires_grad_(True)
+    xm, mask, ids = model.random_masking(xg, r)
+    w = torch.randn_like(xm)
+    (xm * w).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    xm_ref, _, _ = P.random_masking(xr, r, model.masking_noise)
+    (xm_ref * w.cpu()).sum().backward()
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("tag", ["small_bs2", "small_t3_bs2"])
+def test_encoder_decoder_loss_methods_compose_to_the_fused_forward(tag):
+    """forward_encoder -> forward_decoder -> forward_loss (three autograd nodes, three plans) against the reference fixture
+    and against the fused forward(): same loss / pred / latent, same parameter gradients."""
+    g = load(f"prithvi_mae_{tag}.npz")
+    cfg, sd, x, noise, ratio = mae_inputs(tag)
+    args = MAE_CASES[tag][0]
+    xg = x.to(DEV)
+
+    def fresh():
+        m = MaskedAutoencoderViT(**args)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        m.masking_noise = noise
+        return m
+
+    fused = fresh()
+    loss_f, pred_f, mask_f = fused(xg, mask_ratio=ratio)
+    loss_f.backward()
+    model = fresh()
+    latent, mask, ids = model.forward_encoder(xg, ratio)
+    pred = model.forward_decoder(latent, ids)
+    loss = model.forward_loss(xg, pred, mask)
+    assert np.array_equal(mask.cpu().to(torch.uint8).numpy(), g["mask"]) and np.array_equal(ids.cpu().to(torch.int32).numpy(), g["ids_restore"])
+    assert rel_err(sub(latent.detach().cpu(), 4096), g["latent_sub"]) < 1e-3
+    assert rel_err(sub(pred.detach().cpu(), 4096), g["pred_sub"]) < 1e-3
+    assert abs(loss.item() - g["loss"][0]) < 1e-4 * abs(g["loss"][0])
+    assert rel_err(pred.detach().cpu().numpy(), pred_f.detach().cpu().numpy()) < 1e-5
+    assert abs(loss.item() - loss_f.item()) < 1e-6 * abs(loss_f.item())
+    loss.backward()
+    torch.cuda.synchronize()
+    gf, gm = fused._grad_buffer(), model._grad_buffer()
+    scale = gf.abs().max().item()
+    assert (gf - gm).abs().max().item() <= 1e-4 * scale, (gf - gm).abs().max().item() / scale
+    for key in g.files:      # and the reference's own gradients
+        if key.startswith("grad:"):
+            got = dict(model.named_parameters())[key[5:]].grad
+            assert rel_err(sub(got.cpu(), 512), g[key]) < 2e-3, key
+    # gradient w.r.t. pred through forward_loss alone, and w.r.t. the latent through forward_decoder alone, vs oracle autograd
+    sd64 = {k: v.detach().double() for k, v in sd.items()}
+    pr = pred.detach().clone().requires_grad_(True)
+    model.forward_loss(xg, pr, mask).backward()
+    pr64 = pred.detach().cpu().double().requires_grad_(True)
+    P.forward_loss(cfg, x.double(), pr64, mask.cpu().double()).backward()
+    assert rel_err(pr.grad.cpu().numpy(), pr64.grad.numpy()) < 1e-4
+    lat = latent.detach().clone().requires_grad_(True)
+    w = torch.randn_like(pred)
+    (model.forward_decoder(lat, ids) * w).sum().backward()
+    lat64 = latent.detach().cpu().double().requires_grad_(True)
+    (P.forward_decoder(sd64, cfg, lat64, ids.cpu()) * w.cpu().double()).sum().backward()
+    assert rel_err(lat.grad.cpu().numpy(), lat64.grad.numpy()) < 2e-3
+
+
+def test_forward_encoder_on_a_decoderless_backbone():
+    """load_prithvi(no_decoder=True) yields a decoder-less model; the reference calls its forward_encoder
+    (prithvi_segmentation.py:159)."""
+    cfg, sd, x, noise, ratio = mae_inputs("small_r0_bs2")
+    g = load("prithvi_mae_small_r0_bs2.npz")
+    args = MAE_CASES["small_r0_bs2"][0]
+    model = MaskedAutoencoderViT(**args, _decoder=False)
+    model.load_state_dict({k: v for k, v in sd.items() if k in model.state_dict()})
+    model.to(DEV)
+    model.masking_noise = noise
+    with torch.no_grad():
+        latent, mask, ids = model.forward_encoder(x.to(DEV), 0.0)
+    assert np.array_equal(ids.cpu().to(torch.int32).numpy(), g["ids_restore"])
+    assert rel_err(sub(latent.cpu(), 4096), g["latent_sub"]) < 1e-3
+    with pytest.raises(RuntimeError, match="without its decoder"):
+        model.forward_decoder(latent, ids)

@@ -109,3 +109,115 @@ def test_seg_programs_match_oracle(tag, wide):
         assert rel_err(bufs[off:off + shape[0]].numpy(), newbuf["head.net.1." + nm].numpy()) < (1e-6 if wide else 1e-5)
     if cfg.frozen_backbone:
         assert plan.trainable_lo == plan.layout.params["neck.feature_pyramid_net.0.weight"][0]
+
+
+# ---- separately callable methods (forward_encoder / forward_decoder / forward_loss / random_masking) ---------------------
+def _method_bases(plan, fp, fb, inputs: dict, noise: dict, wide=True):
+    """Packed X / NOISE / DOUT / DX bases of a MethodPlan for the emulator."""
+    from s2lc_amd.plan import opdefs as D
+    from tests.plan_harness import _bytes
+
+    fd = torch.float64
+    bases = make_bases_vit(type("P", (), dict(ws_bytes=plan.ws_bytes, aux_bytes=plan.aux_bytes, out_bytes=plan.out_bytes, noise_bytes=max(plan.noise_bytes, 4),
+                                               dout_shape=(1,), const_table=plan.const_table, wpack_bytes=plan.wpack_bytes))(),
+                           fp, fb, torch.zeros(1), torch.zeros(1), wide)
+    k = 2
+    mem = __import__("oracle.ops_ref", fromlist=["Mem"])
+    for base, size in (("X", plan.x_bytes), ("DOUT", plan.dout_bytes), ("DX", plan.dx_bytes), ("NOISE", max(plan.noise_bytes, 8))):
+        bases[D.BASE[base]] = torch.zeros(k * ((size + 7) // 8 * 8) + 64, dtype=torch.uint8)
+    m = mem.Mem(bases, wide, (D.BASE["CONST"],))
+    for name, t in inputs.items():
+        r = plan.inputs[name]
+        m.view(r.ref, r.shape, r.dtype).copy_(t)
+    for name, t in noise.items():
+        r = plan.noise[name]
+        m.view(r.ref, r.shape, r.dtype).copy_(t)
+    return bases, m
+
+
+def test_method_plans_match_oracle_float64():
+    cfg, sd, x, noise, ratio = mae_inputs("small_bs2")
+    B = x.shape[0]
+    spec = _mae_spec(cfg)
+    layout = V.mae_layout(spec)
+    fp, fb = flat_from_state(layout, sd)
+    sd64 = {k: v.detach().double().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    x64, n64 = x.double(), noise.double()
+    lat64, mask64, ids64 = P.forward_encoder(sd64, cfg, x64, ratio, n64)
+    # --- forward_encoder: outputs + gradient of sum(latent * w) --------------------------------------------------------
+    plan = V.plan_mae_encoder(spec, B, ratio, True, layout)
+    bases, m = _method_bases(plan, fp, fb, {"x": x64}, {"noise": n64})
+    emulate(plan.fwd.pack(), bases, True)
+    o = plan.outputs
+    assert torch.equal(m.view(o["ids_restore"].ref, o["ids_restore"].shape, "i64"), ids64)
+    assert torch.equal(m.view(o["mask"].ref, o["mask"].shape).double(), mask64)
+    assert rel_err(m.view(o["latent"].ref, o["latent"].shape).numpy(), lat64.detach().numpy()) < 1e-6
+    w = torch.randn(lat64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    (lat64 * w).sum().backward()
+    d = plan.douts["latent"]
+    m.view(d.ref, d.shape).copy_(w)
+    emulate(plan.bwd.pack(), bases, True)
+    enc_names = {n for n in layout.params if not n.startswith(("decoder", "mask_token"))}
+    scale = max(sd64[n].grad.abs().max().item() for n in enc_names if sd64[n].grad is not None)
+    for name in enc_names:
+        off, shape = layout.params[name]
+        g = fview(bases, "GRADS", True)[off:off + int(np.prod(shape))].view(shape)
+        ref = sd64[name].grad
+        if ref is None:
+            assert g.abs().max() == 0, name
+        else:
+            assert (g - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1e-3 * scale), name
+    # --- forward_decoder: pred + gradients w.r.t. x and the decoder parameters ----------------------------------------
+    for v in sd64.values():
+        v.grad = None
+    lat_in = lat64.detach().clone().requires_grad_(True)
+    pred64 = P.forward_decoder(sd64, cfg, lat_in, ids64)
+    plan = V.plan_mae_decoder(spec, B, lat_in.shape[1], True, layout)
+    bases, m = _method_bases(plan, fp, fb, {"x": lat_in.detach(), "ids_restore": ids64}, {})
+    emulate(plan.fwd.pack(), bases, True)
+    r = plan.outputs["pred"]
+    assert rel_err(m.view(r.ref, r.shape).numpy(), pred64.detach().numpy()) < 1e-6
+    w = torch.randn(pred64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    (pred64 * w).sum().backward()
+    d = plan.douts["pred"]
+    m.view(d.ref, d.shape).copy_(w)
+    emulate(plan.bwd.pack(), bases, True)
+    gx = plan.dins["x"]
+    assert rel_err(m.view(gx.ref, gx.shape).numpy(), lat_in.grad.numpy()) < 1e-5
+    for name in layout.params:
+        if name.startswith(("decoder_blocks", "decoder_embed", "decoder_norm", "decoder_pred", "mask_token")):
+            off, shape = layout.params[name]
+            g = fview(bases, "GRADS", True)[off:off + int(np.prod(shape))].view(shape)
+            ref = sd64[name].grad
+            assert (g - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1e-9), name
+    # --- forward_loss: value + gradient w.r.t. pred ---------------------------------------------------------------------
+    pr = pred64.detach().clone().requires_grad_(True)
+    loss64 = P.forward_loss(cfg, x64, pr, mask64)
+    loss64.backward()
+    plan = V.plan_mae_loss(spec, B, True, layout)
+    bases, m = _method_bases(plan, fp, fb, {"imgs": x64, "pred": pr.detach(), "mask": mask64}, {})
+    emulate(plan.fwd.pack(), bases, True)
+    r = plan.outputs["loss"]
+    assert abs(m.view(r.ref, r.shape).item() - loss64.item()) < 1e-9 * abs(loss64.item())
+    d = plan.douts["loss"]
+    m.view(d.ref, d.shape).fill_(1.0)
+    emulate(plan.bwd.pack(), bases, True)
+    gp = plan.dins["pred"]
+    assert rel_err(m.view(gp.ref, gp.shape).numpy(), pr.grad.numpy()) < 1e-9
+    # --- random_masking: exact indices, gathered rows, scatter backward ----------------------------------------------
+    xt = torch.randn(B, cfg.num_patches, 12, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+    xm64, mk64, id64 = P.random_masking(xt, 0.5, n64)
+    plan = V.plan_random_masking(spec, B, cfg.num_patches, 12, 0.5, True, layout)
+    bases, m = _method_bases(plan, fp, fb, {"x": xt.detach()}, {"noise": n64})
+    emulate(plan.fwd.pack(), bases, True)
+    o = plan.outputs
+    assert torch.equal(m.view(o["x_masked"].ref, o["x_masked"].shape), xm64.detach())
+    assert torch.equal(m.view(o["ids_restore"].ref, o["ids_restore"].shape, "i64"), id64)
+    assert torch.equal(m.view(o["mask"].ref, o["mask"].shape).double(), mk64)
+    w = torch.randn(xm64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(4))
+    (xm64 * w).sum().backward()
+    d = plan.douts["x_masked"]
+    m.view(d.ref, d.shape).copy_(w)
+    emulate(plan.bwd.pack(), bases, True)
+    gx = plan.dins["x"]
+    assert torch.equal(m.view(gx.ref, gx.shape), xt.grad)
