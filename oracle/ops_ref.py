@@ -585,6 +585,11 @@ def _patch_cols(x, P, TUB, order):
 def op_patchify(m: Mem, o):
     B, C, T, H, W, P, TUB = (o[k] for k in ("B", "C", "T", "H", "W", "P", "TUB"))
     x = m.view(o["X"], (B, C, T, H, W))
+    if o.get("INVERSE", 0):      # columns -> images: the inverse permutation
+        cols = m.view(o["OUT"], (B, C * TUB * P * P, (T // TUB) * (H // P) * (W // P)))
+        v = cols.reshape(B, C, TUB, P, P, T // TUB, H // P, W // P).permute(0, 1, 5, 2, 6, 3, 7, 4)   # b c t tt h py w px
+        x.copy_(v.reshape(B, C, T, H, W))
+        return
     cols = _patch_cols(x, P, TUB, "conv")
     m.view(o["OUT"], tuple(cols.shape)).copy_(cols)
 
@@ -631,6 +636,15 @@ def op_transpose_cl(m: Mem, o):
     y = m.view(o["Y"], (B, Lout, ys))
     y.zero_()
     y[:, :, yo:yo + C] = x[:, :, LO:LO + Lout].permute(0, 2, 1)
+
+
+def op_upsample_zero(m: Mem, o):
+    B, C, H, W, S, HO, WO = o["B"], o["C"], o["H"], o["W"], o["S"], o["HO"], o["WO"]
+    x = m.view(o["X"], (B, C, H, W))
+    y = m.view(o["Y"], (B, C, HO, WO))
+    y.zero_()
+    hh, ww = min(H, (HO + S - 1) // S), min(W, (WO + S - 1) // S)
+    y[:, :, 0:hh * S:S, 0:ww * S:S] = x[:, :, :hh, :ww]
 
 
 def op_ids_to_dec_idx(m: Mem, o):
@@ -723,7 +737,7 @@ DISPATCH = {
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
     "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_FC_WGRAD": op_se_fc_wgrad, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
-    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "IDS_TO_DEC_IDX": op_ids_to_dec_idx, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
+    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "IDS_TO_DEC_IDX": op_ids_to_dec_idx, "UPSAMPLE_ZERO": op_upsample_zero, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
 }
 
 

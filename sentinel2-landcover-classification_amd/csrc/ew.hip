@@ -937,6 +937,32 @@ int launch_space_to_depth(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
+// ---------------- zero-insertion upsampling (data gradient of a strided dense conv; only planned for input gradients) ------
+__global__ void upsample_zero_kernel(const float* x, float* y, int H, int W, int S, int HO, int WO, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {   // over Y elements
+        const int xx = (int)(i % WO);
+        int64_t r = i / WO;
+        const int yy = (int)(r % HO);
+        r /= HO;                                                  // r = b * C + c
+        const int ys = yy / S, xs = xx / S;
+        const bool on = (yy - ys * S) == 0 && (xx - xs * S) == 0 && ys < H && xs < W;
+        y[i] = on ? x[(r * H + ys) * (int64_t)W + xs] : 0.0f;
+    }
+}
+
+int launch_upsample_zero(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_UPSAMPLE_ZERO_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_UPSAMPLE_ZERO_T_Y]);
+    CHECK_PTRS("upsample_zero", x, y);
+    const int B = op.d[S2K_UPSAMPLE_ZERO_D_B], C = op.d[S2K_UPSAMPLE_ZERO_D_C], H = op.d[S2K_UPSAMPLE_ZERO_D_H], W = op.d[S2K_UPSAMPLE_ZERO_D_W];
+    const int S = op.d[S2K_UPSAMPLE_ZERO_D_S], HO = op.d[S2K_UPSAMPLE_ZERO_D_HO], WO = op.d[S2K_UPSAMPLE_ZERO_D_WO];
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || S <= 0 || HO <= 0 || WO <= 0) { set_error("upsample_zero: bad args"); return S2K_EINVAL; }
+    const int64_t total = (int64_t)B * C * HO * WO;
+    hipLaunchKernelGGL(upsample_zero_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65536)), dim3(256), 0, c.stream, x, y, H, W, S, HO, WO, total);
+    return S2K_OK;
+}
+
 // ---------------- fused Adam (L2-coupled weight decay; torch.optim.Adam semantics) -------------------------------
 // Same operation order as torch's single-tensor Adam (the optimiser the reference configures,
 // /root/reference/src/train_segmentation.py:109-115):  g' = g + wd*p;  m = lerp(m, g', 1-b1);  v = b2*v + (1-b2)*g'*g';

@@ -443,7 +443,9 @@ __global__ void patchify_kernel(const PatchP p) {
         const int k = (int)(bk % p.PD), b = (int)(bk / p.PD);
         const int px = k % p.P, py = (k / p.P) % p.P, tt = (k / (p.P * p.P)) % p.TUB, cc = k / (p.P * p.P * p.TUB);
         const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
-        p.out[i] = p.x[((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px];
+        const int64_t xi = ((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px;
+        if (p.norm_pix) const_cast<float*>(p.x)[xi] = p.out[i];    // INVERSE (flag carried in norm_pix): columns -> images
+        else p.out[i] = p.x[xi];
     }
 }
 
@@ -452,6 +454,7 @@ int launch_patchify(const S2kOp& op, const Ctx& c) {
     if (int e = fill_patch(p, op.d)) return e;
     p.x = ref_ptr<const float>(c, op.t[S2K_PATCHIFY_T_X]);
     p.out = ref_ptr<float>(c, op.t[S2K_PATCHIFY_T_OUT]);
+    p.norm_pix = op.d[S2K_PATCHIFY_D_INVERSE];
     CHECK_PTRS("patchify", p.x, p.out);
     if (!p.x || !p.out) { set_error("patchify: missing tensor"); return S2K_EINVAL; }
     const int64_t n = (int64_t)p.B * p.PD * p.L;

@@ -61,8 +61,10 @@ class WorkspacePool:
 class UnetEngine:
     """Buffers + packed programs for one (B, H, W, training) shape of one module."""
 
-    def __init__(self, module, B: int, H: int, W: int, training: bool, device: torch.device, want_bwd: bool | None = None):
-        plan = module._make_plan(B, H, W, training, want_bwd)
+    def __init__(self, module, B: int, H: int, W: int, training: bool, device: torch.device, want_bwd: bool | None = None,
+                 want_dx: bool = False):
+        plan = module._make_plan(B, H, W, training, want_bwd, want_dx)
+        self.want_dx = want_dx
         self.plan = plan
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
@@ -88,7 +90,7 @@ class UnetEngine:
     def aux(self) -> torch.Tensor:
         return self.resident.aux
 
-    def bases(self, module, x, out, dout=None, noise=None, grads=None, space: Workspace | None = None) -> _lib.Bases:
+    def bases(self, module, x, out, dout=None, noise=None, grads=None, space: Workspace | None = None, dx=None) -> _lib.Bases:
         space = space or self.resident
         b = _lib.Bases()
         b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
@@ -102,6 +104,8 @@ class UnetEngine:
             b.set("NOISE", noise)
         if grads is not None:
             b.set("GRADS", grads)
+        if dx is not None:
+            b.set("DX", dx)
         return b
 
 
@@ -109,12 +113,12 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _engine(module, x: torch.Tensor, training: bool, want_bwd: bool) -> UnetEngine:
-    key = (tuple(x.shape), training, want_bwd, x.device)
+def _engine(module, x: torch.Tensor, training: bool, want_bwd: bool, want_dx: bool = False) -> UnetEngine:
+    key = (tuple(x.shape), training, want_bwd, want_dx, x.device)
     eng = module._engines.get(key)
     if eng is None:
         B, _, H, W = x.shape
-        eng = UnetEngine(module, B, H, W, training, x.device, want_bwd)
+        eng = UnetEngine(module, B, H, W, training, x.device, want_bwd, want_dx)
         module._engines[key] = eng
     return eng
 
@@ -150,7 +154,8 @@ class _UnetFunction(torch.autograd.Function):
         module._overwrite_next = False
         grads = module._grad_buffer() if not accumulate else module._grad_scratch()
         grads.zero_()
-        bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads, space=lease.space)
+        dx = torch.empty_like(x) if eng.want_dx else None      # gradient w.r.t. the input (planned only when x.requires_grad)
+        bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads, space=lease.space, dx=dx)
         hook = getattr(module, "_bwd_segment_hook", None)
         st = _stream(x.device)
         with torch.cuda.device(x.device):
@@ -167,7 +172,7 @@ class _UnetFunction(torch.autograd.Function):
             module._grad_buffer().add_(grads)
         if not live:
             module._publish_grads(module._no_grad_params)
-        return None, None, None, None, None
+        return dx, None, None, None, None
 
 
 def run_unet(module, x: torch.Tensor) -> torch.Tensor:
@@ -183,9 +188,10 @@ def run_unet(module, x: torch.Tensor) -> torch.Tensor:
     training = module.training
     # train() plans always carry the backward program; eval() plans only when autograd wants one (torch differentiates an
     # eval-mode module just the same: BatchNorm on its running statistics, no drop-connect)
-    differentiate = torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+    want_dx = torch.is_grad_enabled() and x.requires_grad
+    differentiate = torch.is_grad_enabled() and (want_dx or any(p.requires_grad for p in module.parameters()))
     want_bwd = training or differentiate
-    eng = _engine(module, x, training, want_bwd)
+    eng = _engine(module, x, training, want_bwd, want_dx)
     noise = None
     if training:
         noise = module.drop_connect_noise

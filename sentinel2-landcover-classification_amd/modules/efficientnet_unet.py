@@ -221,9 +221,9 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
         return CAT_SIZES[self.encoder.name] + [32 + self.config.in_channels, 32]
 
     # -- engine ---------------------------------------------------------------------------
-    def _make_plan(self, B: int, H: int, W: int, training: bool, want_bwd: bool | None = None):
+    def _make_plan(self, B: int, H: int, W: int, training: bool, want_bwd: bool | None = None, want_dx: bool = False):
         return plan_unet(self.spec, B, H, W, training, self._layout, defer_wgrads=getattr(self, "_defer_wgrads", None),
-                         want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20))
+                         want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..engine import run_unet

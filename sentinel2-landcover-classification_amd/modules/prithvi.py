@@ -169,9 +169,9 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         return x.reshape(B, t, n, n, tub, p, p, C).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, C, t * tub, n * p, n * p)
 
     # -- engine -------------------------------------------------------------------------------------------
-    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.75, want_bwd: bool | None = None):
+    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.75, want_bwd: bool | None = None, want_dx: bool = False):
         return plan_mae(self.spec, B, mask_ratio, training, self._layout,    # (no BatchNorm / dropout: training == want_bwd)
-                        bucket_floats=getattr(self, "_bucket_floats", 8 << 20))
+                        bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx)
 
     def _check_imgs(self, imgs):
         s = self.spec
@@ -200,7 +200,9 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
 
         self._check_imgs(x)
         mr = float(mask_ratio)
-        out = run_method(self, ("encoder", tuple(x.shape), mr), lambda bwd: plan_mae_encoder(self.spec, x.shape[0], mr, bwd, self._layout),
+        wdx = torch.is_grad_enabled() and x.requires_grad
+        out = run_method(self, ("encoder", tuple(x.shape), mr, wdx),
+                         lambda bwd: plan_mae_encoder(self.spec, x.shape[0], mr, bwd, self._layout, want_dx=wdx and bwd),
                          {"x": x.contiguous()}, {"noise": self.masking_noise})
         return out["latent"], out["mask"], out["ids_restore"]
 
@@ -231,7 +233,7 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         if tuple(pred.shape) != (B, s.num_patches, s.patch_dim) or tuple(mask.shape) != (B, s.num_patches):
             raise ValueError(f"expected pred [B, {s.num_patches}, {s.patch_dim}] and mask [B, {s.num_patches}]")
         out = run_method(self, ("loss", B), lambda bwd: plan_mae_loss(s, B, bwd, self._layout),
-                         {"imgs": imgs.contiguous(), "pred": pred.contiguous(), "mask": mask.contiguous()})
+                         {"imgs": imgs.contiguous(), "pred": pred.contiguous(), "mask": mask.contiguous()}, uses_params=False)
         return out["loss"].reshape(())
 
     def random_masking(self, x: torch.Tensor, mask_ratio: float):
@@ -245,5 +247,5 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
         N, L, Dm = x.shape
         mr = float(mask_ratio)
         out = run_method(self, ("masking", N, L, Dm, mr), lambda bwd: plan_random_masking(self.spec, N, L, Dm, mr, bwd, self._layout),
-                         {"x": x.contiguous()}, {"noise": self.masking_noise})
+                         {"x": x.contiguous()}, {"noise": self.masking_noise}, uses_params=False)
         return out["x_masked"], out["mask"], out["ids_restore"]

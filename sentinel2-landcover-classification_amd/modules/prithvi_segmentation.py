@@ -111,8 +111,9 @@ class PrithviSegmentationNet(FlatParamsMixin, nn.Module):
         self._unused_params = {n for n in layout.params if n in layout.frozen or (config.frozen_backbone and n.startswith("backbone."))}
         self._init_flat(layout)
 
-    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.0, want_bwd: bool | None = None):
-        return plan_seg(self.spec, B, training, self._layout, want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20))
+    def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.0, want_bwd: bool | None = None, want_dx: bool = False):
+        return plan_seg(self.spec, B, training, self._layout, want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20),
+                        want_dx=want_dx)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..vit_engine import run_vit

@@ -148,7 +148,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "TOKEN_SCATTER": (["DOUT", "IDX", "DIN", "DFILL"], [], ["B", "C", "LIN", "LOUT", "LIN_S", "LOUT_S"], []),
     # im2col of non-overlapping patches (PatchEmbed's Conv3d as a GEMM):
     #   OUT[b][((c*TUB + tt)*P + py)*P + px][(t, h, w)] = X[b][c][t*TUB + tt][h*P + py][w*P + px]
-    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB"], []),
+    # INVERSE: the same index map the other way round, X[...] = OUT[...] (every pixel belongs to exactly one patch): turns the
+    # gradient of the patch columns into the gradient w.r.t. the images
+    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB", "INVERSE"], []),
     # MAE loss (prithvi.py:333-350).  PRED is feature-major [B][PD][LP], token l in column l + L_OFF, feature order
     # (tt, py, px, c).  LOSS[0] = sum_l MASK * mean_f (PRED - target)^2 / sum MASK;  NORM_PIX: per-patch standardised target
     "MAE_LOSS_FWD": (["PRED", "IMGS", "MASK", "LOSS", "ACC"], [],
@@ -179,6 +181,10 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # Y[b][c*4 + dy*2 + dx][y][x] = X[b][c][2y + dy][2x + dx]   (H, W = the low-resolution size): the gradient of a
     # ConvTranspose2d(k2, s2) output regrouped so that its weight / data gradients are plain 1x1 contractions over 4*C channels
     "SPACE_TO_DEPTH": (["X", "Y"], [], ["B", "C", "H", "W"], []),
+    # Y[b][c][S*y][S*x] = X[b][c][y][x], every other element of Y [B][C][HO][WO] zero: the gradient of a STRIDED dense conv's output
+    # spread onto the input grid, so that its data gradient is a stride-1 conv with the flipped kernel (only planned when the
+    # caller asks for the gradient w.r.t. the network input: the stem is the only strided dense conv)
+    "UPSAMPLE_ZERO": (["X", "Y"], [], ["B", "C", "H", "W", "S", "HO", "WO"], []),
     # parameter gradients of the two SE Linears from what SE_FC_BWD left behind (DGP = its DGATE, DHP = its HPRE, HS):
     #   DW2[c][j] += sum_b DGP[b][c]*HS[b][j];  DB2 += sum_b DGP;  DW1[j][c] += sum_b DHP[b][j]*POOL[b][c];  DB1 += sum_b DHP
     "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),

@@ -305,13 +305,19 @@ def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: i
     c_off = 0
     for i, s in enumerate(srcs):
         if s.needs_grad:
-            assert stride == 1, "dgrad of strided dense conv is never needed on this path"
             g = p.grad_of(s, f"{wname}.src{i}")
+            src_dy, Hd, Wd = dY, Ho, Wo
+            if stride != 1:
+                # strided conv (the stem; only when the gradient w.r.t. the network input is asked for): spread dY onto the
+                # input grid with zeros in between, then it is the stride-1 case below
+                Hd, Wd = min(stride * Ho, s.H + k), min(stride * Wo, s.W + k)
+                src_dy = p.alloc(f"up:{wname}", (B, M, Hd, Wd))
+                p.bwd.add("UPSAMPLE_ZERO", X=dY, Y=src_dy, B=B, C=M, H=Ho, W=Wo, S=stride, HO=Hd, WO=Wd)
             # dX[b][c][y][x] = sum_{m,tap} W[m][c_off+c][flip(tap)] * dY[b][m][y+ky-(k-1-pt)][...]
             wp, MP = p.pack_weight("bwd", wname, s.C, M, T, T, Ctot * T, 1, 1, src_elem_off=c_off * T)
-            p.bwd.add("CONV", X1=dY, BNV1=None, GATE1=None, X2=None, BNV2=None,
+            p.bwd.add("CONV", X1=src_dy, BNV1=None, GATE1=None, X2=None, BNV2=None,
                       WT=wp, BIAS=None, Y=g, STATS=None,
-                      B=B, C1=M, C2=0, H=Ho, W=Wo, M=s.C, KH=k, KW=k, STRIDE=1,
+                      B=B, C1=M, C2=0, H=Hd, W=Wd, M=s.C, KH=k, KW=k, STRIDE=1,
                       PAD_T=k - 1 - pt, PAD_L=k - 1 - pl, HO=s.H, WO=s.W, PRO1=D.PRO_NONE, PRO2=D.PRO_NONE,
                       MODE=D.MODE_CONV, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(s.grad_init), YC=s.C, NREP=1)
             s.grad_init = True
@@ -792,7 +798,8 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
 
 
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
-              bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None, want_bwd: bool | None = None) -> UnetPlan:
+              bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None, want_bwd: bool | None = None,
+              want_dx: bool = False) -> UnetPlan:
     """defer_wgrads: None = the S2K_DEFER_WGRAD default (on); False keeps the decoder's weight gradients where the tape emits
     them, so that gradient buckets become final progressively (what the data-parallel reducer wants, see ddp.py)."""
     if H % 32 or W % 32:
@@ -801,8 +808,9 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
     p = _P(spec, layout, B, H, W, training, want_bwd)
     p.defer_wgrads = defer_wgrads
     eps, mom = spec.bn_eps, spec.bn_momentum
+    # want_dx: the caller's input requires a gradient (torch semantics: x.requires_grad) — it lands in the DX base
     x_in = Act(TRef(D.BASE["X"], 0, (B, spec.in_channels, H, W), "f32", "x"), spec.in_channels, H, W,
-               needs_grad=False)
+               needs_grad=bool(want_dx), grad=TRef(D.BASE["DX"], 0, (B, spec.in_channels, H, W), "f32", "dx") if want_dx else None)
 
     # encoder --------------------------------------------------------------------------
     cur = conv_bn(p, "encoder.stem.0.weight", "encoder.stem.1", [x_in], spec.stem_out, 3, 2, True,

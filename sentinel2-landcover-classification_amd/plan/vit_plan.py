@@ -95,6 +95,9 @@ class VitPlan:
     wpack_bytes: int = 0
     trainable_lo: int = 0    # flat floats [trainable_lo, n_params) receive gradients (frozen backbone sits in front)
     x_shape: tuple = ()
+    douts: dict | None = None   # several differentiable outputs: name -> TRef in a packed DOUT buffer (None: `dout_shape` only)
+    dout_bytes: int = 0
+    want_dx: bool = False       # the backward program also writes the gradient w.r.t. the images into the DX base
 
 
 # ---- layouts (reference registration order) ---------------------------------------------
@@ -308,8 +311,9 @@ def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int
     return latent, N, rec
 
 
-def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef):
-    """g_latent: gradient of the normalised encoder output [B][Dm][NS] (consumed; zero in the padding columns)."""
+def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef, dx: TRef | None = None):
+    """g_latent: gradient of the normalised encoder output [B][Dm][NS] (consumed; zero in the padding columns).
+    dx: where to put the gradient w.r.t. the images (DX base) when the caller's input requires one."""
     p, B = v.p, v.p.B
     prefix, N, NS, Dm, Lp, Kp = rec["prefix"], rec["N"], rec["NS"], rec["Dm"], rec["Lp"], rec["Kp"]
     g = p.alloc("g:enc:" + prefix, (B, Dm, NS))
@@ -317,9 +321,14 @@ def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef):
     for r in reversed(rec["blocks"]):
         v.block_bwd(r, g)
     g_pe = p.alloc("g:pe:" + prefix, (B, Dm, Lp))
-    p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token"), B=B, C=Dm, LIN=Lp, LOUT=N,
+    p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token") if v.trainable(prefix + "cls_token") else None,
+              B=B, C=Dm, LIN=Lp, LOUT=N,
               LIN_S=Lp, LOUT_S=NS)
-    v.linear_bwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", rec["cols"], g_pe, Kp, Dm, Lp)
+    g_cols = p.alloc("g:cols:" + prefix, (B, Kp, Lp)) if dx is not None else None
+    v.linear_bwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", rec["cols"], g_pe, Kp, Dm, Lp, dx=g_cols)
+    if dx is not None:     # patches do not overlap: the column gradient is a permutation of the image gradient
+        p.bwd.add("PATCHIFY", X=dx, OUT=g_cols, B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size,
+                  TUB=s.tubelet_size, INVERSE=1)
 
 
 def _out(outs: dict, cursor: list, name: str, shape: tuple, dtype: str = "f32") -> TRef:
@@ -331,7 +340,7 @@ def _out(outs: dict, cursor: list, name: str, shape: tuple, dtype: str = "f32") 
 
 
 def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: ParamLayout | None = None,
-             bucket_floats: int = 8 << 20) -> VitPlan:
+             bucket_floats: int = 8 << 20, want_dx: bool = False) -> VitPlan:
     """MaskedAutoencoderViT.forward(imgs, mask_ratio) -> (loss, pred, mask) (+ latent, ids_restore for forward_encoder)."""
     assert s.decoder
     layout = layout or mae_layout(s)
@@ -372,10 +381,19 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
                NORM_PIX=int(s.norm_pix_loss))
     p.fwd.add("MAE_LOSS_FWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], LOSS=outs["loss"], ACC=acc, **geo)
 
+    # upstream gradients: the loss (what the reference's trainer uses) and `pred` (torch lets a caller differentiate through
+    # it too); both arrive in one packed DOUT buffer, an unused one as zeros
+    d_loss = TRef(D.BASE["DOUT"], 0, (1,), "f32", "dloss")
+    d_pred = TRef(D.BASE["DOUT"], 256, (B, Lp, PD), "f32", "dpred")
+    x_dx = TRef(D.BASE["DX"], 0, x_shape, "f32", "dx") if want_dx else None
+
     def backward():
-        gout = TRef(D.BASE["DOUT"], 0, (1,), "f32", "dloss")
+        gout = d_loss
         g_pred = p.alloc("g:pred", (B, PD, NDS))
         p.bwd.add("MAE_LOSS_BWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], ACC=acc, GOUT=gout, DPRED=g_pred, **geo)
+        g_user = p.alloc("g:pred_user", (B, PD, NDS))
+        p.bwd.add("TRANSPOSE_CL", X=d_pred, Y=g_user, B=B, C=Lp, L=PD, L_OFF=0, LOUT=PD, YS=NDS, Y_OFF=1)
+        p.bwd.add("AXPY", X=g_user, Y=g_pred, COUNT=B * PD * NDS)
         g_yn = p.alloc("g:yn", (B, Dd, NDS))
         v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, NDS, dx=g_yn)
         g = p.alloc("g:dec", (B, Dd, NDS))
@@ -387,16 +405,17 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
                   LIN_S=NS, LOUT_S=NDS)
         g_lat = p.alloc("g:latent", (B, Dm, NS))
         v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, NS, dx=g_lat)
-        _encoder_bwd(v, s, erec, g_lat)
+        _encoder_bwd(v, s, erec, g_lat, x_dx)
 
     p.tape.append(backward)
     segments, bwd = finish_plan(p, layout, training, bucket_floats)
     return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
-                   {"noise": noise}, B * Lp * 4, (1,), p.tensors, p.wpack.mark(), 0, x_shape)
+                   {"noise": noise}, B * Lp * 4, (1,), p.tensors, p.wpack.mark(), 0, x_shape,
+                   douts={"loss": d_loss, "pred": d_pred}, dout_bytes=256 + B * Lp * PD * 4, want_dx=want_dx)
 
 
 def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20,
-             want_bwd: bool | None = None) -> VitPlan:
+             want_bwd: bool | None = None, want_dx: bool = False) -> VitPlan:
     """PrithviSegmentationNet.forward (prithvi_segmentation.py:156-162)."""
     m = s.mae
     assert not m.decoder
@@ -421,13 +440,15 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
     _out(outs, cur, "mask", (B, Lp))
     _out(outs, cur, "ids_restore", (B, Lp), "i64")
     latent, N, erec = _encoder(v, m, "backbone.", x_img, noise, Lp, outs, not frozen)   # mask_ratio 0: a pure shuffle
+    x_dx = TRef(D.BASE["DX"], 0, x_shape, "f32", "dx") if want_dx else None
+    need_enc_bwd = p.want_bwd and (not frozen or want_dx)     # (a frozen backbone still passes the gradient through to the input)
     # neck (:66-72): drop cls, tokens -> [B][E][g][g]
     drop_idx = p.const_table([[j + 1 for j in range(Lp)] for _ in range(B)], Lp)
     t0 = p.alloc("neck_in", (B, Dm, Lp))
     NS = erec["NS"]
     p.fwd.add("TOKEN_GATHER", IN=latent, IDX=drop_idx, FILL=None, POS=None, OUT=t0, B=B, C=Dm, LIN=N, LOUT=Lp, POS_BY_SRC=0, POS_OFF=0,
               LIN_S=NS, LOUT_S=Lp)
-    a0 = Act(t0, Dm, g, g, needs_grad=(p.want_bwd and not frozen))
+    a0 = Act(t0, Dm, g, g, needs_grad=need_enc_bwd)
     nk = "neck.feature_pyramid_net."
 
     def norm2d_gelu(prefix: str, src: Act) -> Act:
@@ -451,11 +472,11 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
         return out
 
     def encoder_tail_backward():
-        if not (p.want_bwd and not frozen):
+        if not need_enc_bwd:
             return
         g_lat = p.alloc("g:latent", (B, Dm, NS))
         p.bwd.add("TOKEN_SCATTER", DOUT=a0.grad, IDX=drop_idx, DIN=g_lat, DFILL=None, B=B, C=Dm, LIN=N, LOUT=Lp, LIN_S=NS, LOUT_S=Lp)
-        _encoder_bwd(v, m, erec, g_lat)
+        _encoder_bwd(v, m, erec, g_lat, x_dx)
 
     p.tape.append(encoder_tail_backward)
     a = conv_transpose(p, nk + "0.weight", nk + "0.bias", a0, E)
@@ -496,7 +517,8 @@ def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = No
         lo = min(off for name, (off, _) in layout.params.items() if not name.startswith("backbone."))
     noise_bytes = drop_off + B * s.fcn_out_channels * 4
     return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
-                   {"noise": noise, "drop_u": drop_u}, noise_bytes, (B, s.num_classes, Hh, Hh), p.tensors, p.wpack.mark(), lo, x_shape)
+                   {"noise": noise, "drop_u": drop_u}, noise_bytes, (B, s.num_classes, Hh, Hh), p.tensors, p.wpack.mark(), lo, x_shape,
+                   want_dx=want_dx)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -570,12 +592,13 @@ def plan_mae_encoder(s: MaeSpec, B: int, mask_ratio: float, want_bwd: bool, layo
     NS = erec["NS"]
     p.fwd.add("TRANSPOSE_CL", X=latent, Y=out_lat, B=B, C=Dm, L=NS, L_OFF=0, LOUT=N)
     d_lat = douts.add("latent", (B, N, Dm))
+    d_x = dins.add("x", tuple(x_img.shape)) if want_dx else None
 
     def backward():
         g_lat = p.alloc("g:latent", (B, Dm, NS))
         # token-major gradient [B][N][Dm] -> feature-major rows of NS floats with zero padding columns
         p.bwd.add("TRANSPOSE_CL", X=d_lat, Y=g_lat, B=B, C=N, L=Dm, L_OFF=0, LOUT=Dm, YS=NS, Y_OFF=0)
-        _encoder_bwd(v, s, erec, g_lat)
+        _encoder_bwd(v, s, erec, g_lat, d_x)
 
     p.tape.append(backward)
     return _method_plan(p, s, B, want_bwd, layout, xin, outs, nz, douts, dins, bucket_floats)

@@ -13,8 +13,9 @@ _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
 
 
 class VitEngine:
-    def __init__(self, module, B: int, training: bool, mask_ratio: float, device: torch.device, want_bwd: bool | None = None):
-        plan = module._make_plan(B, training, mask_ratio, want_bwd)
+    def __init__(self, module, B: int, training: bool, mask_ratio: float, device: torch.device, want_bwd: bool | None = None,
+                 want_dx: bool = False):
+        plan = module._make_plan(B, training, mask_ratio, want_bwd, want_dx)
         self.plan = plan
         self.fwd = plan.fwd.pack()
         self.bwd = plan.bwd.pack() if plan.bwd is not None else None
@@ -36,7 +37,7 @@ class VitEngine:
     def aux(self) -> torch.Tensor:
         return self.resident.aux
 
-    def bases(self, module, x, out, noise, dout=None, grads=None, space: Workspace | None = None) -> _lib.Bases:
+    def bases(self, module, x, out, noise, dout=None, grads=None, space: Workspace | None = None, dx=None) -> _lib.Bases:
         space = space or self.resident
         b = _lib.Bases()
         b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
@@ -48,6 +49,8 @@ class VitEngine:
             b.set("DOUT", dout)
         if grads is not None:
             b.set("GRADS", grads)
+        if dx is not None:
+            b.set("DX", dx)
         return b
 
     def views(self, out: torch.Tensor) -> dict:
@@ -75,7 +78,8 @@ class _VitFunction(torch.autograd.Function):
         ctx.module, ctx.eng, ctx.noise, ctx.names, ctx.out, ctx.lease = module, eng, noise, names, out, lease
         ctx.save_for_backward(x)
         outs = tuple(v[n] for n in names)
-        ctx.mark_non_differentiable(*outs[1:])
+        diff = set(eng.plan.douts) if eng.plan.douts else {primary}
+        ctx.mark_non_differentiable(*[o for n, o in zip(names, outs) if n not in diff])
         return outs
 
     @staticmethod
@@ -84,16 +88,29 @@ class _VitFunction(torch.autograd.Function):
         if lease.space is None:
             raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
         (x,) = ctx.saved_tensors
-        dout = dprimary.contiguous().reshape(eng.plan.dout_shape).to(torch.float32)
+        plan = eng.plan
         scale = getattr(module, "_grad_scale", 1.0)
-        if scale != 1.0:
-            dout = dout * scale
+        if plan.douts:        # several differentiable outputs: one packed buffer, absent gradients as zeros
+            buf = torch.zeros(plan.dout_bytes + 256, dtype=torch.uint8, device=x.device)
+            for name, g in zip(ctx.names, (dprimary,) + tuple(unused)):
+                if g is not None and name in plan.douts:
+                    t = plan.douts[name]
+                    dst = buf[t.off:t.off + t.nbytes].view(torch.float32).view(t.shape)
+                    dst.copy_(g.reshape(t.shape))
+                    if scale != 1.0:
+                        dst.mul_(scale)
+            dout = buf
+        else:
+            dout = dprimary.contiguous().reshape(plan.dout_shape).to(torch.float32)
+            if scale != 1.0:
+                dout = dout * scale
         live = module._grads_live()
         accumulate = live and not getattr(module, "_overwrite_next", False)
         module._overwrite_next = False
         grads = module._grad_buffer() if not accumulate else module._grad_scratch()
         grads.zero_()
-        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads, space=lease.space)
+        dx = torch.empty_like(x) if plan.want_dx else None
+        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads, space=lease.space, dx=dx)
         hook = getattr(module, "_bwd_segment_hook", None)
         st = _stream(x.device)
         with torch.cuda.device(x.device):
@@ -111,7 +128,7 @@ class _VitFunction(torch.autograd.Function):
             module._grad_buffer().add_(grads)
         if not live:
             module._publish_grads(module._no_grad_params)
-        return None, None, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = None) -> dict:
@@ -131,14 +148,15 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
     # the segmentation head has BatchNorm / Dropout2d: its plan follows module.training (train() plans always carry the
     # backward program, eval() plans only when autograd wants one); the MAE has neither, so its plan carries a backward
     # program iff a gradient is wanted
-    want_grad = torch.is_grad_enabled() and trainable
+    want_dx = torch.is_grad_enabled() and x.requires_grad
+    want_grad = torch.is_grad_enabled() and (trainable or want_dx)
     training = module.training if is_seg else want_grad
     want_bwd = (training or want_grad) if is_seg else want_grad
     mr = 0.0 if is_seg else float(mask_ratio)
-    key = (tuple(x.shape), training, want_bwd, mr, x.device)
+    key = (tuple(x.shape), training, want_bwd, want_dx, mr, x.device)
     eng = module._engines.get(key)
     if eng is None:
-        eng = VitEngine(module, B, training, mr, x.device, want_bwd)
+        eng = VitEngine(module, B, training, mr, x.device, want_bwd, want_dx)
         module._engines[key] = eng
     plan = eng.plan
     noise = torch.empty(max(plan.noise_bytes // 4, 1), dtype=torch.float32, device=x.device)
@@ -253,7 +271,7 @@ class _MethodFunction(torch.autograd.Function):
         return (None, None, None, None, None) + grads_in
 
 
-def run_method(module, key, make_plan, inputs: dict, injected: dict | None = None) -> dict:
+def run_method(module, key, make_plan, inputs: dict, injected: dict | None = None, uses_params: bool = True) -> dict:
     """Runs one separately callable method.  `key`: cache key of the plan (shapes, ratios); `make_plan(want_bwd)` builds the
     MethodPlan; `inputs`: name -> tensor (device tensors; moved / cast as the plan asks).  Returns {output name: tensor}."""
     dev = module._flat_params.device
@@ -265,7 +283,7 @@ def run_method(module, key, make_plan, inputs: dict, injected: dict | None = Non
         if not t.is_cuda:
             raise RuntimeError(f"{name}: the HIP engine takes GPU tensors")
     needs = torch.is_grad_enabled() and (any(t.requires_grad for t in inputs.values() if t.dtype.is_floating_point)
-                                         or any(p.requires_grad for p in module.parameters()))
+                                         or (uses_params and any(p.requires_grad for p in module.parameters())))
     ckey = ("method",) + tuple(key) + (needs, dev)
     eng = module._engines.get(ckey)
     if eng is None:

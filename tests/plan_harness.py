@@ -33,6 +33,7 @@ def make_bases(plan, flat_params, flat_bufs, x, noise, n_out, wide: bool = False
         D.BASE["NOISE"]: _bytes(noise.clone().to(fd)),
         D.BASE["CONST"]: _bytes(torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32)),
         D.BASE["WPACK"]: torch.zeros(k * pad8(plan.wpack_bytes) + 64, dtype=torch.uint8),
+        D.BASE["DX"]: _bytes(torch.full(tuple(x.shape), float("nan"), dtype=fd)),
     }
     # poison the workspace so that reads of never-written memory show up as NaN
     bases[D.BASE["WS"]][: k * pad8(plan.ws_bytes)].view(fd).fill_(float("nan"))
@@ -64,7 +65,9 @@ def make_bases_vit(plan, flat_params, flat_bufs, x, noise_f32: torch.Tensor, wid
         D.BASE["BUFS"]: _bytes(flat_bufs.detach().to(fd).clone()),
         D.BASE["X"]: _bytes(x.to(fd).clone()),
         D.BASE["OUT"]: torch.zeros(k * pad8(plan.out_bytes) + 64, dtype=torch.uint8),
-        D.BASE["DOUT"]: _bytes(torch.zeros(n_dout, dtype=fd)),
+        D.BASE["DOUT"]: (torch.zeros(k * pad8(plan.dout_bytes) + 64, dtype=torch.uint8) if getattr(plan, "dout_bytes", 0)
+                         else _bytes(torch.zeros(n_dout, dtype=fd))),
+        D.BASE["DX"]: torch.zeros(k * pad8(x.numel() * 4) + 64, dtype=torch.uint8),
         D.BASE["NOISE"]: _bytes(nz),
         D.BASE["CONST"]: _bytes(torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32)),
         D.BASE["WPACK"]: torch.zeros(k * pad8(plan.wpack_bytes) + 64, dtype=torch.uint8),

@@ -207,3 +207,35 @@ def test_eval_mode_backward_program_matches_oracle_autograd():
         assert (g - r).abs().max().item() <= 1e-7 * max(r.abs().max().item(), 1e-6 * scale), name
         n += 1
     assert n > 200
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_input_gradient_program_matches_oracle_autograd(train):
+    """want_dx plans (x.requires_grad in torch terms): the gradient w.r.t. the network input — through the stride-2 stem
+    (zero-insertion + flipped stride-1 conv) and through the raw-input concat of input_double_conv — float64, exact."""
+    ncls, B, H, C = 4, 2, 64, 5
+    model, net, sd, x, y, noise = _setup("b0", C, H, B, ncls, seed=29, dcr=0.25)
+    plan = plan_unet_for(model, B, H, train, want_dx=True)
+    kinds = [k for k, _ in plan.bwd.ops]
+    assert kinds.count("UPSAMPLE_ZERO") == 1
+    bases = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H, True)
+    emulate(plan.fwd.pack(), bases, True)
+    sdd = {}
+    for k, v in sd.items():
+        sdd[k] = v.detach().double() if v.dtype.is_floating_point else v
+    xg = x.double().requires_grad_(True)
+    logits = R.unet_forward(sdd, net, xg, training=train, dc_noise=noise.double() if train else None, new_buffers={})
+    loss = losses_ref.focal(logits, y, torch.ones(ncls, dtype=torch.float64), 2.0, 0.0, ignore_index=0)
+    (dlogits,) = torch.autograd.grad(loss, logits, retain_graph=True)
+    loss.backward()
+    fview(bases, "DOUT", True).copy_(dlogits.reshape(-1))
+    emulate(plan.bwd.pack(), bases, True)
+    dx = fview(bases, "DX", True).view(B, C, H, H)
+    assert torch.isfinite(dx).all()
+    assert (dx - xg.grad).abs().max().item() <= 1e-7 * xg.grad.abs().max().item()
+
+
+def plan_unet_for(model, B, H, train, want_dx=False):
+    from s2lc_amd.plan.unet_plan import plan_unet
+
+    return plan_unet(model.spec, B, H, H, train, model._layout, want_bwd=True, want_dx=want_dx)

@@ -158,6 +158,7 @@ def test_random_masking_matches_reference_fixture_exactly():
         x = detgen.normal(f"rm.{tag}.x", (N, L, Dm), seed=5)
         model.masking_noise = detgen.uniform(f"rm.{tag}.n", (N, L), 0.0, 1.0, seed=5)
         xm, mask, ids = model.random_masking(x.to(DEV), r)
+        assert not xm.requires_grad            # (no parameters involved: differentiable only through x)
         assert np.array_equal(xm.cpu().numpy(), g[f"rm:{tag}:xm"]), tag
         assert np.array_equal(mask.cpu().to(torch.uint8).numpy(), g[f"rm:{tag}:mask"]), tag
         assert np.array_equal(ids.cpu().to(torch.int32).numpy(), g[f"rm:{tag}:ids"]), tag
