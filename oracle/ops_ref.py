@@ -585,13 +585,25 @@ def _patch_cols(x, P, TUB, order):
 def op_patchify(m: Mem, o):
     B, C, T, H, W, P, TUB = (o[k] for k in ("B", "C", "T", "H", "W", "P", "TUB"))
     x = m.view(o["X"], (B, C, T, H, W))
-    if o.get("INVERSE", 0):      # columns -> images: the inverse permutation
-        cols = m.view(o["OUT"], (B, C * TUB * P * P, (T // TUB) * (H // P) * (W // P)))
-        v = cols.reshape(B, C, TUB, P, P, T // TUB, H // P, W // P).permute(0, 1, 5, 2, 6, 3, 7, 4)   # b c t tt h py w px
-        x.copy_(v.reshape(B, C, T, H, W))
+    inv, order = o.get("INVERSE", 0), "mae" if o.get("ORDER", 0) else "conv"
+    L = (T // TUB) * (H // P) * (W // P)
+    ls = o.get("LS", 0) or L
+    lo = o.get("L_OFF", 0)
+    out = m.view(o["OUT"], (B, C * TUB * P * P, ls))[:, :, lo:lo + L]
+    if inv == 0:
+        out.copy_(_patch_cols(x, P, TUB, order))
         return
-    cols = _patch_cols(x, P, TUB, "conv")
-    m.view(o["OUT"], tuple(cols.shape)).copy_(cols)
+    if order == "conv":      # rows (c, tt, py, px)
+        v = out.reshape(B, C, TUB, P, P, T // TUB, H // P, W // P).permute(0, 1, 5, 2, 6, 3, 7, 4)      # b c t tt h py w px
+    else:                    # rows (tt, py, px, c)
+        v = out.reshape(B, TUB, P, P, C, T // TUB, H // P, W // P).permute(0, 4, 5, 1, 6, 2, 7, 3)
+    v = v.reshape(B, C, T, H, W)
+    if inv == 1:
+        x.copy_(v)
+    elif inv == 2:
+        x.copy_(-v)
+    else:
+        x.add_(v)
 
 
 def _mae_loss_terms(m: Mem, o):

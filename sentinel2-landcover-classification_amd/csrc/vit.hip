@@ -433,19 +433,26 @@ static int fill_patch(PatchP& p, const int32_t* d) {
     return S2K_OK;
 }
 
-// OUT[b][((c*TUB + tt)*P + py)*P + px][l] ; lanes along l
-__global__ void patchify_kernel(const PatchP p) {
+// OUT[b][((c*TUB + tt)*P + py)*P + px][l] ; lanes along l.  inverse: 0 OUT = f(X), 1 X = OUT, 2 X = -OUT, 3 X += OUT;
+// order 1: rows in the MAE target's order (tt, py, px, c); OUT rows have stride ls, patch l sits in column l + l_off
+__global__ void patchify_kernel(const PatchP p, int inverse, int order, int ls, int l_off) {
     const int64_t n = (int64_t)p.B * p.PD * p.L;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float* xw = const_cast<float*>(p.x);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int l = (int)(i % p.L);
         const int64_t bk = i / p.L;
         const int k = (int)(bk % p.PD), b = (int)(bk / p.PD);
-        const int px = k % p.P, py = (k / p.P) % p.P, tt = (k / (p.P * p.P)) % p.TUB, cc = k / (p.P * p.P * p.TUB);
+        int px, py, tt, cc;
+        if (order == 0) { px = k % p.P; py = (k / p.P) % p.P; tt = (k / (p.P * p.P)) % p.TUB; cc = k / (p.P * p.P * p.TUB); }
+        else { cc = k % p.C; px = (k / p.C) % p.P; py = (k / (p.C * p.P)) % p.P; tt = k / (p.C * p.P * p.P); }
         const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
         const int64_t xi = ((((int64_t)b * p.C + cc) * p.T + t * p.TUB + tt) * p.H + h * p.P + py) * p.W + w * p.P + px;
-        if (p.norm_pix) const_cast<float*>(p.x)[xi] = p.out[i];    // INVERSE (flag carried in norm_pix): columns -> images
-        else p.out[i] = p.x[xi];
+        const int64_t oi = ((int64_t)b * p.PD + k) * ls + l + l_off;
+        if (inverse == 0) p.out[oi] = p.x[xi];
+        else if (inverse == 1) xw[xi] = p.out[oi];
+        else if (inverse == 2) xw[xi] = -p.out[oi];
+        else xw[xi] += p.out[oi];
     }
 }
 
@@ -454,11 +461,13 @@ int launch_patchify(const S2kOp& op, const Ctx& c) {
     if (int e = fill_patch(p, op.d)) return e;
     p.x = ref_ptr<const float>(c, op.t[S2K_PATCHIFY_T_X]);
     p.out = ref_ptr<float>(c, op.t[S2K_PATCHIFY_T_OUT]);
-    p.norm_pix = op.d[S2K_PATCHIFY_D_INVERSE];
     CHECK_PTRS("patchify", p.x, p.out);
     if (!p.x || !p.out) { set_error("patchify: missing tensor"); return S2K_EINVAL; }
+    const int inverse = op.d[S2K_PATCHIFY_D_INVERSE], order = op.d[S2K_PATCHIFY_D_ORDER], l_off = op.d[S2K_PATCHIFY_D_L_OFF];
+    const int ls = op.d[S2K_PATCHIFY_D_LS] > 0 ? op.d[S2K_PATCHIFY_D_LS] : p.L;
+    if (inverse < 0 || inverse > 3 || order < 0 || order > 1 || l_off < 0 || ls < p.L + l_off) { set_error("patchify: bad mode / stride"); return S2K_EINVAL; }
     const int64_t n = (int64_t)p.B * p.PD * p.L;
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 16384)), dim3(256), 0, c.stream, p);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 16384)), dim3(256), 0, c.stream, p, inverse, order, ls, l_off);
     return S2K_OK;
 }
 

@@ -150,7 +150,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   OUT[b][((c*TUB + tt)*P + py)*P + px][(t, h, w)] = X[b][c][t*TUB + tt][h*P + py][w*P + px]
     # INVERSE: the same index map the other way round, X[...] = OUT[...] (every pixel belongs to exactly one patch): turns the
     # gradient of the patch columns into the gradient w.r.t. the images
-    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB", "INVERSE"], []),
+    # INVERSE 2: X = -OUT, 3: X += OUT.  ORDER 1: row index (tt, py, px, c) — the MAE loss target's feature order (prithvi.py:236-245)
+    # instead of the Conv3d weight's (c, tt, py, px).  LS / L_OFF: row stride (0 = L) and first column of OUT's patches.
+    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB", "INVERSE", "ORDER", "LS", "L_OFF"], []),
     # MAE loss (prithvi.py:333-350).  PRED is feature-major [B][PD][LP], token l in column l + L_OFF, feature order
     # (tt, py, px, c).  LOSS[0] = sum_l MASK * mean_f (PRED - target)^2 / sum MASK;  NORM_PIX: per-patch standardised target
     "MAE_LOSS_FWD": (["PRED", "IMGS", "MASK", "LOSS", "ACC"], [],

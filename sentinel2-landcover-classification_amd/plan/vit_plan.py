@@ -311,7 +311,7 @@ def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int
     return latent, N, rec
 
 
-def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef, dx: TRef | None = None):
+def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef, dx: TRef | None = None, dx_accum: bool = False):
     """g_latent: gradient of the normalised encoder output [B][Dm][NS] (consumed; zero in the padding columns).
     dx: where to put the gradient w.r.t. the images (DX base) when the caller's input requires one."""
     p, B = v.p, v.p.B
@@ -328,7 +328,7 @@ def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef, dx: TRef | None =
     v.linear_bwd(prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias", rec["cols"], g_pe, Kp, Dm, Lp, dx=g_cols)
     if dx is not None:     # patches do not overlap: the column gradient is a permutation of the image gradient
         p.bwd.add("PATCHIFY", X=dx, OUT=g_cols, B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size,
-                  TUB=s.tubelet_size, INVERSE=1)
+                  TUB=s.tubelet_size, INVERSE=3 if dx_accum else 1)
 
 
 def _out(outs: dict, cursor: list, name: str, shape: tuple, dtype: str = "f32") -> TRef:
@@ -391,6 +391,13 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
         gout = d_loss
         g_pred = p.alloc("g:pred", (B, PD, NDS))
         p.bwd.add("MAE_LOSS_BWD", PRED=pred_fm, IMGS=x_img, MASK=outs["mask"], ACC=acc, GOUT=gout, DPRED=g_pred, **geo)
+        if x_dx is not None:
+            # the loss also depends on the images through its TARGET (patchify(imgs), prithvi.py:340): d loss / d target = -d loss /
+            # d pred; written first (it covers every pixel), the encoder's part is added at the end of the backward
+            if s.norm_pix_loss:
+                raise NotImplementedError("gradient w.r.t. the images through the per-patch normalised target (norm_pix_loss)")
+            p.bwd.add("PATCHIFY", X=x_dx, OUT=g_pred, B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size,
+                      TUB=s.tubelet_size, INVERSE=2, ORDER=1, LS=NDS, L_OFF=1)
         g_user = p.alloc("g:pred_user", (B, PD, NDS))
         p.bwd.add("TRANSPOSE_CL", X=d_pred, Y=g_user, B=B, C=Lp, L=PD, L_OFF=0, LOUT=PD, YS=NDS, Y_OFF=1)
         p.bwd.add("AXPY", X=g_user, Y=g_pred, COUNT=B * PD * NDS)
@@ -405,7 +412,7 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
                   LIN_S=NS, LOUT_S=NDS)
         g_lat = p.alloc("g:latent", (B, Dm, NS))
         v.linear_bwd("decoder_embed.weight", "decoder_embed.bias", latent, g_dx, Dm, Dd, NS, dx=g_lat)
-        _encoder_bwd(v, s, erec, g_lat, x_dx)
+        _encoder_bwd(v, s, erec, g_lat, x_dx, dx_accum=True)
 
     p.tape.append(backward)
     segments, bwd = finish_plan(p, layout, training, bucket_floats)

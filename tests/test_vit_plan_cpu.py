@@ -221,3 +221,30 @@ def test_method_plans_match_oracle_float64():
     emulate(plan.bwd.pack(), bases, True)
     gx = plan.dins["x"]
     assert torch.equal(m.view(gx.ref, gx.shape), xt.grad)
+
+
+def test_mae_input_gradient_program_float64():
+    """want_dx: d loss / d imgs = the encoder path (inverse patchify of the patch-embed data gradient) + the loss TARGET path
+    (the reference's forward_loss differentiates patchify(imgs) too); plus an upstream gradient on pred."""
+    cfg, sd, x, noise, ratio = mae_inputs("small_t3_bs2")
+    B = x.shape[0]
+    spec = _mae_spec(cfg)
+    plan = V.plan_mae(spec, B, ratio, True, want_dx=True)
+    fp, fb = flat_from_state(plan.layout, sd)
+    bases = make_bases_vit(plan, fp, fb, x, noise, True)
+    emulate(plan.fwd.pack(), bases, True)
+    sd64 = {k: v.detach().double().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    loss64, pred64, _ = P.mae_forward(sd64, cfg, x64, ratio, noise.double())
+    w = torch.randn(pred64.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    (loss64 + 0.1 * (pred64 * w).sum()).backward()
+    from oracle import ops_ref
+    from s2lc_amd.plan import opdefs as D
+
+    m = ops_ref.Mem(bases, True, (D.BASE["CONST"],))
+    m.view(plan.douts["loss"].ref, (1,)).fill_(1.0)
+    m.view(plan.douts["pred"].ref, plan.douts["pred"].shape).copy_(0.1 * w)
+    emulate(plan.bwd.pack(), bases, True)
+    dx = m.view((D.BASE["DX"] << 56), tuple(x.shape))
+    assert (dx - x64.grad).abs().max().item() <= 1e-6 * x64.grad.abs().max().item()
+    _check_grads(plan, fview(bases, "GRADS", True), sd64, 1e-5)
