@@ -470,13 +470,18 @@ def op_chan_ln_bwd(m: Mem, o):
 def op_act_bwd(m: Mem, o):
     n = o["COUNT"]
     g = m.view(o["G"], (n,))
-    g.mul_(_act_grad(m.view(o["X"], (n,)), o["ACT"]))
+    x = m.view(o["X"], (n,))
+    g.mul_(x if o["ACT"] == 5 else _act_grad(x, o["ACT"]))
 
 
 def op_act_fwd(m: Mem, o):
     n = o["COUNT"]
     x = m.view(o["X"], (n,))
     act = o["ACT"]
+    if o.get("BNV", -1) >= 0:
+        C, HW = o["C"], o["HW"]
+        bnv = m.view(o["BNV"], (4, C))
+        x = (x.view(-1, C, HW) * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)).reshape(-1)
     y = F.gelu(x) if act == 4 else (F.silu(x) if act == 2 else (F.relu(x) if act == 3 else x))
     m.view(o["Y"], (n,)).copy_(y)
 

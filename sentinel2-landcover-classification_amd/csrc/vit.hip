@@ -230,7 +230,7 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
 // ---------------- G *= act'(X) ---------------------------------------------------------------------------
 __global__ void act_bwd_kernel(float* g, const float* x, int64_t n, int act) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= act_grad(x[i], act);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= (act == 5 ? x[i] : act_grad(x[i], act));
 }
 
 int launch_act_bwd(const S2kOp& op, const Ctx& c) {
@@ -239,25 +239,36 @@ int launch_act_bwd(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("act_bwd", g, x);
     const int64_t n = op.n[S2K_ACT_BWD_N_COUNT];
     const int act = op.d[S2K_ACT_BWD_D_ACT];
-    if (!g || !x || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU)) { set_error("act_bwd: bad args"); return S2K_EINVAL; }
+    if (!g || !x || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU && act != 5)) { set_error("act_bwd: bad args"); return S2K_EINVAL; }
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, g, x, n, act);
     return S2K_OK;
 }
 
 // ---------------- Y = act(X) ------------------------------------------------------------------------------
-__global__ void act_fwd_kernel(const float* x, float* y, int64_t n, int act) {
+__global__ void act_fwd_kernel(const float* x, float* y, int64_t n, int act, const float* bnv, int C, int HW) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = apply_pro(x[i], act, 1.0f, 0.0f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float sc = 1.0f, sh = 0.0f;
+        if (bnv) {
+            const int c = (int)((i / HW) % C);
+            sc = bnv[c];
+            sh = bnv[C + c];
+        }
+        y[i] = apply_pro(x[i], act, sc, sh);
+    }
 }
 
 int launch_act_fwd(const S2kOp& op, const Ctx& c) {
     const float* x = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_X]);
     float* y = ref_ptr<float>(c, op.t[S2K_ACT_FWD_T_Y]);
-    CHECK_PTRS("act_fwd", x, y);
+    const float* bnv = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_BNV]);
+    CHECK_PTRS("act_fwd", x, y, bnv);
     const int64_t n = op.n[S2K_ACT_FWD_N_COUNT];
-    const int act = op.d[S2K_ACT_FWD_D_ACT];
-    if (!x || !y || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU)) { set_error("act_fwd: bad args"); return S2K_EINVAL; }
-    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, x, y, n, act);
+    const int act = op.d[S2K_ACT_FWD_D_ACT], C = op.d[S2K_ACT_FWD_D_C], HW = op.d[S2K_ACT_FWD_D_HW];
+    if (!x || !y || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU) || (bnv && (C <= 0 || HW <= 0))) {
+        set_error("act_fwd: bad args"); return S2K_EINVAL;
+    }
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 8192)), dim3(256), 0, c.stream, x, y, n, act, bnv, C, HW);
     return S2K_OK;
 }
 

@@ -147,15 +147,18 @@ class MBConvBlock(_Holder):
                                          nn.BatchNorm2d(b.cout, momentum=mom, eps=eps))
 
 
-class EfficientNet(_Holder):
-    """Encoder parameter tree (reference :179-244).  `fc` exists for state-dict parity only; the
-    U-Net path never uses it, so it never receives a gradient (as in the reference)."""
+class EfficientNet(FlatParamsMixin, nn.Module):
+    """EfficientNet b0-b7 (reference :179-263): `encode(x) -> (x, feature_maps)`, `forward(x) -> logits [B, num_classes]`.
+    Standalone it owns its flat parameter buffer; as the `encoder` of an EfficientnetUnet it is a view of the owner's (the U-Net
+    never uses `fc`, which therefore never receives a gradient there — as in the reference)."""
 
-    def __init__(self, config: EfficientNetConfig) -> None:
+    def __init__(self, config: EfficientNetConfig, _owner=None) -> None:
         super().__init__()
         self.name = config.version
         self.drop_connect_rate = config.drop_connect_rate
+        self.dropout_rate = config.dropout_rate
         spec = unet_spec(config)
+        self.spec = spec
         mom, eps = config.bn_momentum, config.bn_epsilon
         self.stem = nn.Sequential(nn.Conv2d(config.in_channels, spec.stem_out, 3, stride=2, bias=False),
                                   nn.BatchNorm2d(spec.stem_out, momentum=mom, eps=eps), nn.SiLU())
@@ -164,6 +167,64 @@ class EfficientNet(_Holder):
                                        nn.BatchNorm2d(spec.head_out, momentum=mom, eps=eps), nn.SiLU())
         self.fc = nn.Sequential(nn.AdaptiveAvgPool2d(1), _Flatten(), nn.Dropout(p=config.dropout_rate),
                                 nn.Linear(spec.head_out, config.num_classes))
+        self.drop_connect_noise: torch.Tensor | None = None   # standalone: inject [n_blocks, B] uniforms for parity tests
+        self.dropout_noise: torch.Tensor | None = None        # [B, head channels] uniforms of fc's Dropout (kept iff u >= p)
+        self._owner_ref = None
+        self._standalone = _owner is None
+        if self._standalone:
+            from ..plan.unet_plan import build_encoder_layout
+
+            self.apply(init_weights)
+            self._unused_params = set()
+            self._init_flat(build_encoder_layout(spec))
+
+    def _apply(self, fn, recurse=True):
+        if self._standalone:
+            return super()._apply(fn, recurse)
+        return nn.Module._apply(self, fn, recurse)      # the owner re-flattens
+
+    def _owner_prefix(self):
+        if self._standalone:
+            return self, ""
+        owner = self._owner_ref() if self._owner_ref is not None else None
+        if owner is None:
+            raise RuntimeError("this EfficientNet was built as the encoder of an EfficientnetUnet that no longer exists")
+        return owner, "encoder."
+
+    def _run(self, x: torch.Tensor, classifier: bool) -> dict:
+        from ..plan.encoder_plan import plan_encoder
+        from ..vit_engine import run_method
+
+        owner, pre = self._owner_prefix()
+        if x.dim() != 4 or x.shape[1] != self.spec.in_channels:
+            raise ValueError(f"expected [B,{self.spec.in_channels},H,W], got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        training = self.training
+        wdx = torch.is_grad_enabled() and x.requires_grad
+        p_drop = float(self.dropout_rate or 0.0)
+        spec, layout = self.spec, owner._layout
+        dc = owner.drop_connect_noise if not self._standalone else self.drop_connect_noise
+        out = run_method(owner, ("efficientnet", pre, tuple(x.shape), training, classifier, wdx),
+                         lambda bwd: plan_encoder(spec, B, H, W, training, layout, pre, classifier, bwd, wdx and bwd, p_drop),
+                         {"x": x.contiguous()}, {"drop_connect": dc if training else None, "dropout_u": self.dropout_noise},
+                         publish_all=classifier)
+        if training:       # num_batches_tracked of the encoder's BatchNorms
+            idx = getattr(self, "_nbt_idx", None)
+            if idx is None or idx.device != owner._flat_nbt.device:
+                idx = torch.tensor([i for i, n in enumerate(layout.nbt) if n.startswith(pre)], dtype=torch.long, device=owner._flat_nbt.device)
+                self._nbt_idx = idx
+            owner._flat_nbt[idx] += 1
+        return out
+
+    def encode(self, x: torch.Tensor):
+        """(x, feature_maps): the activated conv_head output, and [x, first block output at each new spatial size, deepest
+        first] (reference :251-263; the (7, 7) literal generalised: maps of the conv_head output's size are dropped)."""
+        out = self._run(x, False)
+        return out["x"], [out["x"]] + [out[f"f{k}"] for k in range(len(out) - 1)]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """logits [B, num_classes] = fc(encode(x)[0]) (reference :246-249)."""
+        return self._run(x, True)["logits"]
 
 
 def _double_conv(cin: int, cout: int) -> nn.Sequential:
@@ -195,7 +256,7 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
 
         self.config = config
         self.spec = unet_spec(config)
-        self.encoder = EfficientNet(config)
+        self.encoder = EfficientNet(config, _owner=self)
         ups_in = [self.n_channels, 512, 256, 128]
         ups_out = [512, 256, 128, 64]
         self.up_convs = nn.ModuleList([nn.ConvTranspose2d(i, o, kernel_size=2, stride=2) for i, o in zip(ups_in, ups_out)])
@@ -209,6 +270,9 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
         self.drop_connect_noise: torch.Tensor | None = None  # inject [n_blocks, B] uniforms for parity tests
         self._unused_params = {"encoder.fc.3.weight", "encoder.fc.3.bias"}  # never on the U-Net path (as in the reference)
         self._init_flat(build_layout(self.spec))
+        import weakref
+
+        self.encoder._owner_ref = weakref.ref(self)
 
     @property
     def n_channels(self) -> int:

@@ -33,6 +33,7 @@ def stats_replicas(C: int) -> int:
 # ---- prologue / activation codes -----------------------------------------------------------
 PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU, PRO_GELU = 0, 1, 2, 3, 4   # v' = act(scale[c]*v + shift[c]); GELU = exact erf form
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 2, 3, 4                   # same numbering as PRO_*
+ACT_MUL = 5                                                            # ACT_BWD only: multiply by X instead of act'(X)
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
 FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream fork / join)
 
@@ -125,10 +126,13 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # DX (+)= rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = DY * GAMMA;  DGAMMA[c] += sum DY * xhat;  DBETA[c] += sum DY
     "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA"], [], ["B", "C", "HW", "ACCUM"], []),
     # G[i] *= act'(X[i])
+    # ACT = ACT_MUL: G[i] *= X[i]  (the dropout gate of EfficientNet's classifier head in the backward)
     "ACT_BWD": (["G", "X"], ["COUNT"], ["ACT"], []),
     # Y[i] = act(X[i])   (GELU of the MLP hidden layer, materialised once: the erf polynomial costs ~25 vector instructions
     # per element, and a conv / wgrad prologue would re-evaluate it for every output-channel tile that reads the element)
-    "ACT_FWD": (["X", "Y"], ["COUNT"], ["ACT"], []),
+    # BNV given (with C, HW): Y = act(scale[c] * X + shift[c]) on [.][C][HW] — EfficientNet.encode materialises SiLU(BN(conv_head)),
+    # which the fused network only ever applies as a load prologue
+    "ACT_FWD": (["X", "Y", "BNV"], ["COUNT"], ["ACT", "C", "HW"], []),
     # multi-head attention on QKV [B][3*HEADS*HD][LS] (rows q | k | v, each (head, d); LS >= L is the row stride, 0 = L):
     #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d];  LSE[b][h][i] = log sum_j exp(SCALE * <q_i, k_j>)
     # backward reads O and LSE back, uses DELTA [B][HEADS][LS] as scratch (sum_d DO * O);  O / DQKV / LSE columns L..LS-1 := 0

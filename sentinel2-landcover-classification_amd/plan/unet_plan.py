@@ -360,8 +360,9 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
 
 
 def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Act, M: int, ident: Act | None,
-                             dc_rate: float | None, eps: float, mom: float) -> Act:
-    """MBConv tail: 1x1 project -> BN -> [drop-connect] + identity, materialised (it has two consumers)."""
+                             dc_rate: float | None, eps: float, mom: float, out_ref: TRef | None = None) -> Act:
+    """MBConv tail: 1x1 project -> BN -> [drop-connect] + identity, materialised (it has two consumers).
+    out_ref: where to materialise it (EfficientNet.encode returns some block outputs: they are written straight into OUT)."""
     B = p.B
     H, W = src.H, src.W
     y = p.alloc("y:" + wname, (B, M, H, W))
@@ -372,7 +373,7 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
               HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=M,
               NREP=D.stats_replicas(M))
     bnv = _bn_forward(p, bnprefix, y, M, B * H * W, stats, eps, mom)
-    xout = p.alloc(f"x:block{idx}", (B, M, H, W))
+    xout = out_ref if out_ref is not None else p.alloc(f"x:block{idx}", (B, M, H, W))
     use_dc = bool(ident is not None and dc_rate and p.training)
     keep = 1.0 - dc_rate if use_dc else 1.0
     noise = TRef(D.BASE["NOISE"], idx * B * 4, (B,), "f32", f"noise{idx}") if use_dc else None
@@ -797,6 +798,71 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
     return segments, bwd
 
 
+def fmap_block_indices(spec: UnetSpec, H: int, W: int) -> list[int]:
+    """Blocks whose output EfficientNet.encode collects: the first block at each new spatial size, deepest first, without the
+    size of the conv_head output (reference :255-260 with the (7, 7) literal generalised)."""
+    h, w = same_pads(H, 3, 2)[0], same_pads(W, 3, 2)[0]
+    sizes = []
+    for b in spec.blocks:
+        h, w = same_pads(h, b.kernel, b.stride)[0], same_pads(w, b.kernel, b.stride)[0]
+        sizes.append((h, w))
+    head = sizes[-1]
+    out: list[int] = []
+    seen: list[tuple] = []
+    for i, sz in enumerate(sizes):
+        if sz not in seen and sz != head:
+            seen.append(sz)
+            out.insert(0, i)
+    return out
+
+
+def emit_encoder(p: "_P", spec: UnetSpec, x_in: Act, pre: str = "encoder.", fmap_refs: dict | None = None):
+    """EfficientNet.encode (reference :251-263): stem, MBConv blocks, conv_head.  Returns (head activation, feature maps deepest
+    first, all block outputs).  fmap_refs: block index -> TRef where that block's output must be materialised."""
+    eps, mom = spec.bn_eps, spec.bn_momentum
+    cur = conv_bn(p, pre + "stem.0.weight", pre + "stem.1", [x_in], spec.stem_out, 3, 2, True, D.PRO_SILU, eps, mom)
+    block_outs: list[Act] = []
+    n = len(spec.blocks)
+    for i, b in enumerate(spec.blocks):
+        bp = f"{pre}blocks.{i}."
+        xin = cur
+        j = 0
+        a = xin
+        if b.expand != 1:
+            a = conv_bn(p, bp + "stem.0.weight", bp + "stem.1", [xin], b.cexp, 1, 1, True, D.PRO_SILU, eps, mom)
+            j = 3
+        a = dwconv_bn(p, bp + f"stem.{j}.weight", bp + f"stem.{j + 1}", a, b.kernel, b.stride, eps, mom)
+        a = squeeze_excite(p, bp + "squeeze_excitation", a, b.se)
+        rate = spec.drop_connect_rate * (i / n) if spec.drop_connect_rate is not None else None
+        cur = project_conv_bn_residual(p, i, bp + "final_layer.0.weight", bp + "final_layer.1", a, b.cout,
+                                       xin if b.residual else None, rate, eps, mom,
+                                       out_ref=(fmap_refs or {}).get(i))
+        block_outs.append(cur)
+    head_hw = (cur.H, cur.W)
+    fmaps: list[Act] = []
+    for a in block_outs:  # first block output at each new spatial size, deepest first (encode :259)
+        if (a.H, a.W) not in [(f.H, f.W) for f in fmaps] and (a.H, a.W) != head_hw:
+            fmaps.insert(0, a)
+    if len(fmaps) != 4:
+        raise ValueError(f"expected 4 skip feature maps, got {len(fmaps)} for input {x_in.H}x{x_in.W}")
+    cur = conv_bn(p, pre + "conv_head.0.weight", pre + "conv_head.1", [cur], spec.head_out, 1, 1, True, D.PRO_SILU, eps, mom)
+    return cur, fmaps, block_outs
+
+
+def build_encoder_layout(spec: UnetSpec) -> ParamLayout:
+    """Flat layout of a standalone EfficientNet (reference :179-244): the encoder entries of `build_layout` without the prefix."""
+    full = build_layout(spec)
+    L = ParamLayout()
+    for name, (_, shape) in full.params.items():
+        if name.startswith("encoder."):
+            L.add_param(name[len("encoder."):], shape)
+    for name, (_, shape) in full.bufs.items():
+        if name.startswith("encoder."):
+            L.add_buf(name[len("encoder."):], shape)
+    L.nbt = [n[len("encoder."):] for n in full.nbt if n.startswith("encoder.")]
+    return L
+
+
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
               bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None, want_bwd: bool | None = None,
               want_dx: bool = False) -> UnetPlan:
@@ -813,33 +879,7 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
                needs_grad=bool(want_dx), grad=TRef(D.BASE["DX"], 0, (B, spec.in_channels, H, W), "f32", "dx") if want_dx else None)
 
     # encoder --------------------------------------------------------------------------
-    cur = conv_bn(p, "encoder.stem.0.weight", "encoder.stem.1", [x_in], spec.stem_out, 3, 2, True,
-                  D.PRO_SILU, eps, mom)
-    block_outs: list[Act] = []
-    n = len(spec.blocks)
-    for i, b in enumerate(spec.blocks):
-        pre = f"encoder.blocks.{i}."
-        xin = cur
-        j = 0
-        a = xin
-        if b.expand != 1:
-            a = conv_bn(p, pre + "stem.0.weight", pre + "stem.1", [xin], b.cexp, 1, 1, True, D.PRO_SILU, eps, mom)
-            j = 3
-        a = dwconv_bn(p, pre + f"stem.{j}.weight", pre + f"stem.{j + 1}", a, b.kernel, b.stride, eps, mom)
-        a = squeeze_excite(p, pre + "squeeze_excitation", a, b.se)
-        rate = spec.drop_connect_rate * (i / n) if spec.drop_connect_rate is not None else None
-        cur = project_conv_bn_residual(p, i, pre + "final_layer.0.weight", pre + "final_layer.1", a, b.cout,
-                                       xin if b.residual else None, rate, eps, mom)
-        block_outs.append(cur)
-    head_hw = (cur.H, cur.W)
-    fmaps: list[Act] = []
-    for a in block_outs:  # first block output at each new spatial size, deepest first (encode :259)
-        if (a.H, a.W) not in [(f.H, f.W) for f in fmaps] and (a.H, a.W) != head_hw:
-            fmaps.insert(0, a)
-    if len(fmaps) != 4:
-        raise ValueError(f"expected 4 skip feature maps, got {len(fmaps)} for input {H}x{W}")
-    cur = conv_bn(p, "encoder.conv_head.0.weight", "encoder.conv_head.1", [cur], spec.head_out, 1, 1, True,
-                  D.PRO_SILU, eps, mom)
+    cur, fmaps, _ = emit_encoder(p, spec, x_in, "encoder.")
 
     # decoder --------------------------------------------------------------------------
     ups_out = [512, 256, 128, 64]
@@ -863,5 +903,5 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
 
     segments, bwd = finish_plan(p, layout, training, bucket_floats)
 
-    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, n,
+    return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, len(spec.blocks),
                     segments if p.want_bwd else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

@@ -265,13 +265,14 @@ class _MethodFunction(torch.autograd.Function):
         _lib.run(eng.bwd, eng.bases(module, lease.space, ctx.xbuf, ctx.out, ctx.noise, dout=dout, grads=scratch, dx=dx), _stream(dev))
         lease.release()
         main.add_(scratch)
-        if not live:
-            module._publish_grads(module._no_grad_params)
+        if not live or getattr(eng, "publish_all", False):
+            module._publish_grads(set() if getattr(eng, "publish_all", False) else module._no_grad_params)
         grads_in = tuple(_view(dx, plan.dins[n]).clone() if n in plan.dins else None for n in ctx.names)
         return (None, None, None, None, None) + grads_in
 
 
-def run_method(module, key, make_plan, inputs: dict, injected: dict | None = None, uses_params: bool = True) -> dict:
+def run_method(module, key, make_plan, inputs: dict, injected: dict | None = None, uses_params: bool = True,
+               publish_all: bool = False) -> dict:
     """Runs one separately callable method.  `key`: cache key of the plan (shapes, ratios); `make_plan(want_bwd)` builds the
     MethodPlan; `inputs`: name -> tensor (device tensors; moved / cast as the plan asks).  Returns {output name: tensor}."""
     dev = module._flat_params.device
@@ -288,6 +289,7 @@ def run_method(module, key, make_plan, inputs: dict, injected: dict | None = Non
     eng = module._engines.get(ckey)
     if eng is None:
         eng = MethodEngine(make_plan(needs), dev)
+        eng.publish_all = publish_all     # every parameter of the layout may receive a gradient from this method
         module._engines[ckey] = eng
     plan = eng.plan
     noise = torch.empty(max(plan.noise_bytes // 4, 1), dtype=torch.float32, device=dev)

@@ -239,3 +239,96 @@ def plan_unet_for(model, B, H, train, want_dx=False):
     from s2lc_amd.plan.unet_plan import plan_unet
 
     return plan_unet(model.spec, B, H, H, train, model._layout, want_bwd=True, want_dx=want_dx)
+
+
+@pytest.mark.parametrize("train,nested", [(True, False), (False, True)])
+def test_efficientnet_encode_and_classifier_programs_float64(train, nested):
+    """EfficientNet.encode / .forward as separately callable programs (reference :246-263): outputs, gradients w.r.t. every
+    encoder parameter, the input and (classifier) fc, against float64 oracle autograd; standalone layout and the U-Net's."""
+    import torch.nn.functional as F
+
+    from oracle.ops_ref import Mem
+    from s2lc_amd.plan import opdefs as D
+    from s2lc_amd.plan.encoder_plan import plan_encoder
+    from s2lc_amd.modules.efficientnet_unet import unet_spec
+    from s2lc_amd.plan.unet_plan import build_encoder_layout, build_layout
+    from tests.plan_harness import _bytes, flat_from_state
+
+    B, C, H, ncls, p_drop = 2, 5, 64, 3, 0.25
+    cfg = EfficientNetConfig("b0", C, ncls, class_distribution=[1.0 / ncls] * ncls, drop_connect_rate=0.25, dropout_rate=p_drop)
+    spec = unet_spec(cfg)
+    net = R.build("b0", C, ncls, drop_connect_rate=0.25)
+    sd = detgen.fill_state(R.state_shapes(net), seed=5)
+    sd["encoder.fc.3.weight"] = detgen.normal("fc.w", (ncls, spec.head_out), seed=5) * 0.05
+    sd["encoder.fc.3.bias"] = detgen.normal("fc.b", (ncls,), seed=5) * 0.05
+    pre = "encoder." if nested else ""
+    layout = build_layout(spec) if nested else build_encoder_layout(spec)
+    own = {k: v for k, v in sd.items()} if nested else {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    fp, fb = flat_from_state(layout, own)
+    x = detgen.normal("enc.x", (B, C, H, H), seed=5)
+    dc = detgen.uniform("enc.dc", (len(net.blocks), B), 0.0, 1.0, seed=5)
+    du = detgen.uniform("enc.du", (B, spec.head_out), 0.0, 1.0, seed=6)
+
+    def oracle(classifier):
+        sdd = {k: (v.detach().double().requires_grad_(not k.endswith(("running_mean", "running_var"))) if v.dtype.is_floating_point else v)
+               for k, v in sd.items()}
+        x64 = x.double().requires_grad_(True)
+        newbuf = {}
+        hx, fmaps = R.encode(sdd, R._BN(sdd, train, newbuf), net, x64, dc.double() if train else None)
+        if not classifier:
+            return sdd, x64, {"x": hx, **{f"f{k}": f for k, f in enumerate(fmaps[1:])}}, newbuf
+        pooled = hx.mean(dim=(2, 3))
+        if train:
+            pooled = pooled * (du.double() >= p_drop) / (1.0 - p_drop)
+        return sdd, x64, {"logits": F.linear(pooled, sdd["encoder.fc.3.weight"], sdd["encoder.fc.3.bias"])}, newbuf
+
+    for classifier in (False, True):
+        plan = plan_encoder(spec, B, H, H, train, layout, pre, classifier, True, True, p_drop)
+        bases = {}
+        k = 2
+        for base, size in (("WS", plan.ws_bytes), ("AUX", plan.aux_bytes), ("OUT", plan.out_bytes), ("X", plan.x_bytes), ("DOUT", plan.dout_bytes),
+                           ("DX", plan.dx_bytes), ("NOISE", max(plan.noise_bytes, 8)), ("WPACK", getattr(plan, "wpack_bytes", 0))):
+            bases[D.BASE[base]] = torch.zeros(k * ((size + 7) // 8 * 8) + 64, dtype=torch.uint8)
+        bases[D.BASE["PARAMS"]] = _bytes(fp.double().clone())
+        bases[D.BASE["GRADS"]] = _bytes(torch.zeros(layout.n_params, dtype=torch.float64))
+        bases[D.BASE["WGS"]] = _bytes(torch.zeros(layout.n_params, dtype=torch.float64))
+        bases[D.BASE["BUFS"]] = _bytes(fb.double().clone())
+        bases[D.BASE["CONST"]] = _bytes(torch.tensor(plan.const_table if plan.const_table else [0] * 8, dtype=torch.int32))
+        m = Mem(bases, True, (D.BASE["CONST"],))
+        m.view(plan.inputs["x"].ref, plan.inputs["x"].shape).copy_(x.double())
+        if train:
+            m.view(plan.noise["drop_connect"].ref, plan.noise["drop_connect"].shape).copy_(dc.double())
+            if classifier:
+                m.view(plan.noise["dropout_u"].ref, plan.noise["dropout_u"].shape).copy_(du.double())
+        emulate(plan.fwd.pack(), bases, True)
+        sdd, x64, outs, newbuf = oracle(classifier)
+        assert set(outs) == set(plan.outputs)
+        tot = 0
+        for j, (name, o) in enumerate(outs.items()):
+            r = plan.outputs[name]
+            assert tuple(r.shape) == tuple(o.shape), name
+            assert rel_err(m.view(r.ref, r.shape).numpy(), o.detach().numpy()) < 1e-6, name   # (BN eps travels as f32)
+            w = torch.randn(o.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(10 + j))
+            tot = tot + (o * w).sum()
+            d = plan.douts[name]
+            m.view(d.ref, d.shape).copy_(w)
+        tot.backward()
+        emulate(plan.bwd.pack(), bases, True)
+        gx = plan.dins["x"]
+        assert rel_err(m.view(gx.ref, gx.shape).numpy(), x64.grad.numpy()) < 1e-6
+        grads = fview(bases, "GRADS", True)
+        scale = max(v.grad.abs().max().item() for v in sdd.values() if getattr(v, "grad", None) is not None)
+        for name, (off, shape) in layout.params.items():
+            full = name if nested else "encoder." + name
+            ref = sdd[full].grad if full in sdd else None
+            g = grads[off:off + int(np.prod(shape))].view(shape)
+            if ref is None:
+                assert g.abs().max() == 0, name
+            else:
+                assert (g - ref).abs().max().item() <= 1e-6 * max(ref.abs().max().item(), 1e-4 * scale), name
+        if train:
+            bufs = fview(bases, "BUFS", True)
+            for name, (off, shape) in layout.bufs.items():
+                full = name if nested else "encoder." + name
+                if full in newbuf:
+                    assert rel_err(bufs[off:off + shape[0]].numpy(), newbuf[full].numpy()) < 1e-6, name
