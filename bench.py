@@ -4,8 +4,11 @@ Workload (BASELINE.json configs[1] / [2]): efficientnet-unet-b5, 13 bands, 256x2
 GPU, focal loss (gamma 2, ignore 0), train-mode BatchNorm, drop-connect 0.2, fp32.  One step =
 forward + loss + backward (+ gradient all-reduce over RCCL when N > 1) + fused Adam step, inputs
 already resident in HBM.  Prints ONE JSON line (rank 0) with the whole-job tiles/s, the roofline of
-the dominant kernel family measured live with HIP events, and a bounded CPU baseline of the same
-step (the CPU oracle, rank 0, N = 1 only).
+the dominant kernel measured live with HIP events (spec peak and the peak measured on this GPU in the
+same run), the Adam time, a bounded CPU baseline of the same step (the CPU oracle, rank 0, N = 1
+only), and - N = 1 only, skipped with --no-prithvi - the Prithvi workloads of BASELINE.json
+configs[3] / [4] as extra keys (`prithvi_mae`, `prithvi_seg_frozen`, `prithvi_seg_unfrozen`); the
+headline `value` is always configs[1].
 
   python bench.py [--gpus N] [--steps K] [--warmup W]       (N > 1: launched by torch.distributed.run)
 """
@@ -28,90 +31,236 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_HBM_GBS = 8000.0
 
 
-def conv_flops(packed, D) -> dict:
-    """Algorithmic FLOPs per launch family, from the stage records themselves (2*M*N*K each)."""
-    names = {v: k for k, v in D.KIND.items()}
-    out = {}
-    for rec in packed:
-        kind = names[int(rec["kind"])]
-        d = rec["d"]
-        if kind == "CONV":
-            B, C1, C2, M, KH, KW, HO, WO = (int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "M", "KH", "KW", "HO", "WO"))
-            fl = 2.0 * M * (C1 + C2) * KH * KW * B * HO * WO
-        elif kind == "WGRAD":
-            B, M, C, KH, KW, HO, WO = (int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "KH", "KW", "HO", "WO"))
-            fl = 2.0 * M * C * KH * KW * B * HO * WO
-        else:
-            continue
-        out[kind] = out.get(kind, 0.0) + fl
-    return out
+KERNEL_OF = {("CONV", 0): "conv_igemm_kernel", ("CONV", 1): "conv_pc_kernel", ("WGRAD", 0): "wgrad_kernel", ("WGRAD", 1): "wgrad_pc_kernel"}
 
 
-def conv_bytes(packed, D) -> dict:
-    """Algorithmic HBM bytes per launch family: every conv-like stage reads its input(s) + weights once and writes its
-    output once (SURVEY §8d convention), from the stage records."""
-    names = {v: k for k, v in D.KIND.items()}
-    out = {}
-    for rec in packed:
-        kind = names[int(rec["kind"])]
-        d = rec["d"]
-        if kind == "CONV":
-            B, C1, C2, H, W, M, KH, KW, HO, WO, mode = (int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "H", "W", "M", "KH", "KW", "HO", "WO", "MODE"))
-            by = 4.0 * (B * (C1 + C2) * H * W + B * M * HO * WO + M * (C1 + C2) * KH * KW)
-        elif kind == "WGRAD":
-            B, M, C, H, W, KH, KW, HO, WO = (int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "H", "W", "KH", "KW", "HO", "WO"))
-            by = 4.0 * (B * M * HO * WO + B * C * H * W + M * C * KH * KW)
-        else:
-            continue
-        out[kind] = out.get(kind, 0.0) + by
-    return out
+def stage_work(rec, D):
+    """(kind, algorithmic FLOPs, algorithmic HBM bytes) of one CONV / WGRAD stage record, else (kind, 0, 0): 2*M*N*K flops;
+    bytes = every operand read once + the result written once (SURVEY §8d convention)."""
+    kind = D.NAME_OF[int(rec["kind"])]
+    d = rec["d"]
+    if kind == "CONV":
+        B, C1, C2, H, W, M, KH, KW, HO, WO = (int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "H", "W", "M", "KH", "KW", "HO", "WO"))
+        return kind, 2.0 * M * (C1 + C2) * KH * KW * B * HO * WO, 4.0 * (B * (C1 + C2) * H * W + B * M * HO * WO + M * (C1 + C2) * KH * KW)
+    if kind == "WGRAD":
+        B, M, C, H, W, KH, KW, HO, WO = (int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "H", "W", "KH", "KW", "HO", "WO"))
+        return kind, 2.0 * M * C * KH * KW * B * HO * WO, 4.0 * (B * M * HO * WO + B * C * H * W + M * C * KH * KW)
+    return kind, 0.0, 0.0
+
+
+def profile_programs(_lib, D, programs, bases_list, stream):
+    """Device time of every stage of `programs` (HIP events on the launch stream, stages run back to back on that one stream).
+    Returns (per stage-kind {ms, launches}, per MFMA kernel name {ms, launches, flops, bytes})."""
+    kinds, kernels = {}, {}
+    for prog, bases in zip(programs, bases_list):
+        ms, var = _lib.profile_variants(prog, bases, stream)
+        for rec, t, v in zip(prog, ms, var):
+            kind, fl, by = stage_work(rec, D)
+            e = kinds.setdefault(kind, {"ms": 0.0, "launches": 0})
+            e["ms"] += float(t); e["launches"] += 1
+            if fl:
+                k = kernels.setdefault(KERNEL_OF[(kind, int(v))], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+                k["ms"] += float(t); k["launches"] += 1; k["flops"] += fl; k["bytes"] += by
+    return kinds, kernels
+
+
+def csrc_fingerprint() -> str:
+    """Hash of the kernel sources: a committed PMC traffic figure is only quoted for the sources it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "sentinel2-landcover-classification_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def make_roofline(kernels: dict, peaks: dict | None) -> dict:
+    """Roofline object of the MFMA kernel with the most device time."""
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    k = kernels[dom]
+    ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+    tot_fl = sum(v["flops"] for v in kernels.values())
+    tot_ms = sum(v["ms"] for v in kernels.values())
+    traffic, src = measured_traffic(dom)
+    r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+         # HBM bytes per launch from the PMC counters of a COMMITTED rocprofv3 run (not this run): null when that file was
+         # measured on other kernel sources than the ones built here
+         "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
+         "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4), "flops_per_step": k["flops"],
+         "all_mfma_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+         "mfma_kernels": {n: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                          for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}}
+    if peaks:
+        r["peak_measured"] = round(peaks["mfma_f32_tflops"], 1)
+        r["frac_of_measured"] = round(ach / peaks["mfma_f32_tflops"], 4)
+    return r
 
 
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC run (profiles/*_hbm_traffic.json, newest), or None."""
+    """(HBM bytes per launch of `kernel`, provenance) from the newest committed PMC run (profiles/*_hbm_traffic.json, written by
+    tools/pmc_traffic.sh + tools/traffic_json.py).  The figure is NOT measured in this run (PMC counters need rocprofv3 around
+    the process); it is dropped - loudly - when the file was measured on kernel sources other than the ones built here."""
     files = sorted((ROOT / "profiles").glob("*_hbm_traffic.json"))
     if not files:
-        return None
+        return None, "none: no profiles/*_hbm_traffic.json"
+    f = files[-1]
     try:
-        return json.loads(files[-1].read_text())["kernels"][kernel]["hbm_bytes"]
-    except Exception:
-        return None
+        doc = json.loads(f.read_text())
+        have, want = doc.get("csrc_fingerprint"), csrc_fingerprint()
+        if have != want:
+            print(f"bench.py: {f.name} was measured on csrc {have}, this tree is {want}: roofline.traffic omitted "
+                  f"(re-run tools/pmc_traffic.sh)", file=sys.stderr)
+            return None, f"stale: profiles/{f.name} (csrc {have}, built {want})"
+        return doc["kernels"][kernel]["hbm_bytes"], f"committed PMC run profiles/{f.name} (same csrc {want}); not measured in this run"
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable: profiles/{f.name}: {e}"
 
 
-def cpu_baseline(version, C, H, ncls, budget_s=20.0):
-    """The CPU oracle (a port of the reference's torch CPU path, validated against the reference via
-    tests/golden) timed on this host: forward + backward of the same step at a small batch."""
+def cpu_model() -> dict:
+    """CPU model string, sockets and cores of this host."""
+    model, phys, cores = None, set(), set()
+    try:
+        pid = None
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip(); phys.add(pid)
+            elif line.startswith("core id"):
+                cores.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return {"model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count(),
+            "usable_cpus": len(os.sched_getaffinity(0))}
+
+
+def cpu_baseline(version, C, H, ncls, steps=5):
+    """The CPU oracle (a port of the reference's torch CPU path, validated against the reference via tests/golden) timed on
+    this host: forward + backward of the same step.  torch's intra-op thread count is swept over {16, 32, 64, all usable}
+    (one warm-up + one timed step each at batch 2), then `steps` timed steps at the best count at batch 2 and at batch 4; the
+    better of the two is reported."""
     from oracle import detgen, losses_ref
     from oracle import efficientnet_unet_ref as R
 
-    B = 2
     net = R.build(version, C, ncls)
     sd = detgen.fill_state(R.state_shapes(net), seed=1)
     for k, v in sd.items():
         if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
-    x = torch.randn(B, C, H, H)
-    y = torch.randint(0, ncls, (B, H, H))
-    noise = torch.rand(len(net.blocks), B)
+
+    def make_step(B):
+        x = torch.randn(B, C, H, H)
+        y = torch.randint(0, ncls, (B, H, H))
+        noise = torch.rand(len(net.blocks), B)
+
+        def step():
+            for v in sd.values():
+                if v.requires_grad:
+                    v.grad = None
+            logits = R.unet_forward(sd, net, x, training=True, dc_noise=noise)
+            losses_ref.focal(logits, y, torch.ones(ncls), 2.0, 0.0, ignore_index=0).backward()
+        return step
+
+    usable = len(os.sched_getaffinity(0))
+    before = torch.get_num_threads()
+    sweep = {}
+    step2 = make_step(2)
+    for t in sorted({min(t, usable) for t in (16, 32, 64, usable)}):
+        torch.set_num_threads(t)
+        step2()
+        t0 = time.perf_counter()
+        step2()
+        sweep[t] = round(2 / (time.perf_counter() - t0), 3)
+    best_t = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_t)
+    by_batch = {}
+    for B in (2, 4):
+        st = step2 if B == 2 else make_step(B)
+        st()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st()
+        by_batch[B] = round(B * steps / (time.perf_counter() - t0), 3)
+    torch.set_num_threads(before)
+    best_b = max(by_batch, key=by_batch.get)
+    return {"value": by_batch[best_b], "unit": "tiles/s", "cores": best_t, "kind": "port", "cpu": cpu_model(),
+            "thread_sweep_tiles_per_s": {str(k): v for k, v in sweep.items()}, "by_batch_tiles_per_s": {str(k): v for k, v in by_batch.items()},
+            "sample": f"{steps} timed fwd+bwd steps (after 1 warm-up) of efficientnet-unet-{version} {C}x{H}x{H} at batch {best_b} with "
+                      f"{best_t} torch threads - the best of a thread sweep {sorted(sweep)} x batch (2, 4) (oracle/, torch CPU fp32 eager)"}
+
+
+def time_adam(opt, dev, iters=10) -> float:
+    """Milliseconds of one fused Adam step over the flat parameter buffer (HIP events on the current stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    opt.step()
+    e0.record()
+    for _ in range(iters):
+        opt.step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters
+
+
+def prithvi_workload(what: str, dev, peaks, steps=8, warmup=3) -> dict:
+    """One Prithvi workload of BASELINE.json (configs[3]: MAE pre-training bs 64 mask 0.75; configs[4]: segmentation fine-tuning
+    bs 16, frozen / unfrozen backbone), 6x1x224x224 synthetic inputs, random-init Prithvi-100M: forward + loss + backward + Adam."""
+    from s2lc_amd import _lib
+    from s2lc_amd.optim import FlatAdam
+    from s2lc_amd.plan import opdefs as D
+    from s2lc_amd.utils import _prithvi_model_args, load_untrained_prithvi
+
+    torch.manual_seed(42)
+    if what == "mae":
+        B = 64
+        model = load_untrained_prithvi(1).to(dev)
+        x = torch.randn(B, 6, 1, 224, 224, device=dev)
+
+        def fwd_loss():
+            return model(x, mask_ratio=0.75)[0]
+        name = "prithvi-100M MAE pre-training step 6x1x224x224 bs64 mask 0.75 (fwd+loss+bwd+adam)"
+    else:
+        from s2lc_amd.losses import CrossEntropyLoss
+        from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+        from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+
+        B = 16
+        frozen = what == "seg_frozen"
+        bb = MaskedAutoencoderViT(**_prithvi_model_args(1), _decoder=False, _flat=False)
+        model = PrithviSegmentationNet(PrithviSegmentationNetConfig(1, 4, 256, 1, 0.1, frozen), backbone=bb).to(dev)
+        x = torch.randn(B, 6, 1, 224, 224, device=dev)
+        y = torch.randint(0, 4, (B, 224, 224), device=dev)
+        lossf = CrossEntropyLoss(ignore_index=0)
+
+        def fwd_loss():
+            return lossf(model(x), y)
+        name = f"prithvi-100M segmentation fine-tuning step 6x1x224x224 bs16 CE(ignore 0), {'frozen' if frozen else 'unfrozen'} backbone (fwd+loss+bwd+adam)"
+    opt = FlatAdam(model, lr=1e-4)
+    model.train()
 
     def step():
-        for v in sd.values():
-            if v.requires_grad:
-                v.grad = None
-        logits = R.unet_forward(sd, net, x, training=True, dc_noise=noise)
-        losses_ref.focal(logits, y, torch.ones(ncls), 2.0, 0.0, ignore_index=0).backward()
+        opt.zero_grad()
+        loss = fwd_loss()
+        loss.backward()
+        opt.step()
+        return loss
 
-    step()
-    t0 = time.perf_counter()
-    n = 0
-    while True:
+    for _ in range(warmup):
         step()
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 8:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd steps of efficientnet-unet-{version} {C}x{H}x{H} at batch {B} (oracle/, torch CPU fp32 eager)"}
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    eng = [e for e in model._engines.values() if getattr(e, "bwd", None) is not None][-1]
+    noise = torch.rand(max(eng.plan.noise_bytes // 4, 1), device=dev)
+    out = torch.empty(eng.plan.out_bytes + 256, dtype=torch.uint8, device=dev)
+    dout = torch.ones(max(eng.plan.dout_bytes // 4, 1), device=dev) * 1e-3
+    bases = eng.bases(model, x, out, noise, dout=dout, grads=model._grad_buffer())
+    _, kernels = profile_programs(_lib, D, (eng.fwd, eng.bwd), (bases, bases), torch.cuda.current_stream().cuda_stream)
+    return {"workload": name, "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
+            "batch": B, "dtype": "f32", "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss), 6), "roofline": make_roofline(kernels, peaks)}
 
 
 def main() -> None:
@@ -125,6 +274,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1 only; the headline is unaffected)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -204,40 +354,29 @@ def main() -> None:
         dt = float(t.item())
     loss_val = float(loss.item())
 
-    roofline, kernels, cpu = None, None, None
+    roofline, kernels, cpu, peaks, adam_ms, extra = None, None, None, None, None, {}
     if rank == 0:
         if not args.no_profile:
-            # live per-kernel-family device time (HIP events on the launch stream) of one fwd+bwd
+            # once per run: the f32-MFMA issue rate and the stream-copy bandwidth THIS GPU sustains (include/s2k.h s2k_measure_peaks)
+            peaks = _lib.measure_peaks(dev)
+            adam_ms = time_adam(opt, dev)
+            # live per-stage device time (HIP events on the launch stream) of one forward + backward
             eng = next(iter(model._engines.values()))
             st = torch.cuda.current_stream().cuda_stream
             out = torch.empty(eng.plan.logits_shape, device=dev)
             noise = torch.rand(eng.n_noise_rows, B, device=dev)
             grads = model._grad_buffer()
             dout = torch.randn(eng.plan.logits_shape, device=dev) * 1e-6
-            pf = _lib.profile(eng.fwd, eng.bases(model, x, out, noise=noise), st)
-            pb = _lib.profile(eng.bwd, eng.bases(model, x, None, dout=dout, noise=noise, grads=grads), st)
-            fl_f, fl_b = conv_flops(eng.fwd, D), conv_flops(eng.bwd, D)
-            kernels = {}
-            for nm in sorted(set(pf) | set(pb)):
-                ms = pf.get(nm, (0, 0))[0] + pb.get(nm, (0, 0))[0]
-                cnt = pf.get(nm, (0, 0))[1] + pb.get(nm, (0, 0))[1]
-                kernels[nm] = {"ms": round(ms, 3), "launches": cnt}
-            conv_ms = kernels["CONV"]["ms"]
-            conv_fl = fl_f.get("CONV", 0.0) + fl_b.get("CONV", 0.0)
-            wg_ms = kernels.get("WGRAD", {"ms": 0.0})["ms"]
-            wg_fl = fl_b.get("WGRAD", 0.0)
-            dom, dms, dfl = ("conv_igemm_kernel", conv_ms, conv_fl) if conv_ms >= wg_ms else ("wgrad_kernel", wg_ms, wg_fl)
-            n_l = kernels["CONV" if dom == "conv_igemm_kernel" else "WGRAD"]["launches"]
-            ach = dfl / (dms * 1e-3) / 1e12
-            by_f, by_b = conv_bytes(eng.fwd, D), conv_bytes(eng.bwd, D)
-            dkind = "CONV" if dom == "conv_igemm_kernel" else "WGRAD"
-            alg_bytes = (by_f.get(dkind, 0.0) + by_b.get(dkind, 0.0)) / n_l
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        # HBM bytes per launch from the PMC counters (committed run, see profiles/); algorithmic bytes beside it
-                        "traffic": measured_traffic(dom), "algorithmic_bytes_per_launch": round(alg_bytes),
-                        "launches": n_l, "avg_launch_ms": round(dms / n_l, 4),
-                        "flops_per_step": dfl, "all_mfma_tflops": round((conv_fl + wg_fl) / ((conv_ms + wg_ms) * 1e-3) / 1e12, 2)}
+            kinds, mfma = profile_programs(_lib, D, (eng.fwd, eng.bwd), (eng.bases(model, x, out, noise=noise),
+                                                                         eng.bases(model, x, None, dout=dout, noise=noise, grads=grads)), st)
+            kernels = {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in sorted(kinds.items())}
+            roofline = make_roofline(mfma, peaks)
+        if world == 1 and not args.no_prithvi and not args.no_profile:
+            del model, opt
+            torch.cuda.empty_cache()
+            for what in ("mae", "seg_frozen", "seg_unfrozen"):
+                extra["prithvi_" + what] = prithvi_workload(what, dev, peaks)
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.version, C, H, ncls)
         tiles = world * B * args.steps
@@ -248,7 +387,12 @@ def main() -> None:
             "config": {"workload": f"efficientnet-unet-{args.version} {C}x{H}x{H} bs{B}/GPU focal(g=2) train step "
                                    f"(fwd+loss+bwd{'+allreduce' if world > 1 else ''}+adam)",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "loss": round(loss_val, 6),
+            "roofline": roofline, "cpu_baseline": cpu, "adam_ms": None if adam_ms is None else round(adam_ms, 4),
+            "measured_peaks": None if peaks is None else {"mfma_f32_tflops": round(peaks["mfma_f32_tflops"], 1),
+                                                          "mfma_clock_mhz": round(peaks["mfma_clock_mhz"]),
+                                                          "stream_copy_gbps": round(peaks["copy_gbps"], 1),
+                                                          "spec": {"mfma_f32_tflops": PEAK_F32_MFMA_TFLOPS, "hbm_gbps": PEAK_HBM_GBS}},
+            "kernels": kernels, "loss": round(loss_val, 6), **extra,
         }
         print(json.dumps(line))
     if dist is not None:

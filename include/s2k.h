@@ -79,6 +79,12 @@ int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases
 int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
                             float* ms_per_op);
 
+/* same, plus which kernel the stage's launcher picked: variant_per_op[i] = 0 for the stage's generic kernel
+ * (conv_igemm_kernel, wgrad_kernel, ...), 1 for the producer/consumer kernel (conv_pc_kernel / wgrad_pc_kernel).
+ * bench.py uses it to attribute time and algorithmic FLOPs to the kernel names a rocprofv3 trace shows. */
+int s2k_program_profile_variants(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
+                                 float* ms_per_op, int* variant_per_op);
+
 /* fused Adam step (L2-coupled decay, train_segmentation.py:109-127): p, g, m, v flat fp32 [n].  Hyper-parameters are
  * doubles, as Python hands them to torch.optim.Adam: `1 - beta2` and `lr / (1 - beta1**step)` are formed in double and
  * rounded to fp32 once, which is what makes the update bit-compatible with torch's (ABI 2; ABI 1 took floats). */

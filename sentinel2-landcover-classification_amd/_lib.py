@@ -46,6 +46,8 @@ def lib() -> ctypes.CDLL:
     L.s2k_program_profile.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp]
     L.s2k_program_profile_ops.restype = i32
     L.s2k_program_profile_ops.argtypes = [vp, i32, i32, vp, i32, vp, vp]
+    L.s2k_program_profile_variants.restype = i32
+    L.s2k_program_profile_variants.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp]
     f64 = ctypes.c_double
     L.s2k_adam_step.restype = i32
     L.s2k_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, f64, f64, f64, f64, f64, i32, vp]
@@ -122,6 +124,16 @@ def profile_ops(packed: np.ndarray, bases: Bases, stream: int) -> np.ndarray:
     with _guard(bases):
         check(lib().s2k_program_profile_ops(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream, ms.ctypes.data))
     return ms
+
+
+def profile_variants(packed: np.ndarray, bases: Bases, stream: int):
+    """(ms per stage, variant per stage): variant 1 = the producer/consumer kernel was launched (include/s2k.h)."""
+    ms = np.zeros(len(packed), dtype=np.float32)
+    var = np.zeros(len(packed), dtype=np.int32)
+    with _guard(bases):
+        check(lib().s2k_program_profile_variants(packed.ctypes.data, 0, len(packed), bases.ptr, len(D.BASES), stream,
+                                                 ms.ctypes.data, var.ctypes.data))
+    return ms, var
 
 
 def measure_peaks(device=None, waves_per_simd: int = 1, scratch_gib: float = 2.0) -> dict:

@@ -184,6 +184,10 @@ inline int tune_int(const char* name, int dflt) {
 #endif
 }
 
+// Which kernel family a stage's launcher picked (read by s2k_program_profile_variants): 0 = the stage's generic kernel,
+// 1 = the producer/consumer kernel (conv_pc_kernel / wgrad_pc_kernel).
+extern thread_local int g_s2k_variant;
+
 // hipFuncSetAttribute acts on the current device: remember per device whether a kernel's attribute has been set.
 struct PerDeviceOnce {
     bool done[64] = {};

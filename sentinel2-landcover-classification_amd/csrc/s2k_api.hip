@@ -18,6 +18,7 @@
 namespace s2k {
 
 static thread_local char g_err[512] = "";
+thread_local int g_s2k_variant = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -287,22 +288,30 @@ int s2k_op_launch(const S2kOp* op, void* const* bases, int n_bases, void* stream
 }
 
 static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
-                        int* launches_by_kind, float* ms_per_op);
+                        int* launches_by_kind, float* ms_per_op, int* variant_per_op);
 
 int s2k_program_profile(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
                         int* launches_by_kind) {
-    return profile_impl(ops, begin, end, bases, n_bases, stream, ms_by_kind, launches_by_kind, nullptr);
+    return profile_impl(ops, begin, end, bases, n_bases, stream, ms_by_kind, launches_by_kind, nullptr, nullptr);
 }
 
 int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
                             float* ms_per_op) {
     float ms[S2K_N_KINDS + 1];
     int cnt[S2K_N_KINDS + 1];
-    return profile_impl(ops, begin, end, bases, n_bases, stream, ms, cnt, ms_per_op);
+    return profile_impl(ops, begin, end, bases, n_bases, stream, ms, cnt, ms_per_op, nullptr);
+}
+
+int s2k_program_profile_variants(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
+                                 float* ms_per_op, int* variant_per_op) {
+    float ms[S2K_N_KINDS + 1];
+    int cnt[S2K_N_KINDS + 1];
+    if (!ms_per_op || !variant_per_op) { set_error("program_profile_variants: bad arguments"); return S2K_EINVAL; }
+    return profile_impl(ops, begin, end, bases, n_bases, stream, ms, cnt, ms_per_op, variant_per_op);
 }
 
 static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream, float* ms_by_kind,
-                        int* launches_by_kind, float* ms_per_op) {
+                        int* launches_by_kind, float* ms_per_op, int* variant_per_op) {
     if (!ops || !bases || !ms_by_kind || !launches_by_kind || begin < 0 || end < begin) {
         set_error("program_profile: bad arguments");
         return S2K_EINVAL;
@@ -317,8 +326,10 @@ static int profile_impl(const S2kOp* ops, int begin, int end, void* const* bases
     hipEventRecord(ev[0], st);
     int done = 0;
     for (int i = 0; i < n; ++i) {
+        g_s2k_variant = 0;
         rc = check_launch(dispatch(ops[begin + i], c), ops[begin + i], begin + i);
         if (rc != S2K_OK) break;
+        if (variant_per_op) variant_per_op[i] = g_s2k_variant;
         hipEventRecord(ev[i + 1], st);
         done = i + 1;
     }

@@ -365,6 +365,7 @@ static int launch_pc2(WgradP& p, hipStream_t st) {
     p.tiles_per_split = cdiv(p.ntiles, splits);
     splits = cdiv(p.ntiles, p.tiles_per_split);
     hipLaunchKernelGGL(kern, dim3(mc * splits), dim3(512), lds, st, p);
+    g_s2k_variant = 1;
     return S2K_OK;
 }
 

@@ -196,6 +196,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),
 }
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
+NAME_OF = {i: name for name, i in KIND.items()}
 
 
 def slot(kind: str, field: str) -> tuple[str, int]:
