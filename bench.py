@@ -131,15 +131,22 @@ def cpu_model() -> dict:
                 cores.add((pid, line.split(":", 1)[1].strip()))
     except OSError:
         pass
+    quota = None
+    try:        # cgroup v2 CPU bandwidth of this container: "max 100000" or "<quota> <period>"
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
     return {"model": model, "sockets": len(phys) or None, "physical_cores": len(cores) or None, "logical_cpus": os.cpu_count(),
-            "usable_cpus": len(os.sched_getaffinity(0))}
+            "usable_cpus": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota}
 
 
 def cpu_baseline(version, C, H, ncls, steps=5):
     """The CPU oracle (a port of the reference's torch CPU path, validated against the reference via tests/golden) timed on
     this host: forward + backward of the same step.  torch's intra-op thread count is swept over {16, 32, 64, all usable}
-    (one warm-up + one timed step each at batch 2), then `steps` timed steps at the best count at batch 2 and at batch 4; the
-    better of the two is reported."""
+    on half-size tiles at batch 2 (one warm-up + one timed step each: the sweep only picks the thread count), then `steps`
+    timed steps at the best count on the full-size tiles at batch 2 and at batch 4; the better of the two is reported.  The sweep runs in ascending order and
+    stops as soon as the rate has fallen to half of the best seen (thread counts beyond the container's CPU share)."""
     from oracle import detgen, losses_ref
     from oracle import efficientnet_unet_ref as R
 
@@ -149,9 +156,9 @@ def cpu_baseline(version, C, H, ncls, steps=5):
         if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
 
-    def make_step(B):
-        x = torch.randn(B, C, H, H)
-        y = torch.randint(0, ncls, (B, H, H))
+    def make_step(B, size):
+        x = torch.randn(B, C, size, size)
+        y = torch.randint(0, ncls, (B, size, size))
         noise = torch.rand(len(net.blocks), B)
 
         def step():
@@ -162,32 +169,45 @@ def cpu_baseline(version, C, H, ncls, steps=5):
             losses_ref.focal(logits, y, torch.ones(ncls), 2.0, 0.0, ignore_index=0).backward()
         return step
 
+    def say(msg):       # progress on stderr: the CPU leg is the long, silent part of a default run
+        print(f"bench.py cpu_baseline: {msg}", file=sys.stderr, flush=True)
+
     usable = len(os.sched_getaffinity(0))
     before = torch.get_num_threads()
     sweep = {}
-    step2 = make_step(2)
+    hs = max(H // 2, 32)
+    probe = make_step(2, hs)
     for t in sorted({min(t, usable) for t in (16, 32, 64, usable)}):
         torch.set_num_threads(t)
-        step2()
+        probe()
         t0 = time.perf_counter()
-        step2()
+        probe()
         sweep[t] = round(2 / (time.perf_counter() - t0), 3)
+        say(f"{t} threads: {sweep[t]} tiles/s on {hs}x{hs} tiles")
+        if sweep[t] < 0.5 * max(sweep.values()):
+            # past the container's CPU share more threads only fight each other (a 128-thread step on a 16-CPU share did not
+            # finish in 7 minutes): stop the sweep once the rate has halved
+            say("rate halved: larger thread counts skipped")
+            break
     best_t = max(sweep, key=sweep.get)
     torch.set_num_threads(best_t)
     by_batch = {}
     for B in (2, 4):
-        st = step2 if B == 2 else make_step(B)
+        st = make_step(B, H)
         st()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             st()
+            say(f"batch {B} step {i + 1}/{steps} at {best_t} threads: {B * (i + 1) / (time.perf_counter() - t0):.3f} tiles/s")
         by_batch[B] = round(B * steps / (time.perf_counter() - t0), 3)
     torch.set_num_threads(before)
     best_b = max(by_batch, key=by_batch.get)
     return {"value": by_batch[best_b], "unit": "tiles/s", "cores": best_t, "kind": "port", "cpu": cpu_model(),
-            "thread_sweep_tiles_per_s": {str(k): v for k, v in sweep.items()}, "by_batch_tiles_per_s": {str(k): v for k, v in by_batch.items()},
+            "thread_sweep_tiles_per_s": {str(k): v for k, v in sweep.items()}, "thread_sweep_tile": f"{C}x{hs}x{hs} bs2",
+            "by_batch_tiles_per_s": {str(k): v for k, v in by_batch.items()},
             "sample": f"{steps} timed fwd+bwd steps (after 1 warm-up) of efficientnet-unet-{version} {C}x{H}x{H} at batch {best_b} with "
-                      f"{best_t} torch threads - the best of a thread sweep {sorted(sweep)} x batch (2, 4) (oracle/, torch CPU fp32 eager)"}
+                      f"{best_t} torch threads - the best of batch (2, 4); thread count picked by a sweep over {sorted(sweep)} on "
+                      f"{hs}x{hs} tiles (oracle/, torch CPU fp32 eager)"}
 
 
 def time_adam(opt, dev, iters=10) -> float:
@@ -256,7 +276,8 @@ def prithvi_workload(what: str, dev, peaks, steps=8, warmup=3) -> dict:
     eng = [e for e in model._engines.values() if getattr(e, "bwd", None) is not None][-1]
     noise = torch.rand(max(eng.plan.noise_bytes // 4, 1), device=dev)
     out = torch.empty(eng.plan.out_bytes + 256, dtype=torch.uint8, device=dev)
-    dout = torch.ones(max(eng.plan.dout_bytes // 4, 1), device=dev) * 1e-3
+    n_dout = eng.plan.dout_bytes // 4 if eng.plan.dout_bytes else int(torch.Size(eng.plan.dout_shape).numel())
+    dout = torch.ones(max(n_dout, 1), device=dev) * 1e-3
     bases = eng.bases(model, x, out, noise, dout=dout, grads=model._grad_buffer())
     _, kernels = profile_programs(_lib, D, (eng.fwd, eng.bwd), (bases, bases), torch.cuda.current_stream().cuda_stream)
     return {"workload": name, "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
@@ -378,6 +399,7 @@ def main() -> None:
                 extra["prithvi_" + what] = prithvi_workload(what, dev, peaks)
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
+            print(f"bench.py: GPU legs done ({world * B * args.steps / dt:.1f} tiles/s); timing the CPU oracle", file=sys.stderr, flush=True)
             cpu = cpu_baseline(args.version, C, H, ncls)
         tiles = world * B * args.steps
         line = {

@@ -99,6 +99,9 @@ class UnetEngine:
         if self.wgs is not None:
             b.set("WGS", self.wgs)
         if dout is not None:
+            need = 4 * int(torch.Size(self.plan.logits_shape).numel())
+            if dout.numel() * dout.element_size() < need:      # the backward program reads DOUT unchecked on the device
+                raise ValueError(f"DOUT holds {dout.numel() * dout.element_size()} bytes, the backward program reads {need}")
             b.set("DOUT", dout)
         if noise is not None:
             b.set("NOISE", noise)

@@ -46,6 +46,10 @@ class VitEngine:
         if self.wgs is not None:
             b.set("WGS", self.wgs)
         if dout is not None:
+            plan = self.plan
+            need = plan.dout_bytes if plan.dout_bytes else 4 * int(torch.Size(plan.dout_shape).numel())
+            if dout.numel() * dout.element_size() < need:      # the backward program reads DOUT unchecked on the device
+                raise ValueError(f"DOUT holds {dout.numel() * dout.element_size()} bytes, the backward program reads {need}")
             b.set("DOUT", dout)
         if grads is not None:
             b.set("GRADS", grads)

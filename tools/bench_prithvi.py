@@ -81,7 +81,8 @@ def main():
                 eng = e
         noise = torch.rand(max(eng.plan.noise_bytes // 4, 1), device=dev)
         out = torch.empty(eng.plan.out_bytes + 256, dtype=torch.uint8, device=dev)
-        dout = torch.ones(int(torch.tensor(eng.plan.dout_shape).prod()), device=dev) * 1e-3
+        n_dout = eng.plan.dout_bytes // 4 if eng.plan.dout_bytes else int(torch.Size(eng.plan.dout_shape).numel())
+        dout = torch.ones(max(n_dout, 1), device=dev) * 1e-3
         bases = eng.bases(model, x, out, noise, dout=dout, grads=model._grad_buffer())
         st = torch.cuda.current_stream().cuda_stream
         kinds = {}
