@@ -190,6 +190,7 @@ def _dw_geo(o):
 
 
 def op_dwconv_fwd(m: Mem, o):
+    _fold(m, o)
     B, C, H, W, K, S, pt, pl, Ho, Wo = _dw_geo(o)
     x = _pro(m.view(o["X"], (B, C, H, W)), m.view(o["BNV"], (4, C)), None, o["PRO"], C)
     w = m.view(o["WT"], (C, 1, K, K))
@@ -260,7 +261,15 @@ def op_bn_finalize(m: Mem, o):
     bnv[3] = invstd
 
 
+def _fold(m: Mem, o):
+    """BN_FINALIZE folded into the first consumer of its {scale, shift} (plan/opdefs.py FOLD_*): run it first."""
+    if o.get("FSTATS", -1) >= 0:
+        op_bn_finalize(m, {"STATS": o["FSTATS"], "GAMMA": o["FGAMMA"], "BETA": o["FBETA"], "RM": o["FRM"], "RV": o["FRV"], "BNV": o["BNV"],
+                           "COUNT": o["FCOUNT"], "C": o["C"], "TRAIN": 1, "NREP": o["FNREP"], "EPS": o["FEPS"], "MOM": o["FMOM"]})
+
+
 def op_se_pool(m: Mem, o):
+    _fold(m, o)
     B, C, HW = o["B"], o["C"], o["HW"]
     a = _pro(m.view(o["Y"], (B, C, HW, 1)), m.view(o["BNV"], (4, C)), None, o["PRO"], C)
     m.view(o["POOL"], (B, C)).copy_(a.view(B, C, HW).mean(2))
@@ -379,6 +388,7 @@ def op_bn_bwd_apply(m: Mem, o):
 
 
 def op_bn_residual(m: Mem, o):
+    _fold(m, o)
     B, C, HW = o["B"], o["C"], o["HW"]
     bnv = m.view(o["BNV"], (4, C))
     v = m.view(o["Y"], (B, C, HW)) * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)

@@ -169,6 +169,60 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 __device__ __forceinline__ void atomic_add_d(double* p, double v) { atomicAdd(p, v); }
 
+// ---- BN_FINALIZE folded into the first consumer of {scale, shift} (plan/opdefs.py FOLD_*) -------------------------------
+// Every workgroup (wave, thread) that needs a channel's {scale, shift} derives them from the statistics replicas itself -
+// the same arithmetic everywhere, so all of them agree bit for bit - and exactly one of them per channel (`writer`) stores
+// BNV = {scale, shift, mean, invstd}[C] for the later readers (the backward) and applies the running-statistics update.
+struct BnFold {
+    const double* stats;      // [nrep][2][C] sum / sum of squares; nullptr = not folded (BNV is read)
+    const float *gamma, *beta;
+    float *rm, *rv, *bnv;
+    double inv_count, unbias;  // 1 / count, count / max(count - 1, 1)
+    float eps, mom;
+    int nrep;
+};
+
+__device__ __forceinline__ void bn_fold_finish(const BnFold& f, int C, int c, double s, double q, bool writer, float& scale, float& shift) {
+    // mean and variance in f64 (the subtraction cancels), the reciprocal square root in f32: this runs once per WAVE of the
+    // consumer (B times per channel), and an f64 divide + square root there cost more than the launch it replaces
+    const double m = s * f.inv_count;
+    double var = fma(q, f.inv_count, -m * m);
+    if (var < 0.0) var = 0.0;
+    const float invstd = 1.0f / sqrtf((float)(var + (double)f.eps));
+    const float mean = (float)m;
+    scale = f.gamma[c] * invstd;
+    shift = f.beta[c] - mean * scale;
+    if (writer) {
+        const double unbiased = var * f.unbias;
+        f.rm[c] = (1.0f - f.mom) * f.rm[c] + f.mom * mean;
+        f.rv[c] = (1.0f - f.mom) * f.rv[c] + f.mom * (float)unbiased;
+        f.bnv[c] = scale;
+        f.bnv[C + c] = shift;
+        f.bnv[2 * C + c] = mean;
+        f.bnv[3 * C + c] = invstd;
+    }
+}
+// one thread per channel (replicas added in order)
+__device__ __forceinline__ void bn_fold_thread(const BnFold& f, int C, int c, bool writer, float& scale, float& shift) {
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < f.nrep; ++r) { s += f.stats[(int64_t)r * 2 * C + c]; q += f.stats[(int64_t)r * 2 * C + C + c]; }
+    bn_fold_finish(f, C, c, s, q, writer, scale, shift);
+}
+// one converged wave per channel (c wave-uniform); the result is in every lane, `writer` is honoured by lane 0
+__device__ __forceinline__ void bn_fold_wave(const BnFold& f, int C, int c, bool writer, float& scale, float& shift) {
+    const int lane = threadIdx.x & 63;
+    c = __builtin_amdgcn_readfirstlane(c);         // tell the compiler: scalar loads below
+    double s = 0.0, q = 0.0;
+    if (f.nrep <= 8) {       // wave-uniform addresses: scalar loads
+        for (int r = 0; r < f.nrep; ++r) { s += f.stats[(int64_t)r * 2 * C + c]; q += f.stats[(int64_t)r * 2 * C + C + c]; }
+    } else {
+        for (int r = lane; r < f.nrep; r += 64) { s += f.stats[(int64_t)r * 2 * C + c]; q += f.stats[(int64_t)r * 2 * C + C + c]; }
+        s = wave_sum_d(s);
+        q = wave_sum_d(q);
+    }
+    bn_fold_finish(f, C, c, s, q, writer && lane == 0, scale, shift);
+}
+
 // ---- host side --------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 
@@ -205,6 +259,33 @@ struct Ctx {
     int n_bases;
     hipStream_t stream;
 };
+
+// host side of BnFold: the five tensor refs FSTATS, FGAMMA, FBETA, FRM, FRV (consecutive t slots) + scalars of a stage record
+inline int fill_bn_fold(BnFold& f, const Ctx& c, const int64_t* t5, int64_t count, int nrep, float eps, float mom, float* bnv,
+                        const char* who) {
+    f = BnFold{};
+    if (t5[0] < 0) return S2K_OK;                       // not folded
+    void* ptr[5];
+    for (int i = 0; i < 5; ++i) {
+        const int64_t ref = t5[i];
+        const int base = (int)(ref >> 56);
+        if (ref < 0 || base >= c.n_bases || c.bases[base] == nullptr) { set_error("%s: folded BN_FINALIZE needs FSTATS, FGAMMA, FBETA, FRM, FRV", who); return S2K_EINVAL; }
+        ptr[i] = static_cast<char*>(c.bases[base]) + (ref & ((1ll << 56) - 1));
+    }
+    if (count <= 0 || !bnv || bnv == reinterpret_cast<float*>(1)) { set_error("%s: folded BN_FINALIZE needs FCOUNT > 0 and BNV", who); return S2K_EINVAL; }
+    f.stats = static_cast<const double*>(ptr[0]);
+    f.gamma = static_cast<const float*>(ptr[1]);
+    f.beta = static_cast<const float*>(ptr[2]);
+    f.rm = static_cast<float*>(ptr[3]);
+    f.rv = static_cast<float*>(ptr[4]);
+    f.bnv = bnv;
+    f.inv_count = 1.0 / (double)count;
+    f.unbias = (double)count / (count > 1 ? (double)(count - 1) : 1.0);
+    f.eps = eps;
+    f.mom = mom;
+    f.nrep = nrep > 0 ? nrep : 1;
+    return S2K_OK;
+}
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

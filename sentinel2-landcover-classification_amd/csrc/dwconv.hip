@@ -28,13 +28,14 @@ struct DwP {
     int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
     int vps_shift;                   // log2(pow2ceil(LW / 4)) capped at 6 (vector stager)
     int bloop, cgroups;              // wgrad on small planes: images per workgroup (0 = off), channel groups
+    BnFold fold;                     // fwd: BN_FINALIZE of the input's BatchNorm folded in (fold.stats != nullptr)
 };
 
 // Scalar stager (any width / column origin): rows [row0, row0 + nrows) x LW columns of PPB planes of `src` into
 // tile[pl][rr][LW]; element (rr, cc) is src row (row0 + rr), column (col0 + cc), zero outside the image.
 template <int PRO>
 __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int Hs, int Ws, float* tile, int64_t pl0,
-                                           int64_t nplanes, int nrows, int row0, int col0) {
+                                           int64_t nplanes, int nrows, int row0, int col0, const float* bnl = nullptr) {
     const rsrc_t rs = make_rsrc(src, nplanes * Hs * Ws * 4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lwp = 1 << p.lwp_shift;                 // pow2 >= LW (capped at 64)
@@ -50,9 +51,14 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
         const bool yok = rok && iy >= 0 && iy < Hs;
         float sc = 1.0f, sh = 0.0f;
         if (PRO != S2K_PRO_NONE) {
-            const int c = (int)((rok ? plane : 0) % p.C);
-            sc = p.bnv[c];
-            sh = p.bnv[p.C + c];
+            if (bnl) {           // folded BN_FINALIZE: this workgroup's own {scale, shift}[PPB] in LDS
+                sc = bnl[rok ? pl : 0];
+                sh = bnl[p.PPB + (rok ? pl : 0)];
+            } else {
+                const int c = (int)((rok ? plane : 0) % p.C);
+                sc = p.bnv[c];
+                sh = p.bnv[p.C + c];
+            }
         }
         const uint32_t rowoff = (uint32_t)((plane * Hs + iy) * Ws) * 4u;
         for (int cc = cc0; cc < p.LW; cc += lwp) {
@@ -70,7 +76,7 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
 // halo on the left and the columns past the row end are zeros (or real data where the source row is wider).
 template <int PRO>
 __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, int Hs, int Ws, float* tile, int64_t pl0,
-                                              int64_t nplanes, int nrows, int row0) {
+                                              int64_t nplanes, int nrows, int row0, const float* bnl = nullptr) {
     const rsrc_t rs = make_rsrc(src, nplanes * Hs * Ws * 4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int VPR = p.LW >> 2;                          // float4 slots per tile row
@@ -88,9 +94,14 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
         const bool yok = rok && iy >= 0 && iy < Hs;
         float sc = 1.0f, sh = 0.0f;
         if (PRO != S2K_PRO_NONE) {
-            const int c = (int)((rok ? plane : 0) % p.C);
-            sc = p.bnv[c];
-            sh = p.bnv[p.C + c];
+            if (bnl) {           // folded BN_FINALIZE: this workgroup's own {scale, shift}[PPB] in LDS
+                sc = bnl[rok ? pl : 0];
+                sh = bnl[p.PPB + (rok ? pl : 0)];
+            } else {
+                const int c = (int)((rok ? plane : 0) % p.C);
+                sc = p.bnv[c];
+                sh = p.bnv[p.C + c];
+            }
         }
         const uint32_t rowoff = (uint32_t)((plane * Hs + iy) * Ws) * 4u;
         for (int vi = v0; vi < VPR; vi += vps) {
@@ -144,7 +155,30 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
     const int band = blockIdx.x % p.bands;
     const int yo0 = band * p.RT;
     const int rows = min(p.RT, p.HO - yo0);
-    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT);
+    float* bnl = nullptr;
+    if (PRO != S2K_PRO_NONE && p.fold.stats) {
+        // BN_FINALIZE of the input's BatchNorm, for this workgroup's planes; the workgroup that holds sample 0 / band 0 of a
+        // channel publishes BNV and updates the running statistics
+        bnl = wsm + p.PPB * K * K;                    // [2][PPB]
+        if (p.PPB <= 4) {
+            if (wave < p.PPB) {
+                const int64_t plane = pl0 + wave;
+                float sc = 1.0f, sh = 0.0f;
+                if (plane < nplanes) bn_fold_wave(p.fold, p.C, (int)(plane % p.C), plane < p.C && band == 0, sc, sh);
+                if (lane == 0) { bnl[wave] = sc; bnl[p.PPB + wave] = sh; }
+            }
+        } else {
+            for (int pl = tid; pl < p.PPB; pl += NTHREADS) {
+                const int64_t plane = pl0 + pl;
+                float sc = 1.0f, sh = 0.0f;
+                if (plane < nplanes) bn_fold_thread(p.fold, p.C, (int)(plane % p.C), plane < p.C && band == 0, sc, sh);
+                bnl[pl] = sc;
+                bnl[p.PPB + pl] = sh;
+            }
+        }
+        __syncthreads();
+    }
+    stage_band_v4<PRO>(p, p.x, p.H, p.W, tile, pl0, nplanes, p.IRt, yo0 * S - p.PT, bnl);
     for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
         const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
@@ -636,10 +670,13 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (op.d[S2K_DWCONV_FWD_D_NREP] > 0) p.nrep = op.d[S2K_DWCONV_FWD_D_NREP];
     if (bad(p.x) || bad(p.bnv) || bad(p.w) || bad(p.out) || bad(p.stats)) { set_error("dwconv_fwd: null base"); return S2K_EFAULT; }
     if (!p.x || !p.w || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_fwd: missing tensor"); return S2K_EINVAL; }
+    if (int e = fill_bn_fold(p.fold, c, &op.t[S2K_DWCONV_FWD_T_FSTATS], op.n[S2K_DWCONV_FWD_N_FCOUNT], op.d[S2K_DWCONV_FWD_D_FNREP],
+                             op.f[S2K_DWCONV_FWD_F_FEPS], op.f[S2K_DWCONV_FWD_F_FMOM], const_cast<float*>(p.bnv), "dwconv_fwd")) return e;
+    if (p.fold.stats && p.pro == S2K_PRO_NONE) { set_error("dwconv_fwd: FSTATS without a prologue"); return S2K_EINVAL; }
     // tile columns: source column cc - 4; the widest window ends at 4 - PL + (4*XG - 1)*S + K - 1
     const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
     if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
-    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true, true);
+    const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true, true) + (p.fold.stats ? 2 * (size_t)p.PPB * sizeof(float) : 0);
     const bool silu = p.pro == S2K_PRO_SILU;
 #define DW_FWD(KK, SS, PP) (silu ? launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_SILU>, p, lds, c.stream) \
                                  : launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_NONE>, p, lds, c.stream))

@@ -219,7 +219,8 @@ int launch_bn_finalize(const S2kOp& op, const Ctx& c) {
 // MODE 2: out[c]    += sum g                        (CHANNEL_SUM, float atomics)
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, const float* y, const float* bnv,
-                                                                float* out, int C, int HW, int64_t nplanes, int pro) {
+                                                                float* out, int C, int HW, int64_t nplanes, int pro,
+                                                                const BnFold fold = BnFold{}) {
     const int lane = threadIdx.x & 63;
     int64_t plane;
     int start, count;
@@ -234,7 +235,8 @@ __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, 
     }
     const int c = (int)(plane % C);
     float scale = 1.0f, shift = 0.0f;
-    if (MODE != 2 && pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
+    if (MODE == 0 && fold.stats) bn_fold_wave(fold, C, c, plane < C, scale, shift);   // BN_FINALIZE folded in (one wave per plane)
+    else if (MODE != 2 && pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
     const int64_t base = plane * HW + start;
     float s = 0.0f;
     if (VEC) {
@@ -267,13 +269,13 @@ __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, 
 
 template <int MODE>
 static int launch_plane_reduce(const float* g, const float* y, const float* bnv, float* out, int B, int C, int HW, int pro,
-                               hipStream_t st) {
+                               hipStream_t st, const BnFold& fold = BnFold{}) {
     const int64_t nplanes = (int64_t)B * C;
     const unsigned blocks = (MODE == 2) ? task_blocks(HW, nplanes) : (unsigned)cdiv64(nplanes, 4);
     if ((HW & 3) == 0)
-        hipLaunchKernelGGL((plane_reduce_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro);
+        hipLaunchKernelGGL((plane_reduce_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro, fold);
     else
-        hipLaunchKernelGGL((plane_reduce_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro);
+        hipLaunchKernelGGL((plane_reduce_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, g, y, bnv, out, C, HW, nplanes, pro, fold);
     return S2K_OK;
 }
 
@@ -284,7 +286,11 @@ int launch_se_pool(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("se_pool", y, bnv, pool);
     const int pro = op.d[S2K_SE_POOL_D_PRO];
     if (!y || !pool || (pro && !bnv)) { set_error("se_pool: bad args"); return S2K_EINVAL; }
-    return launch_plane_reduce<0>(nullptr, y, bnv, pool, op.d[S2K_SE_POOL_D_B], op.d[S2K_SE_POOL_D_C], op.d[S2K_SE_POOL_D_HW], pro, c.stream);
+    BnFold fold;
+    if (int e = fill_bn_fold(fold, c, &op.t[S2K_SE_POOL_T_FSTATS], op.n[S2K_SE_POOL_N_FCOUNT], op.d[S2K_SE_POOL_D_FNREP], op.f[S2K_SE_POOL_F_FEPS],
+                             op.f[S2K_SE_POOL_F_FMOM], const_cast<float*>(bnv), "se_pool")) return e;
+    if (fold.stats && !pro) { set_error("se_pool: FSTATS without a prologue"); return S2K_EINVAL; }
+    return launch_plane_reduce<0>(nullptr, y, bnv, pool, op.d[S2K_SE_POOL_D_B], op.d[S2K_SE_POOL_D_C], op.d[S2K_SE_POOL_D_HW], pro, c.stream, fold);
 }
 
 int launch_se_bwd_reduce(const S2kOp& op, const Ctx& c) {
@@ -770,7 +776,7 @@ struct BnFuse {
 template <int MODE, bool VEC>
 __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, const float* y, const float* bnv, const float* coef,
                                                              const float* noise, float* out, int C, int HW, int64_t nplanes,
-                                                             float keep, const BnFuse fz) {
+                                                             float keep, const BnFuse fz, const BnFold fold = BnFold{}) {
     Task t;
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
@@ -807,7 +813,10 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     } else {
         float dcs = 1.0f;
         if (noise) dcs = floorf(keep + noise[(int)(t.plane / C)]) / keep;
-        k0 = a ? 1.0f : 0.0f; k1 = bnv[c] * dcs; k2 = bnv[C + c] * dcs;
+        float sc, sh;
+        if (fold.stats) bn_fold_wave(fold, C, c, t.plane < C && t.start == 0, sc, sh);   // BN_FINALIZE folded in (one wave per task)
+        else { sc = bnv[c]; sh = bnv[C + c]; }
+        k0 = a ? 1.0f : 0.0f; k1 = sc * dcs; k2 = sh * dcs;
     }
     const int64_t base = t.plane * HW + t.start;
     if (VEC) {
@@ -838,13 +847,13 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
 
 template <int MODE>
 static void launch_plane_map(const float* a, const float* y, const float* bnv, const float* coef, const float* noise, float* out,
-                             int B, int C, int HW, float keep, hipStream_t st, const BnFuse& fz = BnFuse{}) {
+                             int B, int C, int HW, float keep, hipStream_t st, const BnFuse& fz = BnFuse{}, const BnFold& fold = BnFold{}) {
     const int64_t nplanes = (int64_t)B * C;
     const unsigned blocks = task_blocks(HW, nplanes);
     if ((HW & 3) == 0)
-        hipLaunchKernelGGL((plane_map_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz);
+        hipLaunchKernelGGL((plane_map_kernel<MODE, true>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz, fold);
     else
-        hipLaunchKernelGGL((plane_map_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz);
+        hipLaunchKernelGGL((plane_map_kernel<MODE, false>), dim3(blocks), dim3(NTHREADS), 0, st, a, y, bnv, coef, noise, out, C, HW, nplanes, keep, fz, fold);
 }
 
 int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
@@ -892,8 +901,11 @@ int launch_bn_residual(const S2kOp& op, const Ctx& c) {
     float* xout = ref_ptr<float>(c, op.t[S2K_BN_RESIDUAL_T_XOUT]);
     CHECK_PTRS("bn_residual", y, bnv, ident, noise, xout);
     if (!y || !bnv || !xout) { set_error("bn_residual: bad args"); return S2K_EINVAL; }
+    BnFold fold;
+    if (int e = fill_bn_fold(fold, c, &op.t[S2K_BN_RESIDUAL_T_FSTATS], op.n[S2K_BN_RESIDUAL_N_FCOUNT], op.d[S2K_BN_RESIDUAL_D_FNREP],
+                             op.f[S2K_BN_RESIDUAL_F_FEPS], op.f[S2K_BN_RESIDUAL_F_FMOM], const_cast<float*>(bnv), "bn_residual")) return e;
     launch_plane_map<1>(ident, y, bnv, nullptr, noise, xout, op.d[S2K_BN_RESIDUAL_D_B], op.d[S2K_BN_RESIDUAL_D_C],
-                        op.d[S2K_BN_RESIDUAL_D_HW], op.f[S2K_BN_RESIDUAL_F_KEEP], c.stream);
+                        op.d[S2K_BN_RESIDUAL_D_HW], op.f[S2K_BN_RESIDUAL_F_KEEP], c.stream, BnFuse{}, fold);
     return S2K_OK;
 }
 

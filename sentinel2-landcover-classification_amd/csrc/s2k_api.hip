@@ -104,7 +104,13 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_DWCONV_FWD: return launch_dwconv_fwd(op, c);
         case S2K_OP_DWCONV_DGRAD: return launch_dwconv_dgrad(op, c);
         case S2K_OP_DWCONV_WGRAD: return launch_dwconv_wgrad(op, c);
-        case S2K_OP_BN_FINALIZE: return launch_bn_finalize(op, c);
+        case S2K_OP_BN_FINALIZE: {
+#ifdef S2K_TUNING
+            static const int skip = tune_int("S2K_EXP_SKIP_BN_FINALIZE", 0);   // timing experiment only: stale scale / shift
+            if (skip) return S2K_OK;
+#endif
+            return launch_bn_finalize(op, c);
+        }
         case S2K_OP_SE_POOL: return launch_se_pool(op, c);
         case S2K_OP_SE_FC: return launch_se_fc(op, c);
         case S2K_OP_SE_FC_BWD: return launch_se_fc_bwd(op, c);

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 from . import opdefs as D
 from .program import TRef
-from .unet_plan import Act, ParamLayout, UnetSpec, _P, _bn_backward, _conv_dgrad_wgrad, _stats, emit_encoder, fmap_block_indices, same_pads
+from .unet_plan import fold_bn_finalize, Act, ParamLayout, UnetSpec, _P, _bn_backward, _conv_dgrad_wgrad, _stats, emit_encoder, fmap_block_indices, same_pads
 from .vit_plan import MethodPlan, _method_plan, _Packer
 
 
@@ -78,4 +78,5 @@ def plan_encoder(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout:
             head.addbc, head.addscale = g_pool, 1.0 / HWh
 
         p.tape.append(cls_backward)
+    fold_bn_finalize(p.fwd)
     return _method_plan(p, spec, B, want_bwd, layout, xin, outs, nz, douts, dins, 8 << 20)

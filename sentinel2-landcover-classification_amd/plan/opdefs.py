@@ -37,6 +37,12 @@ ACT_MUL = 5                                                            # ACT_BWD
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
 FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream fork / join)
 
+# BN_FINALIZE folded into the first consumer of its {scale, shift} (a 5 us launch per BatchNorm otherwise: 126 per U-Net step):
+# the consumer's BNV becomes an OUTPUT computed from FSTATS (NREP replicas of {sum, sumsq}[C], FCOUNT elements per channel) with
+# FGAMMA / FBETA, and FRM / FRV receive the momentum update - the arithmetic of BN_FINALIZE with TRAIN = 1.
+FOLD_T, FOLD_N, FOLD_D, FOLD_F = ["FSTATS", "FGAMMA", "FBETA", "FRM", "FRV"], ["FCOUNT"], ["FNREP"], ["FEPS", "FMOM"]
+FOLD_KINDS = ("DWCONV_FWD", "SE_POOL", "BN_RESIDUAL")
+
 # kind -> (t slots, n slots, d slots, f slots); positional
 OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # zero `BYTES` bytes at DST
@@ -73,8 +79,11 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # GRADS[off + (m*C + c)*T + t] += WGS[off + (t*M + m)*C + c] for every TABLE entry {off, M, C, T, start}
     "WGRAD_FINALIZE": (["TABLE", "WGS", "GRADS"], ["TOTAL"], ["N_ENTRIES"], []),
     # depthwise KxK, TF-SAME pads, prologue on X, BN stats of Y
-    "DWCONV_FWD": (["X", "BNV", "WT", "Y", "STATS"], [],
-                   ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "NREP"], []),
+    # FSTATS given (training): BN_FINALIZE of the INPUT's BatchNorm is folded into this stage (see FOLD_T below) - every
+    # workgroup derives {scale, shift} of its channels from FSTATS itself, the first one of a channel also writes BNV and
+    # updates the running statistics
+    "DWCONV_FWD": (["X", "BNV", "WT", "Y", "STATS"] + FOLD_T, FOLD_N,
+                   ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "NREP"] + FOLD_D, FOLD_F),
     # G[b][c][iy][ix] (+)= (sum_taps W*DY) * act'(u), u = scale*XRAW+shift; STATS2 += {sum G, sum G*xhat}
     "DWCONV_DGRAD": (["DY", "WT", "XRAW", "BNV", "G", "STATS2"], [],
                      ["B", "C", "H", "W", "K", "STRIDE", "PAD_T", "PAD_L", "HO", "WO", "PRO", "BETA", "NREP"], []),
@@ -84,7 +93,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # BNV = {scale, shift, mean, invstd}[C]; TRAIN: from STATS + running-stat update; else from RM/RV
     "BN_FINALIZE": (["STATS", "GAMMA", "BETA", "RM", "RV", "BNV"], ["COUNT"], ["C", "TRAIN", "NREP"], ["EPS", "MOM"]),
     # POOL[b][c] = mean_hw act(scale*Y+shift)
-    "SE_POOL": (["Y", "BNV", "POOL"], [], ["B", "C", "HW", "PRO"], []),
+    "SE_POOL": (["Y", "BNV", "POOL"] + FOLD_T, FOLD_N, ["B", "C", "HW", "PRO"] + FOLD_D, FOLD_F),
     # HPRE = W1 pool + B1; GATE = sigmoid(W2 silu(HPRE) + B2)
     "SE_FC": (["POOL", "W1", "B1", "W2", "B2", "HPRE", "GATE"], [], ["B", "C", "CSQ"], []),
     # DGATE is overwritten with d(pre-sigmoid), HPRE with d(pre-SiLU); HS = scratch [B][CSQ] for silu(HPRE).
@@ -108,7 +117,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC"], ["COUNT"],
                      ["B", "C", "HW", "NREP", "ACT", "EVAL"], ["ADDSCALE"]),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
-    "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"], [], ["B", "C", "HW"], ["KEEP"]),
+    "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"] + FOLD_T, FOLD_N, ["B", "C", "HW"] + FOLD_D, ["KEEP"] + FOLD_F),
     # OUT[c] += sum_{b,hw} G[b][c][hw]
     "CHANNEL_SUM": (["G", "OUT"], [], ["B", "C", "HW"], []),
     # per-pixel CE / focal (losses.py:24-89): LOSS[0] = value; LABELS int64; ALPHA float[C] class weights

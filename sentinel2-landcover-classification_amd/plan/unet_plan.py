@@ -798,6 +798,43 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
     return segments, bwd
 
 
+def fold_bn_finalize(prog: Program) -> int:
+    """Peephole over a forward program: a training BN_FINALIZE whose {scale, shift} are first read by a depthwise conv, an SE
+    pool or a BN_RESIDUAL is folded INTO that stage (opdefs.FOLD_*: every workgroup derives the two numbers of its channels
+    from the statistics itself, one of them publishes BNV and updates the running statistics) and its own 5-us launch
+    disappears - 117 of the 126 per U-Net-b5 step, 0.9 ms of a 38.5 ms step.  Returns the number of folded stages."""
+    if tune("S2K_FOLD_BN", "1") != "1":
+        return 0
+    ops = prog.ops
+    folded = 0
+    i = 0
+    while i < len(ops):
+        kind, f = ops[i]
+        if kind != "BN_FINALIZE" or not f.get("TRAIN") or f.get("_flags"):
+            i += 1
+            continue
+        bnv = f["BNV"]
+        touched = {t.ref for k in ("BNV", "RM", "RV", "STATS") if isinstance(t := f.get(k), TRef)}
+        target = None
+        for j in range(i + 1, len(ops)):
+            k2, f2 = ops[j]
+            refs = {v.ref for v in f2.values() if isinstance(v, TRef)}
+            if not (refs & touched):
+                continue
+            if (k2 in D.FOLD_KINDS and isinstance(f2.get("BNV"), TRef) and f2["BNV"].ref == bnv.ref and f2.get("FSTATS") is None
+                    and f2.get("C") == f["C"] and f2.get("PRO", 1) and len(refs & touched) == 1 and not f2.get("_flags")):
+                target = j
+            break
+        if target is None:
+            i += 1
+            continue
+        ops[target][1].update(FSTATS=f["STATS"], FGAMMA=f["GAMMA"], FBETA=f["BETA"], FRM=f["RM"], FRV=f["RV"], FCOUNT=f["COUNT"],
+                              FNREP=f["NREP"], FEPS=f["EPS"], FMOM=f["MOM"])
+        del ops[i]
+        folded += 1
+    return folded
+
+
 def fmap_block_indices(spec: UnetSpec, H: int, W: int) -> list[int]:
     """Blocks whose output EfficientNet.encode collects: the first block at each new spatial size, deepest first, without the
     size of the conv_head output (reference :255-260 with the (7, 7) literal generalised)."""
@@ -902,6 +939,7 @@ def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: Pa
     logits = out_conv(p, "out_conv1x1.weight", "out_conv1x1.bias", cur, spec.num_classes)
 
     segments, bwd = finish_plan(p, layout, training, bucket_floats)
+    fold_bn_finalize(p.fwd)
 
     return UnetPlan(spec, B, H, W, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, len(spec.blocks),
                     segments if p.want_bwd else [], (B, spec.num_classes, H, W), p.tensors, p.wpack.mark())

@@ -677,3 +677,47 @@ def test_wgrad_1x1_thin_large_map(M, C, pro):
     wgs = c.t("wgs", (1, M, C), "zeros")
     c.run("WGRAD", ["wgs"], 3e-4, P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bnv, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=W,
           KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=W, PROP=D.PRO_NONE, PROQ=pro, MODE=D.MODE_CONV)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BN_FINALIZE folded into the first consumer of its {scale, shift} (opdefs.FOLD_*)
+# ---------------------------------------------------------------------------------------------------
+def _fold_fields(c: "Case", C: int, n: int, nrep: int):
+    """Statistics replicas of a plausible batch + affine parameters + running statistics; BNV starts as NaN (it is an output)."""
+    mean = torch.randn(C, dtype=torch.float64, generator=c.gen) * 0.5
+    var = torch.rand(C, dtype=torch.float64, generator=c.gen) + 0.2
+    full = torch.stack([mean * n, (var + mean * mean) * n])
+    parts = torch.rand(nrep, 2, C, dtype=torch.float64, generator=c.gen) + 0.5
+    parts = parts / parts.sum(0, keepdim=True) * full
+    f = dict(FSTATS=c.t("fstats", (nrep, 2, C), parts, "f64"), FGAMMA=c.t("fgamma", (C,), "pos"), FBETA=c.t("fbeta", (C,)),
+             FRM=c.t("frm", (C,)), FRV=c.t("frv", (C,), "pos"), FCOUNT=n, FNREP=nrep, FEPS=1e-3, FMOM=0.01)
+    return f, c.t("bnv", (4, C), "nan")
+
+
+@pytest.mark.parametrize("geo", [(2, 48, 32, 32, 3, 1), (2, 20, 17, 17, 5, 2), (3, 600, 8, 8, 5, 1), (1, 70, 64, 64, 3, 2), (4, 7, 4, 4, 3, 1)])
+def test_dwconv_fwd_with_folded_bn_finalize(geo):
+    B, C, H, W, K, S = geo
+    g, Ho, Wo = _dw_geo(*geo)
+    c = Case(31)
+    x = c.t("x", (B, C, H, W))
+    w = c.t("w", (C, K, K), scale=0.3)
+    y = c.t("y", (B, C, Ho, Wo), "nan")
+    nrep = D.stats_replicas(C)
+    st = c.t("stats", (nrep, 2, C), "zeros", "f64")
+    fold, bnv = _fold_fields(c, C, B * H * W, nrep)
+    c.run("DWCONV_FWD", ["y", "stats", "bnv", "frm", "frv"], 1e-4, sum0=("stats",), X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=2, NREP=nrep, **fold, **g)
+
+
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (2, 3000, 64)])
+def test_se_pool_and_bn_residual_with_folded_bn_finalize(B, C, HW):
+    c = Case(32)
+    y = c.t("y", (B, C, HW))
+    pool = c.t("pool", (B, C), "nan")
+    fold, bnv = _fold_fields(c, C, B * HW, D.stats_replicas(C))
+    c.run("SE_POOL", ["pool", "bnv", "frm", "frv"], 1e-5, Y=y, BNV=bnv, POOL=pool, B=B, C=C, HW=HW, PRO=2, **fold)
+    c = Case(33)
+    y = c.t("y", (B, C, HW))
+    idt, nz = c.t("ident", (B, C, HW)), c.t("noise", (B,), "rand")
+    out = c.t("xout", (B, C, HW), "nan")
+    fold, bnv = _fold_fields(c, C, B * HW, D.stats_replicas(C))
+    c.run("BN_RESIDUAL", ["xout", "bnv", "frm", "frv"], 1e-5, Y=y, BNV=bnv, IDENT=idt, NOISE=nz, XOUT=out, B=B, C=C, HW=HW, KEEP=0.55, **fold)

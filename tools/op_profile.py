@@ -38,7 +38,7 @@ def main():
     for tag, packed, bases in (("fwd", eng.fwd, eng.bases(model, x, out, noise=noise)),
                                ("bwd", eng.bwd, eng.bases(model, x, None, dout=dout, noise=noise, grads=grads))):
         _lib.profile_ops(packed, bases, st)
-        ms = _lib.profile_ops(packed, bases, st)
+        ms, var = _lib.profile_variants(packed, bases, st)
         rows = []
         for i, rec in enumerate(packed):
             kind = names[int(rec["kind"])]
@@ -46,13 +46,17 @@ def main():
                 continue
             d = rec["d"]
             if kind == "CONV":
-                g = {k: int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "M", "KH", "H", "W", "HO", "WO", "MODE", "STRIDE")}
+                g = {k: int(d[D.slot("CONV", k)[1]]) for k in ("B", "C1", "C2", "M", "KH", "H", "W", "HO", "WO", "MODE", "STRIDE", "PRO1", "PRO2")}
                 fl = 2.0 * g["M"] * (g["C1"] + g["C2"]) * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
-                desc = f"M={g['M']:5d} C={g['C1']}+{g['C2']} k{g['KH']} s{g['STRIDE']} {g['HO']}x{g['WO']} mode{g['MODE']}"
+                gate = int(rec["t"][D.slot("CONV", "GATE1")[1]]) >= 0
+                desc = (f"M={g['M']:5d} C={g['C1']}+{g['C2']} k{g['KH']} s{g['STRIDE']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PRO1']}{g['PRO2']}"
+                        f"{' gate' if gate else ''} {'PC' if var[i] else 'generic'}")
             elif kind == "WGRAD":
-                g = {k: int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "KH", "HO", "WO", "MODE")}
+                g = {k: int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "KH", "HO", "WO", "MODE", "PROP", "PROQ")}
                 fl = 2.0 * g["M"] * g["C"] * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
-                desc = f"M={g['M']:5d} C={g['C']} k{g['KH']} {g['HO']}x{g['WO']} mode{g['MODE']}"
+                gate = int(rec["t"][D.slot("WGRAD", "GATEP")[1]]) >= 0 or int(rec["t"][D.slot("WGRAD", "GATEQ")[1]]) >= 0
+                desc = (f"M={g['M']:5d} C={g['C']} k{g['KH']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PROP']}{g['PROQ']}"
+                        f"{' gate' if gate else ''} {'PC' if var[i] else 'generic'}")
             else:
                 fl, desc = 0.0, " ".join(str(int(v)) for v in d[:11])
             rows.append((float(ms[i]), tag, i, kind, desc, fl))
@@ -61,7 +65,7 @@ def main():
         print(f"== {tag}: {tot:.2f} ms in {len(rows)} stages of kinds {sorted(kinds)}")
         for t, tg, i, kind, desc, fl in rows[: a.top]:
             tf = fl / (t * 1e-3) / 1e12 if t > 0 and fl else 0.0
-            print(f"{t:8.3f} ms  {tg} #{i:4d} {kind:14s} {desc:60s} {tf:7.1f} TF/s")
+            print(f"{t:8.3f} ms  {tg} #{i:4d} {kind:14s} {desc:78s} {tf:7.1f} TF/s")
 
 
 if __name__ == "__main__":
