@@ -183,12 +183,16 @@ struct BnFold {
 };
 
 __device__ __forceinline__ void bn_fold_finish(const BnFold& f, int C, int c, double s, double q, bool writer, float& scale, float& shift) {
-    // mean and variance in f64 (the subtraction cancels), the reciprocal square root in f32: this runs once per WAVE of the
-    // consumer (B times per channel), and an f64 divide + square root there cost more than the launch it replaces
+    // mean and variance in f64 (the subtraction cancels).  This runs once per WAVE of the consumer (B times per channel), where
+    // an f64 divide + square root cost more than the launch they replace: the reciprocal square root is an f32 estimate plus
+    // one Newton step in f64 (relative error ~1e-14 before the rounding to f32, i.e. the value BN_FINALIZE's 1 / sqrt gives)
     const double m = s * f.inv_count;
     double var = fma(q, f.inv_count, -m * m);
     if (var < 0.0) var = 0.0;
-    const float invstd = 1.0f / sqrtf((float)(var + (double)f.eps));
+    const double xx = var + (double)f.eps;
+    double yy = (double)rsqrtf((float)xx);
+    yy = yy * (1.5 - 0.5 * xx * yy * yy);
+    const float invstd = (float)yy;
     const float mean = (float)m;
     scale = f.gamma[c] * invstd;
     shift = f.beta[c] - mean * scale;
