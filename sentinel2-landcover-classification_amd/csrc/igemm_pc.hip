@@ -21,12 +21,16 @@
 
 namespace s2k {
 
-template <int BMODE, int WM, int KCH, int R, int XW, int PRO>
+// THIN (3x3 only): M <= 32 - one 32-row m-tile shared by the four consumer waves, which split a 256-pixel tile 1 (m) x 4 (n)
+// (the decoder's full-resolution 32-channel convs and their data gradients: a quarter of a 128-row tile would be padding)
+template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false>
 __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
     constexpr int NT = 256;
     constexpr int TT = (BMODE == BM_PIX) ? 1 : 9;
     constexpr int WN = 2;
-    constexpr int BM = WM * 64, BN = 128;
+    constexpr int BM = THIN ? 32 : WM * 64, BN = THIN ? 256 : 128;
+    constexpr int NWCOL = THIN ? 4 : 2;                    // wave columns (n) of the consumer grid
+    static_assert(!THIN || (WM == 1 && BMODE == BM_SPATIAL), "thin tiles: 3x3, one m-tile of 32 rows");
     constexpr int KT = KCH * TT;                           // rows of an A chunk
     constexpr int WS = XW + 2, IR = R + 2;                 // 3x3 stride-1 halo tile
     constexpr int USED = IR * WS;
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
         // CONSUMER
         // =================================================================================================================
         __builtin_amdgcn_s_setprio(2);
-        const int wm0 = (wave >> 1) * (WM * 32), wn0 = (wave & 1) * (WN * 32);
+        const int wm0 = THIN ? 0 : (wave >> 1) * (WM * 32), wn0 = (THIN ? wave : (wave & 1)) * (WN * 32);
         int boff[WN];
 #pragma unroll
         for (int rn = 0; rn < WN; ++rn) {
@@ -256,8 +260,8 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
             }
         }
         __syncthreads();                                            // (E1) every wave is done with the LDS image
-        float* srow = smem;                                         // [2 n-columns of waves][2][BM]
-        const int wn_idx = wave & 1;
+        float* srow = smem;                                         // [NWCOL n-columns of waves][2][BM]
+        const int wn_idx = THIN ? wave : (wave & 1);
 #pragma unroll
         for (int rm = 0; rm < WM; ++rm)
 #pragma unroll
@@ -299,23 +303,24 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
         double* st = p.stats + (int64_t)(tile % p.nrep) * 2 * p.M;
         for (int i = threadIdx.x; i < 2 * BM; i += 2 * NT) {
             const int row = i % BM, which = i / BM, gm = m0 + row;
-            const float tot = srow[(0 * 2 + which) * BM + row] + srow[(1 * 2 + which) * BM + row];
+            float tot = srow[(0 * 2 + which) * BM + row] + srow[(1 * 2 + which) * BM + row];
+            if (NWCOL == 4) tot += srow[(2 * 2 + which) * BM + row] + srow[(3 * 2 + which) * BM + row];
             if (gm < p.M) atomic_add_d(st + which * p.M + gm, (double)tot);
         }
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int BMODE, int WM, int KCH, int R, int XW, int PRO>
+template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false>
 static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr int TT = (BMODE == BM_PIX) ? 1 : 9;
-    constexpr int BM = WM * 64;
+    constexpr int BM = THIN ? 32 : WM * 64;
     constexpr int USED = (R + 2) * (XW + 2);
     constexpr int CSB = (BMODE == BM_PIX) ? 128 : USED;
     constexpr int BUF = (KCH * TT * BM + KCH * CSB + 3) & ~3;
     constexpr size_t lds = (size_t)2 * BUF * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS image");
-    static_assert(4 * BM * sizeof(float) <= lds, "statistics rows fit in the image");
+    static_assert((THIN ? 8 : 4) * BM * sizeof(float) <= lds, "statistics rows fit in the image");
     p.n_mtiles = cdiv(p.M, BM);
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
         const bool local = BMODE == BM_SPATIAL || (p.HW % 128) == 0;
@@ -327,7 +332,7 @@ static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
     p.n_tiles = (int)blocks;
     p.splits = 1;
-    auto kern = conv_pc_kernel<BMODE, WM, KCH, R, XW, PRO>;
+    auto kern = conv_pc_kernel<BMODE, WM, KCH, R, XW, PRO, THIN>;
     static PerDeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -348,6 +353,19 @@ int launch_conv_pc(ConvP& p, hipStream_t st) {
     if (p.mode != S2K_MODE_CONV || p.S != 1 || p.gate1) return 1;
     if (p.pro1 != S2K_PRO_NONE && p.pro1 != S2K_PRO_RELU) return 1;
     if (p.C2 > 0 && p.pro2 != p.pro1) return 1;
+    if (p.M <= 32 && p.KH == 3 && p.KW == 3) {                        // thin 3x3: one 32-row m-tile, 4 x 64 pixel tiles
+        static const int thin = tune_int("S2K_CONV_PC_THIN", 1);
+        if (!thin || p.HO != p.H || p.WO != p.W || p.PT != 1 || p.PL != 1 || p.WO % 64 != 0 || p.M < 20) return 1;
+        p.R = 4; p.XW = 64; p.IR = 6; p.IC = 66; p.WS = 66; p.CS = 6 * 66;
+        p.tiles_x = p.WO / 64;
+        p.tiles_y = cdiv(p.HO, 4);
+        const int n = p.B * p.tiles_x * p.tiles_y;
+        if (n < 512) return 1;
+        static const int kch = tune_int("S2K_CONV_PC_THIN_KCH", 4);
+        const bool relu = p.pro1 == S2K_PRO_RELU;
+        if (kch == 8) return relu ? launch_pc<BM_SPATIAL, 1, 8, 4, 64, S2K_PRO_RELU, true>(p, n, st) : launch_pc<BM_SPATIAL, 1, 8, 4, 64, S2K_PRO_NONE, true>(p, n, st);
+        return relu ? launch_pc<BM_SPATIAL, 1, 4, 4, 64, S2K_PRO_RELU, true>(p, n, st) : launch_pc<BM_SPATIAL, 1, 4, 4, 64, S2K_PRO_NONE, true>(p, n, st);
+    }
     if (p.M < 48) return 1;                                           // thin layers: the wide-pixel tiles of igemm.hip
     // tile height: 128 unless it pads M by more than 12 %
     const int bm = ((double)cdiv(p.M, 128) * 128 / p.M <= 1.12) ? 128 : 64;

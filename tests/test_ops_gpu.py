@@ -188,6 +188,9 @@ def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
     (4, 16, 8, 30, 56, 72, 0, 0),        # (2, 56) (224-pixel inputs), odd row count, K tail (24 channels = 3 chunks)
     (12, 32, 0, 28, 28, 64, 3, 0),       # (4, 28)
     (40, 64, 0, 14, 14, 128, 0, 0),      # (8, 14)
+    (32, 32, 13, 64, 64, 32, 0, 0),      # thin (M <= 32): 4 x 64 pixel tiles, consumers 1 x 4; concat with the raw input bands
+    (32, 32, 0, 64, 64, 32, 3, 0),       # thin, BatchNorm + ReLU prologue
+    (36, 64, 0, 62, 128, 24, 0, 1),      # thin, M = 24, ragged last tile row, accumulate
 ])
 def test_conv3x3_producer_consumer(B, C1, C2, H, W, M, pro, beta):
     # (statistics + accumulate never occur together in a plan; the oracle takes the statistics before the accumulate)
