@@ -267,6 +267,37 @@ __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, 
     }
 }
 
+// Small planes (HW <= 256, the 16x16 and 8x8 stages where C is in the hundreds or thousands): one wave per CHANNEL walks
+// the batch - LPP = pow2ceil(HW / 4) lanes hold one plane as float4s, 64 / LPP planes (samples) per pass.  {scale, shift}
+// (from BNV, or from the statistics when BN_FINALIZE is folded in) are formed once per channel instead of once per (b, c)
+// plane: with one wave per plane the folded arithmetic cost more than the 64-element plane itself.
+__global__ void __launch_bounds__(NTHREADS) se_pool_small_kernel(const float* y, const float* bnv, float* out, int B, int C, int HW,
+                                                                 int pro, int lpp, const BnFold fold) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float scale = 1.0f, shift = 0.0f;
+    if (fold.stats) bn_fold_wave(fold, C, c, blockIdx.y == 0, scale, shift);
+    else if (pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
+    const int pp = 64 / lpp, sub = lane / lpp, li = lane & (lpp - 1);
+    const bool in = 4 * li < HW;
+    const float inv = 1.0f / (float)HW;
+    const int bper = (B + gridDim.y - 1) / gridDim.y, b_lo = blockIdx.y * bper;
+    B = min(B, b_lo + bper);
+    for (int b0 = b_lo; b0 < B; b0 += pp) {
+        const int b = b0 + sub;
+        float s = 0.0f;
+        if (b < B && in) {
+            float4 v = *reinterpret_cast<const float4*>(y + ((int64_t)b * C + c) * HW + 4 * li);
+            v.x = apply_pro(v.x, pro, scale, shift); v.y = apply_pro(v.y, pro, scale, shift);
+            v.z = apply_pro(v.z, pro, scale, shift); v.w = apply_pro(v.w, pro, scale, shift);
+            s = (v.x + v.y) + (v.z + v.w);
+        }
+        s = group_sum(s, lpp);
+        if (li == 0 && b < B) out[(int64_t)b * C + c] = s * inv;
+    }
+}
+
 template <int MODE>
 static int launch_plane_reduce(const float* g, const float* y, const float* bnv, float* out, int B, int C, int HW, int pro,
                                hipStream_t st, const BnFold& fold = BnFold{}) {
@@ -290,6 +321,16 @@ int launch_se_pool(const S2kOp& op, const Ctx& c) {
     if (int e = fill_bn_fold(fold, c, &op.t[S2K_SE_POOL_T_FSTATS], op.n[S2K_SE_POOL_N_FCOUNT], op.d[S2K_SE_POOL_D_FNREP], op.f[S2K_SE_POOL_F_FEPS],
                              op.f[S2K_SE_POOL_F_FMOM], const_cast<float*>(bnv), "se_pool")) return e;
     if (fold.stats && !pro) { set_error("se_pool: FSTATS without a prologue"); return S2K_EINVAL; }
+    {
+        const int B = op.d[S2K_SE_POOL_D_B], C = op.d[S2K_SE_POOL_D_C], HW = op.d[S2K_SE_POOL_D_HW];
+        if (HW <= 256 && (HW & 3) == 0 && B > 1) {
+            int lpp = 1;
+            while (4 * lpp < HW) lpp <<= 1;
+            const int bsplit = std::max(1, std::min(cdiv(B, 64 / lpp), cdiv(2048, C)));     // >= ~2048 waves in all
+            hipLaunchKernelGGL(se_pool_small_kernel, dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, c.stream, y, bnv, pool, B, C, HW, pro, lpp, fold);
+            return S2K_OK;
+        }
+    }
     return launch_plane_reduce<0>(nullptr, y, bnv, pool, op.d[S2K_SE_POOL_D_B], op.d[S2K_SE_POOL_D_C], op.d[S2K_SE_POOL_D_HW], pro, c.stream, fold);
 }
 
@@ -845,6 +886,35 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     }
 }
 
+// BN_RESIDUAL on small planes: one wave per channel walks the batch (see se_pool_small_kernel)
+__global__ void __launch_bounds__(NTHREADS) bn_residual_small_kernel(const float* ident, const float* y, const float* bnv, const float* noise,
+                                                                     float* out, int B, int C, int HW, float keep, int lpp,
+                                                                     const BnFold fold) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float sc, sh;
+    if (fold.stats) bn_fold_wave(fold, C, c, blockIdx.y == 0, sc, sh);
+    else { sc = bnv[c]; sh = bnv[C + c]; }
+    const int pp = 64 / lpp, sub = lane / lpp, li = lane & (lpp - 1);
+    if (4 * li >= HW) return;
+    const int bper = (B + gridDim.y - 1) / gridDim.y, b_lo = blockIdx.y * bper;
+    B = min(B, b_lo + bper);
+    for (int b = b_lo + sub; b < B; b += pp) {
+        float dcs = 1.0f;
+        if (noise) dcs = floorf(keep + noise[b]) / keep;
+        const float k1 = sc * dcs, k2 = sh * dcs;
+        const int64_t off = ((int64_t)b * C + c) * HW + 4 * li;
+        const float4 yv = *reinterpret_cast<const float4*>(y + off);
+        float4 av = make_float4(0, 0, 0, 0);
+        if (ident) av = *reinterpret_cast<const float4*>(ident + off);
+        float4 o;
+        o.x = av.x + fmaf(k1, yv.x, k2); o.y = av.y + fmaf(k1, yv.y, k2);
+        o.z = av.z + fmaf(k1, yv.z, k2); o.w = av.w + fmaf(k1, yv.w, k2);
+        *reinterpret_cast<float4*>(out + off) = o;
+    }
+}
+
 template <int MODE>
 static void launch_plane_map(const float* a, const float* y, const float* bnv, const float* coef, const float* noise, float* out,
                              int B, int C, int HW, float keep, hipStream_t st, const BnFuse& fz = BnFuse{}, const BnFold& fold = BnFold{}) {
@@ -904,6 +974,17 @@ int launch_bn_residual(const S2kOp& op, const Ctx& c) {
     BnFold fold;
     if (int e = fill_bn_fold(fold, c, &op.t[S2K_BN_RESIDUAL_T_FSTATS], op.n[S2K_BN_RESIDUAL_N_FCOUNT], op.d[S2K_BN_RESIDUAL_D_FNREP],
                              op.f[S2K_BN_RESIDUAL_F_FEPS], op.f[S2K_BN_RESIDUAL_F_FMOM], const_cast<float*>(bnv), "bn_residual")) return e;
+    {
+        const int B = op.d[S2K_BN_RESIDUAL_D_B], C = op.d[S2K_BN_RESIDUAL_D_C], HW = op.d[S2K_BN_RESIDUAL_D_HW];
+        if (HW <= 256 && (HW & 3) == 0 && B > 1) {
+            int lpp = 1;
+            while (4 * lpp < HW) lpp <<= 1;
+            const int bsplit = std::max(1, std::min(cdiv(B, 64 / lpp), cdiv(2048, C)));
+            hipLaunchKernelGGL(bn_residual_small_kernel, dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, c.stream, ident, y, bnv, noise, xout, B, C, HW,
+                               op.f[S2K_BN_RESIDUAL_F_KEEP], lpp, fold);
+            return S2K_OK;
+        }
+    }
     launch_plane_map<1>(ident, y, bnv, nullptr, noise, xout, op.d[S2K_BN_RESIDUAL_D_B], op.d[S2K_BN_RESIDUAL_D_C],
                         op.d[S2K_BN_RESIDUAL_D_HW], op.f[S2K_BN_RESIDUAL_F_KEEP], c.stream, BnFuse{}, fold);
     return S2K_OK;

@@ -445,7 +445,8 @@ def test_bn_backward_trio(B, C, HW, variant):
                DBETA=db, COUNT=B * HW, B=B, C=C, HW=HW, NREP=nrep)
 
 
-@pytest.mark.parametrize("B,C,HW,ident,noise", [(2, 24, 256, True, True), (3, 10, 49, False, False), (1, 3, 9000, True, False)])
+@pytest.mark.parametrize("B,C,HW,ident,noise", [(2, 24, 256, True, True), (3, 10, 49, False, False), (1, 3, 9000, True, False),
+                                                 (9, 70, 64, True, True), (40, 5, 100, False, True)])
 def test_bn_residual(B, C, HW, ident, noise):
     c = Case(9)
     y, bnv = c.t("y", (B, C, HW)), c.bnv("bnv", C)
@@ -455,7 +456,7 @@ def test_bn_residual(B, C, HW, ident, noise):
     c.run("BN_RESIDUAL", ["xout"], 1e-6, Y=y, BNV=bnv, IDENT=idt, NOISE=nz, XOUT=out, B=B, C=C, HW=HW, KEEP=0.55)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000)])
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (11, 130, 64), (3, 7, 36)])
 def test_se_pool_bwd_reduce_channel_sum(B, C, HW):
     c = Case(10)
     y, bnv = c.t("y", (B, C, HW)), c.bnv("bnv", C)
@@ -711,7 +712,7 @@ def test_dwconv_fwd_with_folded_bn_finalize(geo):
     c.run("DWCONV_FWD", ["y", "stats", "bnv", "frm", "frv"], 1e-4, sum0=("stats",), X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=2, NREP=nrep, **fold, **g)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (2, 3000, 64)])
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (2, 3000, 64), (7, 100, 64), (33, 9, 16), (5, 300, 196)])
 def test_se_pool_and_bn_residual_with_folded_bn_finalize(B, C, HW):
     c = Case(32)
     y = c.t("y", (B, C, HW))
