@@ -204,120 +204,6 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
     }
 }
 
-// Two-kernel backward (used when the stage carries a scratch tensor SCR [LN_NP][B*HW][2]): the single kernel above keeps one
-// workgroup per 64-position tile (64 workgroups for the ViT encoder's 50-token planes) and pays two wave reductions per
-// (channel, tile) for the parameter gradients - 105 us against a 10-26 us HBM bound.
-//   stats:  workgroup = (tile, channel slab q of LN_NP): partial sums of g and g * xhat over the slab -> SCR[q]
-//   apply:  workgroup = (slab of 4 * LN_CPW channels, group of tiles): DX, and the parameter sums held PER LANE in registers
-//           across the group's tiles - one wave reduction per channel per workgroup at the end.
-constexpr int LN_NP = 8;
-constexpr int LN_CPW = 8;
-
-__global__ void __launch_bounds__(256) chan_ln_bwd_stats_kernel(const LnP p, float* scr) {
-    __shared__ float red[4][64][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = blockIdx.x % LN_NP;
-    const int64_t tile = blockIdx.x / LN_NP;
-    const int b = (int)(tile / p.tiles_per_b);
-    const int hw = (int)(tile - (int64_t)b * p.tiles_per_b) * 64 + lane;
-    const bool ok = hw < p.HW;
-    const int slab = (p.C + LN_NP - 1) / LN_NP, c_lo = q * slab, c_hi = min(c_lo + slab, p.C);
-    const int64_t base = (int64_t)b * p.C * p.HW + (ok ? hw : 0);
-    float mean = 0.0f, rstd = 0.0f;
-    if (ok) {
-        const float* mr = p.mr_in + ((int64_t)b * p.HW + hw) * 2;
-        mean = mr[0];
-        rstd = mr[1];
-    }
-    float s1 = 0.0f, s2 = 0.0f;
-    for (int c0 = c_lo + wave; c0 < c_hi; c0 += 4 * LN_U) {
-        float dv[LN_U], xv[LN_U];
-#pragma unroll
-        for (int u = 0; u < LN_U; ++u) {
-            const int64_t off = base + (int64_t)min(c0 + 4 * u, p.C - 1) * p.HW;   // clamped: loads never sit under a condition
-            dv[u] = p.dy[off];
-            xv[u] = p.x[off];
-        }
-#pragma unroll
-        for (int u = 0; u < LN_U; ++u) {
-            const int c = c0 + 4 * u;
-            const float g = (ok && c < c_hi) ? dv[u] * p.gamma[min(c, p.C - 1)] : 0.0f;
-            s1 += g;
-            s2 = fmaf(g, (xv[u] - mean) * rstd, s2);
-        }
-    }
-    red[wave][lane][0] = s1;
-    red[wave][lane][1] = s2;
-    __syncthreads();
-    if (wave == 0 && ok) {
-        float* o = scr + ((int64_t)q * p.B * p.HW + (int64_t)b * p.HW + hw) * 2;
-        o[0] = (red[0][lane][0] + red[1][lane][0]) + (red[2][lane][0] + red[3][lane][0]);
-        o[1] = (red[0][lane][1] + red[1][lane][1]) + (red[2][lane][1] + red[3][lane][1]);
-    }
-}
-
-__global__ void __launch_bounds__(256) chan_ln_bwd_apply_kernel(const LnP p, const float* scr, int tiles_per_group) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c_lo = blockIdx.x * 4 * LN_CPW;
-    const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
-    const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_group, t_hi = min(t_lo + tiles_per_group, ntiles);
-    const bool want_p = p.dgamma != nullptr;
-    const float invC = 1.0f / p.C;
-    float gam[LN_CPW], ag[LN_CPW], ab[LN_CPW];
-#pragma unroll
-    for (int u = 0; u < LN_CPW; ++u) {
-        gam[u] = p.gamma[min(c_lo + wave + 4 * u, p.C - 1)];
-        ag[u] = 0.0f;
-        ab[u] = 0.0f;
-    }
-    for (int64_t tile = t_lo; tile < t_hi; ++tile) {
-        const int b = (int)(tile / p.tiles_per_b);
-        const int hw = (int)(tile - (int64_t)b * p.tiles_per_b) * 64 + lane;
-        const bool ok = hw < p.HW;
-        const int64_t pix = (int64_t)b * p.HW + (ok ? hw : 0);
-        const int64_t base = (int64_t)b * p.C * p.HW + (ok ? hw : 0);
-        const float mean = p.mr_in[pix * 2], rstd = p.mr_in[pix * 2 + 1];
-        float m1 = 0.0f, m2 = 0.0f;
-#pragma unroll
-        for (int q = 0; q < LN_NP; ++q) {
-            const float* o = scr + ((int64_t)q * p.B * p.HW + pix) * 2;
-            m1 += o[0];
-            m2 += o[1];
-        }
-        m1 *= invC;
-        m2 *= invC;
-        float dv[LN_CPW], xv[LN_CPW], ov[LN_CPW];
-#pragma unroll
-        for (int u = 0; u < LN_CPW; ++u) {
-            const int64_t off = base + (int64_t)min(c_lo + wave + 4 * u, p.C - 1) * p.HW;
-            dv[u] = p.dy[off];
-            xv[u] = p.x[off];
-            ov[u] = p.accum ? p.dx[off] : 0.0f;      // kernel-uniform condition
-        }
-#pragma unroll
-        for (int u = 0; u < LN_CPW; ++u) {
-            const int c = c_lo + wave + 4 * u;
-            if (c < p.C && ok) {
-                const float xh = (xv[u] - mean) * rstd;
-                p.dx[base + (int64_t)c * p.HW] = rstd * (dv[u] * gam[u] - m1 - xh * m2) + ov[u];
-                ag[u] = fmaf(dv[u], xh, ag[u]);
-                ab[u] += dv[u];
-            }
-        }
-    }
-    if (want_p) {
-#pragma unroll
-        for (int u = 0; u < LN_CPW; ++u) {
-            const int c = c_lo + wave + 4 * u;
-            const float a = wave_sum_hi(ag[u]), bb = wave_sum_hi(ab[u]);
-            if (lane == 63 && c < p.C) {
-                atomicAdd(p.dgamma + c, a);
-                atomicAdd(p.dbeta + c, bb);
-            }
-        }
-    }
-}
-
 int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     LnP p{};
     p.dy = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_DY]);
@@ -335,17 +221,6 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
-    float* scr = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_SCR]);
-    CHECK_PTRS("chan_ln_bwd", scr);
-    if (scr && tiles * LN_NP < 0x7fffffff) {
-        hipLaunchKernelGGL(chan_ln_bwd_stats_kernel, dim3((unsigned)(tiles * LN_NP)), dim3(256), 0, c.stream, p, scr);
-        const int slabs = cdiv(p.C, 4 * LN_CPW);
-        int64_t tpg = std::max<int64_t>(1, std::min<int64_t>(8, tiles * slabs / 1024));
-        while (cdiv64(tiles, tpg) > 65535) tpg *= 2;
-        hipLaunchKernelGGL(chan_ln_bwd_apply_kernel, dim3((unsigned)slabs, (unsigned)cdiv64(tiles, tpg)), dim3(256), 0, c.stream, p,
-                           static_cast<const float*>(scr), (int)tpg);
-        return S2K_OK;
-    }
     const size_t lds = (2 * (size_t)p.C + LN_NW * 64 * 2) * sizeof(float);
     if (lds > 64 * 1024) { set_error("chan_ln_bwd: C too large"); return S2K_EINVAL; }
     hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(64 * LN_NW), lds, c.stream, p);

@@ -133,8 +133,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   MR[b][hw] = {mean, rstd};  Y = (X - mean) * rstd * GAMMA[c] + BETA[c]
     "CHAN_LN_FWD": (["X", "GAMMA", "BETA", "Y", "MR"], [], ["B", "C", "HW"], ["EPS"]),
     # DX (+)= rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = DY * GAMMA;  DGAMMA[c] += sum DY * xhat;  DBETA[c] += sum DY
-    # SCR (optional, [CHAN_LN_NP][B*HW][2] floats): scratch of the two-kernel backward (partial per-position sums by channel slab)
-    "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA", "SCR"], [], ["B", "C", "HW", "ACCUM"], []),
+    "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA"], [], ["B", "C", "HW", "ACCUM"], []),
     # G[i] *= act'(X[i])
     # ACT = ACT_MUL: G[i] *= X[i]  (the dropout gate of EfficientNet's classifier head in the backward)
     "ACT_BWD": (["G", "X"], ["COUNT"], ["ACT"], []),
@@ -205,7 +204,6 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   DW2[c][j] += sum_b DGP[b][c]*HS[b][j];  DB2 += sum_b DGP;  DW1[j][c] += sum_b DHP[b][j]*POOL[b][c];  DB1 += sum_b DHP
     "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),
 }
-CHAN_LN_NP = 8     # csrc/vit.hip LN_NP
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 NAME_OF = {i: name for name, i in KIND.items()}
 

@@ -236,13 +236,9 @@ class _V:
     def ln_bwd(self, prefix: str, dy: TRef, x: TRef, mr: TRef, dx: TRef, C: int, N: int, accum: int):
         p, B = self.p, self.p.B
         tr = self.trainable(prefix + ".weight")
-        # one scratch per plane size for the two-kernel backward (every CHAN_LN_BWD runs on the main stream, in order)
-        cache = p.__dict__.setdefault("_ln_scratch", {})
-        if N not in cache:
-            cache[N] = p.alloc(f"ln_bwd_scratch:{N}", (D.CHAN_LN_NP, B * N, 2))
         p.bwd.add("CHAN_LN_BWD", DY=dy, X=x, MR=mr, GAMMA=p.param(prefix + ".weight"), DX=dx,
                   DGAMMA=p.pgrad(prefix + ".weight") if tr else None, DBETA=p.pgrad(prefix + ".bias") if tr else None,
-                  SCR=cache[N], B=B, C=C, HW=N, ACCUM=accum)
+                  B=B, C=C, HW=N, ACCUM=accum)
 
     # timm Block on [B][Dm][N] ------------------------------------------------------------------------
     def block_fwd(self, prefix: str, x: TRef, Dm: int, heads: int, hidden: int, L: int) -> tuple[TRef, dict]:

@@ -26,6 +26,7 @@ def main():
         fetch, write = raw.get(kind, {}).get("FETCH_SIZE", {}), raw.get(kind, {}).get("WRITE_SIZE", {})
         for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, {}).get("sum", 0) + write.get(k, {}).get("sum", 0))):
             f, w = fetch.get(k, {"avg": 0.0, "dispatches": 0}), write.get(k, {"avg": 0.0, "dispatches": 0})
+            k = k.replace("s2k::", "")
             name = k if kind == "bench" else f"{kind}:{k}"
             dst[name] = {"fetch_kb_raw": round(f["avg"], 1), "write_kb": round(w["avg"], 1),
                          "hbm_bytes": round((2.0 * f["avg"] + w["avg"]) * 1024), "dispatches": max(f["dispatches"], w["dispatches"])}
