@@ -29,6 +29,11 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+# SURVEY §8d, whole-step denominators (fp32): the layer-wise roofline T = sum over layers of max(FLOP / peak, bytes / BW) of
+# efficientnet-unet-b5 13x256x256 is 0.464 ms per tile (pure MFMA 0.418, pure HBM 0.140) = 2,154 tiles/s per GPU; the Prithvi
+# steps are compute-bound: forward + backward FLOP per sample / the f32 MFMA peak.
+UNET_B5_LAYERWISE_TILES_PER_S = 2154.0
+PRITHVI_GFLOP_PER_SAMPLE = {"mae": 59.8, "seg_frozen": 804.0, "seg_unfrozen": 875.0}
 
 
 KERNEL_OF = {("CONV", 0): "conv_igemm_kernel", ("CONV", 1): "conv_pc_kernel", ("WGRAD", 0): "wgrad_kernel", ("WGRAD", 1): "wgrad_pc_kernel"}
@@ -280,8 +285,9 @@ def prithvi_workload(what: str, dev, peaks, steps=8, warmup=3) -> dict:
     dout = torch.ones(max(n_dout, 1), device=dev) * 1e-3
     bases = eng.bases(model, x, out, noise, dout=dout, grads=model._grad_buffer())
     _, kernels = profile_programs(_lib, D, (eng.fwd, eng.bwd), (bases, bases), torch.cuda.current_stream().cuda_stream)
+    alg_tf = PRITHVI_GFLOP_PER_SAMPLE[what] * 1e9 * B / dt / 1e12
     return {"workload": name, "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
-            "batch": B, "dtype": "f32", "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss), 6), "roofline": make_roofline(kernels, peaks)}
+            "batch": B, "dtype": "f32", "step_algorithmic_tflops": round(alg_tf, 1), "step_frac_of_mfma_peak": round(alg_tf / PEAK_F32_MFMA_TFLOPS, 4), "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss), 6), "roofline": make_roofline(kernels, peaks)}
 
 
 def main() -> None:
@@ -409,7 +415,11 @@ def main() -> None:
             "config": {"workload": f"efficientnet-unet-{args.version} {C}x{H}x{H} bs{B}/GPU focal(g=2) train step "
                                    f"(fwd+loss+bwd{'+allreduce' if world > 1 else ''}+adam)",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "adam_ms": None if adam_ms is None else round(adam_ms, 4),
+            "roofline": roofline,
+            "layerwise_roofline": {"tiles_per_s_per_gpu_at_100pct": UNET_B5_LAYERWISE_TILES_PER_S,
+                                   "frac": round(tiles / dt / (world * UNET_B5_LAYERWISE_TILES_PER_S), 4), "source": "SURVEY.md §8d"}
+            if (args.version, C, H) == ("b5", 13, 256) else None,
+            "cpu_baseline": cpu, "adam_ms": None if adam_ms is None else round(adam_ms, 4),
             "measured_peaks": None if peaks is None else {"mfma_f32_tflops": round(peaks["mfma_f32_tflops"], 1),
                                                           "mfma_clock_mhz": round(peaks["mfma_clock_mhz"]),
                                                           "stream_copy_gbps": round(peaks["copy_gbps"], 1),

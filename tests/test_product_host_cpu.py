@@ -132,3 +132,26 @@ def test_load_prithvi_pop_and_reinit_rules(tmp_path):
     assert list(sdf) == list(src.state_dict())            # registration order of the reference kept
     with pytest.raises(FileNotFoundError):
         load_prithvi(1, weights=str(tmp_path / "missing.pt"))
+
+
+def test_standalone_efficientnet_accepts_foreign_state_dict_like_the_reference_self_test():
+    """reference efficientnet_unet.py:415-431 (`_test`): every version b0-b7 constructs as a standalone `EfficientNet`, and
+    `load_state_dict(imagenet_weights, strict=False)` - whose keys follow another naming scheme - neither raises nor touches a
+    parameter; the module keeps the reference's own key set."""
+    import torch
+
+    from s2lc_amd.modules.efficientnet_unet import EfficientNet, EfficientNetConfig
+
+    for version in ("b0", "b3", "b7"):
+        m = EfficientNet(EfficientNetConfig(version, 6, 4, class_distribution=[0.25] * 4))
+        keys = list(m.state_dict())
+        assert keys[0] == "stem.0.weight" and keys[-1] == "fc.3.bias" and not any(k.startswith("encoder.") for k in keys)
+        before = m._flat_params.clone()
+        foreign = {"_conv_stem.weight": torch.zeros(32, 3, 3, 3), "_bn0.weight": torch.ones(32), "_fc.bias": torch.zeros(1000)}
+        res = m.load_state_dict(foreign, strict=False)
+        assert set(res.unexpected_keys) == set(foreign)
+        assert set(res.missing_keys) >= {k for k in keys if not k.endswith("num_batches_tracked")}
+        assert torch.equal(m._flat_params, before)
+        own = {k: torch.full_like(v, 0.5) if v.dtype.is_floating_point else v for k, v in m.state_dict().items()}
+        m.load_state_dict(own)
+        assert float(m.fc[3].weight.min()) == 0.5 and float(m._flat_params[: m.stem[0].weight.numel()].max()) == 0.5
