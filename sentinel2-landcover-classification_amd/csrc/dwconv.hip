@@ -85,6 +85,53 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
     const int sub = lane >> vshift, v0 = lane & (vps - 1);
     const int total_rows = p.PPB * nrows;
     const bool vec = (Ws & 3) == 0;
+    if (vec && VPR <= vps) {
+        // A tile row fits one pass of a lane group: issue the loads of U row groups before the first one is used.  (The plain
+        // loop below waits for each load in turn - six dependent HBM round trips per workgroup on the 8x8 planes, 20 us for a
+        // tensor that a copy streams in 4.)
+        constexpr int U = 4;
+        const int ix = 4 * v0 - 4;
+        const bool col_ok = v0 < VPR && ix >= 0 && ix < Ws;
+        for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw * U) {
+            f32x4 v[U];
+            float sc[U], sh[U];
+            int dst[U];
+            bool okv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = rbase + u * 4 * rpw + sub;
+                const int pl = row / nrows, rr = row - pl * nrows;
+                const int64_t plane = pl0 + pl;
+                const bool rok = row < total_rows && plane < nplanes;
+                const int iy = row0 + rr;
+                okv[u] = rok && iy >= 0 && iy < Hs && col_ok;
+                sc[u] = 1.0f;
+                sh[u] = 0.0f;
+                if (PRO != S2K_PRO_NONE) {
+                    if (bnl) {
+                        sc[u] = bnl[rok ? pl : 0];
+                        sh[u] = bnl[p.PPB + (rok ? pl : 0)];
+                    } else {
+                        const int c = (int)((rok ? plane : 0) % p.C);
+                        sc[u] = p.bnv[c];
+                        sh[u] = p.bnv[p.C + c];
+                    }
+                }
+                const uint32_t rowoff = (uint32_t)((plane * Hs + iy) * Ws) * 4u;
+                v[u] = bload4(rs, okv[u] ? rowoff + (uint32_t)ix * 4u : BUF_OOB);
+                dst[u] = (row < total_rows && v0 < VPR) ? (pl * nrows + rr) * p.LW + 4 * v0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = okv[u] ? apply_pro_c<PRO>(v[u][j], sc[u], sh[u]) : 0.0f;
+                }
+                if (dst[u] >= 0) *reinterpret_cast<f32x4*>(tile + dst[u]) = v[u];
+            }
+        }
+        return;
+    }
     for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
         const int row = rbase + sub;
         const int pl = row / nrows, rr = row - pl * nrows;
