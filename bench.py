@@ -79,14 +79,15 @@ def csrc_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
-def make_roofline(kernels: dict, peaks: dict | None) -> dict:
-    """Roofline object of the MFMA kernel with the most device time."""
+def make_roofline(kernels: dict, peaks: dict | None, traffic_workload: bool = True) -> dict:
+    """Roofline object of the MFMA kernel with the most device time.  `traffic_workload`: the committed PMC run measured THIS
+    workload (the U-Net headline step); other workloads launch the same kernel names on other shapes and get no figure."""
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     k = kernels[dom]
     ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
     tot_fl = sum(v["flops"] for v in kernels.values())
     tot_ms = sum(v["ms"] for v in kernels.values())
-    traffic, src = measured_traffic(dom)
+    traffic, src = measured_traffic(dom) if traffic_workload else (None, "none: the committed PMC run covers the U-Net headline step only")
     r = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
          # HBM bytes per launch from the PMC counters of a COMMITTED rocprofv3 run (not this run): null when that file was
@@ -94,7 +95,9 @@ def make_roofline(kernels: dict, peaks: dict | None) -> dict:
          "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
          "launches": k["launches"], "avg_launch_ms": round(k["ms"] / k["launches"], 4), "flops_per_step": k["flops"],
          "all_mfma_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-         "mfma_kernels": {n: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+         "mfma_kernels": {n: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                              "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]),
+                              "traffic": measured_traffic(n, quiet=True)[0] if traffic_workload else None}
                           for n, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}}
     if peaks:
         r["peak_measured"] = round(peaks["mfma_f32_tflops"], 1)
@@ -102,7 +105,7 @@ def make_roofline(kernels: dict, peaks: dict | None) -> dict:
     return r
 
 
-def measured_traffic(kernel: str):
+def measured_traffic(kernel: str, quiet: bool = False):
     """(HBM bytes per launch of `kernel`, provenance) from the newest committed PMC run (profiles/*_hbm_traffic.json, written by
     tools/pmc_traffic.sh + tools/traffic_json.py).  The figure is NOT measured in this run (PMC counters need rocprofv3 around
     the process); it is dropped - loudly - when the file was measured on kernel sources other than the ones built here."""
@@ -114,8 +117,9 @@ def measured_traffic(kernel: str):
         doc = json.loads(f.read_text())
         have, want = doc.get("csrc_fingerprint"), csrc_fingerprint()
         if have != want:
-            print(f"bench.py: {f.name} was measured on csrc {have}, this tree is {want}: roofline.traffic omitted "
-                  f"(re-run tools/pmc_traffic.sh)", file=sys.stderr)
+            if not quiet:
+                print(f"bench.py: {f.name} was measured on csrc {have}, this tree is {want}: roofline.traffic omitted "
+                      f"(re-run tools/pmc_traffic.sh)", file=sys.stderr)
             return None, f"stale: profiles/{f.name} (csrc {have}, built {want})"
         return doc["kernels"][kernel]["hbm_bytes"], f"committed PMC run profiles/{f.name} (same csrc {want}); not measured in this run"
     except Exception as e:  # noqa: BLE001
@@ -287,7 +291,7 @@ def prithvi_workload(what: str, dev, peaks, steps=8, warmup=3) -> dict:
     _, kernels = profile_programs(_lib, D, (eng.fwd, eng.bwd), (bases, bases), torch.cuda.current_stream().cuda_stream)
     alg_tf = PRITHVI_GFLOP_PER_SAMPLE[what] * 1e9 * B / dt / 1e12
     return {"workload": name, "value": round(B / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
-            "batch": B, "dtype": "f32", "step_algorithmic_tflops": round(alg_tf, 1), "step_frac_of_mfma_peak": round(alg_tf / PEAK_F32_MFMA_TFLOPS, 4), "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss), 6), "roofline": make_roofline(kernels, peaks)}
+            "batch": B, "dtype": "f32", "step_algorithmic_tflops": round(alg_tf, 1), "step_frac_of_mfma_peak": round(alg_tf / PEAK_F32_MFMA_TFLOPS, 4), "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss.detach()), 6), "roofline": make_roofline(kernels, peaks, traffic_workload=False)}
 
 
 def main() -> None:
