@@ -23,12 +23,17 @@ namespace s2k {
 
 // THIN (3x3 only): M <= 32 - one 32-row m-tile shared by the four consumer waves, which split a 256-pixel tile 1 (m) x 4 (n)
 // (the decoder's full-resolution 32-channel convs and their data gradients: a quarter of a 128-row tile would be padding)
-template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false>
+// NARROW (1x1 only): 64 x 64 tiles (each consumer wave one 32 x 32 tile) for problems whose 128-pixel tiles would leave CUs
+// empty - the ViT encoder's Linears over 3,328 visible tokens are 156 tiles of 128 x 128 on 256 CUs
+template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false, bool NARROW = false>
 __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
     constexpr int NT = 256;
     constexpr int TT = (BMODE == BM_PIX) ? 1 : 9;
-    constexpr int WN = 2;
-    constexpr int BM = THIN ? 32 : WM * 64, BN = THIN ? 256 : 128;
+    constexpr int WN = NARROW ? 1 : 2;
+    constexpr int BM = THIN ? 32 : WM * 64, BN = THIN ? 256 : (NARROW ? 64 : 128);
+    constexpr int RPPB = NT / (BN / 4);                     // PIX: channel rows of B per producer pass
+    static_assert(!NARROW || (BMODE == BM_PIX && WM == 1 && !THIN), "narrow tiles: 1x1, 64 rows");
+    static_assert(BMODE != BM_PIX || KCH % RPPB == 0, "chunk rows per pass");
     constexpr int NWCOL = THIN ? 4 : 2;                    // wave columns (n) of the consumer grid
     static_assert(!THIN || (WM == 1 && BMODE == BM_SPATIAL), "thin tiles: 3x3, one m-tile of 32 rows");
     constexpr int KT = KCH * TT;                           // rows of an A chunk
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
         // =================================================================================================================
         const float* a_src = p.wt + (int64_t)(tid / (BM / 4)) * p.w_st + m0 + 4 * (tid % (BM / 4));
         f32x4 areg[NA];
-        f32x4 bvec[(BMODE == BM_PIX) ? KCH / 8 : 1];
+        f32x4 bvec[(BMODE == BM_PIX) ? KCH / RPPB : 1];
         float breg[(BMODE == BM_PIX) ? 1 : KCH * EPT];
         // ---- geometry of this workgroup's B tile: fixed for the whole K loop ----
         uint32_t bvoff = BUF_OOB;            // PIX: byte offset of this lane's pixel quad (image-relative) or out of range
@@ -105,8 +110,8 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
                 areg[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)i * A_RPP * p.w_st);
             if (BMODE == BM_PIX) {
 #pragma unroll
-                for (int i = 0; i < KCH / 8; ++i) {
-                    const int c = min(c0 + kc0 + 8 * i, p.Ctot - 1);       // channels past Ctot meet zero rows of the packed weights
+                for (int i = 0; i < KCH / RPPB; ++i) {
+                    const int c = min(c0 + kc0 + RPPB * i, p.Ctot - 1);    // channels past Ctot meet zero rows of the packed weights
                     bvec[(BMODE == BM_PIX) ? i : 0] = bload4(rx1, bvoff + (uint32_t)c * cs4);     // out of range + channel offset stays out of range
                 }
             } else {
@@ -128,8 +133,8 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
                     *reinterpret_cast<f32x4*>(As + (tid / (BM / 4) + i * A_RPP) * BM + 4 * (tid % (BM / 4))) = areg[i];
             if (BMODE == BM_PIX) {
 #pragma unroll
-                for (int i = 0; i < KCH / 8; ++i) {
-                    const int kc = kc0 + 8 * i;
+                for (int i = 0; i < KCH / RPPB; ++i) {
+                    const int kc = kc0 + RPPB * i;
                     f32x4 v = bvec[(BMODE == BM_PIX) ? i : 0];     // no validity select: out-of-range pixels feed discarded output columns
                     if (PRO == S2K_PRO_RELU) {
                         const int c = min(c0 + kc, p.Ctot - 1);
@@ -311,19 +316,20 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false>
+template <int BMODE, int WM, int KCH, int R, int XW, int PRO, bool THIN = false, bool NARROW = false>
 static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr int TT = (BMODE == BM_PIX) ? 1 : 9;
     constexpr int BM = THIN ? 32 : WM * 64;
+    constexpr int BNP = NARROW ? 64 : 128;
     constexpr int USED = (R + 2) * (XW + 2);
-    constexpr int CSB = (BMODE == BM_PIX) ? 128 : USED;
+    constexpr int CSB = (BMODE == BM_PIX) ? BNP : USED;
     constexpr int BUF = (KCH * TT * BM + KCH * CSB + 3) & ~3;
     constexpr size_t lds = (size_t)2 * BUF * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS image");
     static_assert((THIN ? 8 : 4) * BM * sizeof(float) <= lds, "statistics rows fit in the image");
     p.n_mtiles = cdiv(p.M, BM);
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
-        const bool local = BMODE == BM_SPATIAL || (p.HW % 128) == 0;
+        const bool local = BMODE == BM_SPATIAL || (p.HW % BNP) == 0;
         const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
         const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
         if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
@@ -332,7 +338,7 @@ static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
     p.n_tiles = (int)blocks;
     p.splits = 1;
-    auto kern = conv_pc_kernel<BMODE, WM, KCH, R, XW, PRO, THIN>;
+    auto kern = conv_pc_kernel<BMODE, WM, KCH, R, XW, PRO, THIN, NARROW>;
     static PerDeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -373,7 +379,15 @@ int launch_conv_pc(ConvP& p, hipStream_t st) {
     if (T == 1) {
         if (!(enabled & 1) || p.C2 != 0 || (p.HW & 3) || p.HO != p.H || p.WO != p.W) return 1;
         const int n_ntiles = cdiv(p.Ntot, 128);
-        if ((int64_t)cdiv(p.M, bm) * n_ntiles < 192) return 1;         // too few tiles for 256 CUs: the split-K path of igemm.hip
+        if ((int64_t)cdiv(p.M, bm) * n_ntiles < 192) {
+            // too few 128-pixel tiles for 256 CUs: 64 x 64 tiles when they fill the chip and the reduction is long enough to
+            // amortise their epilogue, else the split-K path of igemm.hip
+            static const int narrow = tune_int("S2K_CONV_PC_NARROW", 1);
+            const int n64 = cdiv(p.Ntot, 64);
+            if (!narrow || p.Ctot < 512 || (int64_t)cdiv(p.M, 64) * n64 < 384) return 1;
+            return p.pro1 == S2K_PRO_RELU ? launch_pc<BM_PIX, 1, 32, 1, 64, S2K_PRO_RELU, false, true>(p, n64, st)
+                                          : launch_pc<BM_PIX, 1, 32, 1, 64, S2K_PRO_NONE, false, true>(p, n64, st);
+        }
         if (p.Ctot < 256) return 1;                                     // short reductions have nothing to pipeline: generic kernels
         static const int kch1 = tune_int("S2K_CONV_PC_KCH1", 32);      // 32: two workgroups per CU (64 KB of LDS each)
         if (kch1 == 64) return launch_pc_bm<BM_PIX, 64, 1, 64>(p, n_ntiles, bm, st);

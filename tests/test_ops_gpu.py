@@ -175,6 +175,8 @@ def test_conv3x3(B, C1, C2, H, W, M, pro1, pro2):
     (4, 264, 64, 64, 200, 3, True, True, 0),     # 64-row tiles (M = 200 pads 128-row tiles by 28 %), ReLU prologue, bias, K tail (264 = 8 x 32 + 8)
     (6, 288, 1, 200, 320, 0, True, False, 1),    # a Linear over feature-major tokens (H = 1), accumulate into Y (beta)
     (3, 256, 100, 100, 176, 0, False, True, 0),  # pixel count not a multiple of the tile: tiles straddle images, ragged last tile
+    (4, 512, 32, 32, 384, 0, True, True, 0),     # 96 tiles of 128 x 128 would leave CUs empty: narrow 64 x 64 tiles (384 of them)
+    (6, 520, 26, 26, 512, 3, True, True, 0),     # narrow tiles, ReLU prologue, K tail, tiles straddle images (HW = 676)
 ])
 def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
     """shapes that take the producer / consumer kernels (csrc/igemm_pc.hip): >= 192 tiles of 128 pixels"""
