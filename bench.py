@@ -23,6 +23,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL over dmabuf IPC (the host driver supports no other mode)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
