@@ -42,6 +42,31 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
     const int rpw = 64 >> p.lwp_shift;                // rows per wave pass
     const int sub = lane >> p.lwp_shift, cc0 = lane & (lwp - 1);
     const int total_rows = p.PPB * nrows;
+    if (PRO == S2K_PRO_NONE && p.LW <= lwp) {
+        // a tile row fits one pass of a lane group: the loads of U row groups are issued before the first one is used
+        // (see stage_band_v4)
+        constexpr int U = 4;
+        const int ix = col0 + cc0;
+        const bool col_ok = cc0 < p.LW && ix >= 0 && ix < Ws;
+        for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw * U) {
+            float v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = rbase + u * 4 * rpw + sub;
+                const int pl = row / nrows, rr = row - pl * nrows;
+                const int64_t plane = pl0 + pl;
+                const int iy = row0 + rr;
+                const bool ok = row < total_rows && plane < nplanes && iy >= 0 && iy < Hs && col_ok;
+                v[u] = bload(rs, ok ? (uint32_t)((plane * Hs + iy) * Ws + ix) * 4u : BUF_OOB);
+                dst[u] = (row < total_rows && cc0 < p.LW) ? (pl * nrows + rr) * p.LW + cc0 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) tile[dst[u]] = v[u];
+        }
+        return;
+    }
     for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
         const int row = rbase + sub;
         const int pl = row / nrows, rr = row - pl * nrows;
