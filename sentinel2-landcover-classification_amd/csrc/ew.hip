@@ -502,9 +502,16 @@ __global__ void __launch_bounds__(NTHREADS) se_fc1_kernel(const float* pool, con
     if (j >= Q) return;
     const float* wr = w1 + (int64_t)j * C;
     const float* pr = pool + (int64_t)b * C;
-    float s = 0.0f;
-    for (int i = lane; i < C; i += 64) s = fmaf(wr[i], pr[i], s);
-    s = wave_sum(s);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;      // eight loads in flight per lane, four independent chains
+    int i = lane;
+    for (; i + 192 < C; i += 256) {
+        s0 = fmaf(wr[i], pr[i], s0);
+        s1 = fmaf(wr[i + 64], pr[i + 64], s1);
+        s2 = fmaf(wr[i + 128], pr[i + 128], s2);
+        s3 = fmaf(wr[i + 192], pr[i + 192], s3);
+    }
+    for (; i < C; i += 64) s0 = fmaf(wr[i], pr[i], s0);
+    const float s = wave_sum((s0 + s1) + (s2 + s3));
     if (lane == 0) hpre[(int64_t)b * Q + j] = s + b1[j];
 }
 
@@ -564,11 +571,18 @@ __global__ void __launch_bounds__(1024) se_fc_bwd_a1_kernel(const float* dgate, 
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (j < Q) {
         int i = wave;
-        for (; i + 48 < C; i += 64) {
-            s0 = fmaf(w2[(int64_t)i * Q + j], sdg[i], s0);
-            s1 = fmaf(w2[(int64_t)(i + 16) * Q + j], sdg[i + 16], s1);
-            s2 = fmaf(w2[(int64_t)(i + 32) * Q + j], sdg[i + 32], s2);
-            s3 = fmaf(w2[(int64_t)(i + 48) * Q + j], sdg[i + 48], s3);
+        for (; i + 112 < C; i += 128) {              // eight row loads in flight per lane (a 3072-channel layer was 48 dependent trips)
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = w2[(int64_t)(i + 16 * u) * Q + j];
+            s0 = fmaf(w[0], sdg[i], s0);
+            s1 = fmaf(w[1], sdg[i + 16], s1);
+            s2 = fmaf(w[2], sdg[i + 32], s2);
+            s3 = fmaf(w[3], sdg[i + 48], s3);
+            s0 = fmaf(w[4], sdg[i + 64], s0);
+            s1 = fmaf(w[5], sdg[i + 80], s1);
+            s2 = fmaf(w[6], sdg[i + 96], s2);
+            s3 = fmaf(w[7], sdg[i + 112], s3);
         }
         for (; i < C; i += 16) s0 = fmaf(w2[(int64_t)i * Q + j], sdg[i], s0);
     }
@@ -597,6 +611,19 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_a2_kernel(float* dgate, co
     dgate[(int64_t)b * C + c] *= g * (1.0f - g);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int j = 0;
+    for (; j + 8 <= Q; j += 8) {                     // eight row loads in flight per lane
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = w1[(int64_t)(j + u) * C + c];
+        s0 = fmaf(w[0], smem[j], s0);
+        s1 = fmaf(w[1], smem[j + 1], s1);
+        s2 = fmaf(w[2], smem[j + 2], s2);
+        s3 = fmaf(w[3], smem[j + 3], s3);
+        s0 = fmaf(w[4], smem[j + 4], s0);
+        s1 = fmaf(w[5], smem[j + 5], s1);
+        s2 = fmaf(w[6], smem[j + 6], s2);
+        s3 = fmaf(w[7], smem[j + 7], s3);
+    }
     for (; j + 4 <= Q; j += 4) {
         s0 = fmaf(w1[(int64_t)j * C + c], smem[j], s0);
         s1 = fmaf(w1[(int64_t)(j + 1) * C + c], smem[j + 1], s1);
