@@ -394,6 +394,61 @@ __global__ void __launch_bounds__(NTHREADS) se_bn_sums_kernel(const float* g, co
     }
 }
 
+// SE_BN_SUMS on small planes (<= 64 elements): one wave per channel (and batch chunk), 16 lanes per plane, four planes per pass,
+// the loads of four passes in flight; the five plane sums are group reductions (one per four planes instead of one per plane)
+__global__ void __launch_bounds__(NTHREADS) se_bn_sums_small_kernel(const float* g, const float* y, const float* bnv, float* dgate,
+                                                                    float* ps, int B, int C, int HW, int lpp) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+    const int pp = 64 / lpp, sub = lane / lpp, li = lane & (lpp - 1);
+    const bool in = 4 * li < HW;
+    const int64_t nplanes = (int64_t)B * C;
+    const int bper = (B + gridDim.y - 1) / gridDim.y, b_lo = blockIdx.y * bper, b_hi = min(B, b_lo + bper);
+    constexpr int U = 4;
+    for (int b0 = b_lo + sub; b0 - sub < b_hi; b0 += pp * U) {
+        float4 dv[U], yv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = min(b0 + u * pp, b_hi - 1);
+            const int64_t off = ((int64_t)b * C + c) * HW + 4 * (in ? li : 0);
+            dv[u] = *reinterpret_cast<const float4*>(g + off);
+            yv[u] = *reinterpret_cast<const float4*>(y + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * pp;
+            if (b - sub >= b_hi) break;                                   // wave-uniform: the whole pass is past the chunk
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
+            if (in && b < b_hi) {
+                const float dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w}, yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float uu = fmaf(yy[k], scale, shift);
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-uu));
+                    const float ap = sg * (1.0f + uu * (1.0f - sg)), xh = (yy[k] - mean) * invstd;
+                    const float t = dd[k] * ap;
+                    p0 = fmaf(dd[k], uu * sg, p0);
+                    p1 += t;
+                    p2 += ap;
+                    p3 = fmaf(t, xh, p3);
+                    p4 = fmaf(ap, xh, p4);
+                }
+            }
+            p0 = group_sum(p0, lpp); p1 = group_sum(p1, lpp); p2 = group_sum(p2, lpp); p3 = group_sum(p3, lpp); p4 = group_sum(p4, lpp);
+            if (li == 0 && b < b_hi) {
+                const int64_t plane = (int64_t)b * C + c;
+                dgate[plane] = p0;
+                ps[plane] = p1;
+                ps[nplanes + plane] = p2;
+                ps[2 * nplanes + plane] = p3;
+                ps[3 * nplanes + plane] = p4;
+            }
+        }
+    }
+}
+
 int launch_se_bn_sums(const S2kOp& op, const Ctx& c) {
     const float* g = ref_ptr<const float>(c, op.t[S2K_SE_BN_SUMS_T_G]);
     const float* y = ref_ptr<const float>(c, op.t[S2K_SE_BN_SUMS_T_Y]);
@@ -406,6 +461,13 @@ int launch_se_bn_sums(const S2kOp& op, const Ctx& c) {
         set_error("se_bn_sums: bad args (SiLU only)"); return S2K_EINVAL;
     }
     const int64_t nplanes = (int64_t)B * C;
+    if (HW <= 64 && (HW & 3) == 0 && B > 1) {
+        int lpp = 1;
+        while (4 * lpp < HW) lpp <<= 1;
+        const int bsplit = std::max(1, std::min(cdiv(B, 64 / lpp), cdiv(2048, C)));
+        hipLaunchKernelGGL(se_bn_sums_small_kernel, dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, B, C, HW, lpp);
+        return S2K_OK;
+    }
     const unsigned blocks = (unsigned)cdiv64(nplanes, 4);
     if ((HW & 3) == 0) hipLaunchKernelGGL((se_bn_sums_kernel<true>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, C, HW, nplanes);
     else hipLaunchKernelGGL((se_bn_sums_kernel<false>), dim3(blocks), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, C, HW, nplanes);
@@ -913,6 +975,84 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     }
 }
 
+// BN_BWD_APPLY (fused finalize, MODE 2 / 3 of plane_map_kernel) on small planes (<= 64 elements: the 8x8 stages, 1824 - 3072
+// channels): one wave per CHANNEL (and batch chunk) forms the three coefficients once - the replica sums, two f64 products -
+// and walks the batch with 16 lanes per plane, four planes per pass, the loads of four passes in flight.  With one wave per
+// 64-element plane the coefficient arithmetic was most of the kernel (23 us for a 15 MB tensor).
+template <int MODE>
+__global__ void __launch_bounds__(NTHREADS) bn_bwd_apply_small_kernel(const float* a, const float* y, const float* bnv, float* out,
+                                                                      int B, int C, int HW, int lpp, const BnFuse fz) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    if (fz.nrep <= 8) {
+        for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+    } else {
+        for (int r = lane; r < fz.nrep; r += 64) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+    }
+    const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+    const double aa = (double)fz.gamma[c] * (double)invstd;
+    const float A = (float)aa, Bq = (float)(-aa * s2 * fz.inv_count), Cq = (float)(-aa * s1 * fz.inv_count);
+    const float k0 = A, k1 = Bq * invstd, k2 = Cq - Bq * invstd * mean;
+    if (blockIdx.y == 0 && lane == 0) {
+        fz.dgamma[c] += (float)s2;
+        fz.dbeta[c] += (float)s1;
+    }
+    const float bscale = bnv[c], bshift = bnv[C + c];
+    const int pp = 64 / lpp, sub = lane / lpp, li = lane & (lpp - 1);
+    if (4 * li >= HW) return;
+    const int bper = (B + gridDim.y - 1) / gridDim.y, b_lo = blockIdx.y * bper, b_hi = min(B, b_lo + bper);
+    constexpr int U = 4;
+    for (int b0 = b_lo + sub; b0 < b_hi; b0 += pp * U) {
+        float4 av[U], yv[U];
+        float gmul[U], gadd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = min(b0 + u * pp, b_hi - 1);                   // clamped: loads never sit under a condition
+            const int64_t plane = (int64_t)b * C + c, off = plane * HW + 4 * li;
+            av[u] = *reinterpret_cast<const float4*>(a + off);
+            yv[u] = *reinterpret_cast<const float4*>(y + off);
+            gmul[u] = 1.0f;
+            gadd[u] = 0.0f;
+            if (MODE == 3) {
+                if (fz.mulbc) gmul[u] = fz.mulbc[plane];
+                if (fz.addbc) gadd[u] = fz.addbc[plane] * fz.addscale;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * pp;
+            if (b >= b_hi) break;
+            float4 g = av[u];
+            const float4 yy = yv[u];
+            if (MODE == 3) {
+                g.x = fmaf(g.x, gmul[u], gadd[u]) * act_grad(fmaf(yy.x, bscale, bshift), S2K_PRO_SILU);
+                g.y = fmaf(g.y, gmul[u], gadd[u]) * act_grad(fmaf(yy.y, bscale, bshift), S2K_PRO_SILU);
+                g.z = fmaf(g.z, gmul[u], gadd[u]) * act_grad(fmaf(yy.z, bscale, bshift), S2K_PRO_SILU);
+                g.w = fmaf(g.w, gmul[u], gadd[u]) * act_grad(fmaf(yy.w, bscale, bshift), S2K_PRO_SILU);
+            }
+            float4 o;
+            o.x = fmaf(k0, g.x, fmaf(k1, yy.x, k2)); o.y = fmaf(k0, g.y, fmaf(k1, yy.y, k2));
+            o.z = fmaf(k0, g.z, fmaf(k1, yy.z, k2)); o.w = fmaf(k0, g.w, fmaf(k1, yy.w, k2));
+            *reinterpret_cast<float4*>(out + ((int64_t)b * C + c) * HW + 4 * li) = o;
+        }
+    }
+}
+
+template <int MODE>
+static bool launch_bn_bwd_apply_small(const float* a, const float* y, const float* bnv, float* out, int B, int C, int HW,
+                                      hipStream_t st, const BnFuse& fz) {
+    if (HW > 64 || (HW & 3) || B < 2) return false;
+    int lpp = 1;
+    while (4 * lpp < HW) lpp <<= 1;
+    const int bsplit = std::max(1, std::min(cdiv(B, 64 / lpp), cdiv(2048, C)));
+    hipLaunchKernelGGL((bn_bwd_apply_small_kernel<MODE>), dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, st, a, y, bnv, out, B, C, HW, lpp, fz);
+    return true;
+}
+
 // BN_RESIDUAL on small planes: one wave per channel walks the batch (see se_pool_small_kernel)
 __global__ void __launch_bounds__(NTHREADS) bn_residual_small_kernel(const float* ident, const float* y, const float* bnv, const float* noise,
                                                                      float* out, int B, int C, int HW, float keep, int lpp,
@@ -981,11 +1121,13 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     fz.addscale = op.f[S2K_BN_BWD_APPLY_F_ADDSCALE];
     CHECK_PTRS("bn_bwd_apply", fz.mulbc, fz.addbc);
     if (op.d[S2K_BN_BWD_APPLY_D_ACT] == S2K_PRO_NONE && !fz.mulbc && !fz.addbc) {
+        if (launch_bn_bwd_apply_small<2>(gp, y, bnv, dy, B, C, HW, c.stream, fz)) return S2K_OK;
         launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
         return S2K_OK;
     }
     // GP holds the raw upstream gradient: g' = (GP * MULBC + ADDBC * ADDSCALE) * silu'(u) is recomputed per element
     if (op.d[S2K_BN_BWD_APPLY_D_ACT] != S2K_PRO_SILU) { set_error("bn_bwd_apply: the recomputing form is SiLU only"); return S2K_EINVAL; }
+    if (launch_bn_bwd_apply_small<3>(gp, y, bnv, dy, B, C, HW, c.stream, fz)) return S2K_OK;
     launch_plane_map<3>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);
     return S2K_OK;
 }

@@ -406,7 +406,7 @@ def test_bn_finalize(train):
           BNV=bnv, COUNT=n, C=C, TRAIN=train, NREP=nrep, EPS=1e-3, MOM=0.01)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 3, 10000)])
+@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 3, 10000), (5, 70, 64), (33, 9, 16), (4, 300, 36)])   # (<= 64: channel-per-wave kernels)
 @pytest.mark.parametrize("variant", ["relu", "silu_se", "none_dc"])
 def test_bn_backward_trio(B, C, HW, variant):
     c = Case(6)
@@ -628,7 +628,7 @@ def test_convt_wgrad_gather_reads_past_2gib():
           H=H2, W=H2, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_GATHER2X2)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 5, 4100)])
+@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 5, 4100), (6, 70, 64), (35, 9, 16), (4, 300, 36)])   # (<= 64: channel-per-wave kernels)
 def test_se_bn_two_pass_stages(B, C, HW):
     """SE_BN_SUMS (one pass: dgate + the four plane sums), SE_BN_COMBINE (per-channel BatchNorm-backward sums once the SE
     factors are known) and the recomputing form of BN_BWD_APPLY; together they equal SE_BWD_REDUCE + BN_BWD_REDUCE + APPLY."""
