@@ -27,9 +27,17 @@ struct DwP {
     int PPB, RT, bands, IRt, LW;     // tiling: planes per workgroup, rows per band, LDS rows / row stride
     int XG, LPP, lwp_shift;          // 4-wide x groups per row, lanes per plane, log2(pow2ceil(LW)) capped at 6
     int vps_shift;                   // log2(pow2ceil(LW / 4)) capped at 6 (vector stager)
+    float inv_xg;                    // 1 / XG
     int bloop, cgroups;              // wgrad on small planes: images per workgroup (0 = off), channel groups
     BnFold fold;                     // fwd: BN_FINALIZE of the input's BatchNorm folded in (fold.stats != nullptr)
 };
+
+// Index arithmetic of the kernels below.  A 64-bit `plane % C` is ~150 instructions and a 32-bit division by a run-time value
+// ~25; on the 8x8 / 16x16 layers (a few hundred instructions per wave in all) they were a third of the kernel.  Planes fit
+// 32 bits (the launchers refuse B * C >= 2^31), and quotients of small non-negative ints come from one multiplication by a
+// float reciprocal (exact for numerators < 2^22: the error of the product is far below the 0.5 / divisor margin).
+__device__ __forceinline__ int chan_of(int64_t plane, int C) { return (int)((uint32_t)plane % (uint32_t)C); }
+__device__ __forceinline__ int fdiv(int num, float inv) { return (int)(((float)num + 0.5f) * inv); }
 
 // Scalar stager (any width / column origin): rows [row0, row0 + nrows) x LW columns of PPB planes of `src` into
 // tile[pl][rr][LW]; element (rr, cc) is src row (row0 + rr), column (col0 + cc), zero outside the image.
@@ -42,6 +50,7 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
     const int rpw = 64 >> p.lwp_shift;                // rows per wave pass
     const int sub = lane >> p.lwp_shift, cc0 = lane & (lwp - 1);
     const int total_rows = p.PPB * nrows;
+    const float inv_nrows = 1.0f / (float)nrows;
     if (PRO == S2K_PRO_NONE && p.LW <= lwp) {
         // a tile row fits one pass of a lane group: the loads of U row groups are issued before the first one is used
         // (see stage_band_v4)
@@ -54,7 +63,7 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = rbase + u * 4 * rpw + sub;
-                const int pl = row / nrows, rr = row - pl * nrows;
+                const int pl = fdiv(row, inv_nrows), rr = row - pl * nrows;
                 const int64_t plane = pl0 + pl;
                 const int iy = row0 + rr;
                 const bool ok = row < total_rows && plane < nplanes && iy >= 0 && iy < Hs && col_ok;
@@ -69,7 +78,7 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
     }
     for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
         const int row = rbase + sub;
-        const int pl = row / nrows, rr = row - pl * nrows;
+        const int pl = fdiv(row, inv_nrows), rr = row - pl * nrows;
         const int64_t plane = pl0 + pl;
         const bool rok = row < total_rows && plane < nplanes;
         const int iy = row0 + rr;
@@ -80,7 +89,7 @@ __device__ __forceinline__ void stage_band(const DwP& p, const float* src, int H
                 sc = bnl[rok ? pl : 0];
                 sh = bnl[p.PPB + (rok ? pl : 0)];
             } else {
-                const int c = (int)((rok ? plane : 0) % p.C);
+                const int c = chan_of(rok ? plane : 0, p.C);
                 sc = p.bnv[c];
                 sh = p.bnv[p.C + c];
             }
@@ -109,6 +118,7 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
     const int vps = 1 << vshift, rpw = 64 >> vshift;
     const int sub = lane >> vshift, v0 = lane & (vps - 1);
     const int total_rows = p.PPB * nrows;
+    const float inv_nrows = 1.0f / (float)nrows;
     const bool vec = (Ws & 3) == 0;
     if (vec && VPR <= vps) {
         // A tile row fits one pass of a lane group: issue the loads of U row groups before the first one is used.  (The plain
@@ -125,7 +135,7 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = rbase + u * 4 * rpw + sub;
-                const int pl = row / nrows, rr = row - pl * nrows;
+                const int pl = fdiv(row, inv_nrows), rr = row - pl * nrows;
                 const int64_t plane = pl0 + pl;
                 const bool rok = row < total_rows && plane < nplanes;
                 const int iy = row0 + rr;
@@ -137,7 +147,7 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
                         sc[u] = bnl[rok ? pl : 0];
                         sh[u] = bnl[p.PPB + (rok ? pl : 0)];
                     } else {
-                        const int c = (int)((rok ? plane : 0) % p.C);
+                        const int c = chan_of(rok ? plane : 0, p.C);
                         sc[u] = p.bnv[c];
                         sh[u] = p.bnv[p.C + c];
                     }
@@ -159,7 +169,7 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
     }
     for (int rbase = wave * rpw; rbase < total_rows; rbase += 4 * rpw) {
         const int row = rbase + sub;
-        const int pl = row / nrows, rr = row - pl * nrows;
+        const int pl = fdiv(row, inv_nrows), rr = row - pl * nrows;
         const int64_t plane = pl0 + pl;
         const bool rok = row < total_rows && plane < nplanes;
         const int iy = row0 + rr;
@@ -170,7 +180,7 @@ __device__ __forceinline__ void stage_band_v4(const DwP& p, const float* src, in
                 sc = bnl[rok ? pl : 0];
                 sh = bnl[p.PPB + (rok ? pl : 0)];
             } else {
-                const int c = (int)((rok ? plane : 0) % p.C);
+                const int c = chan_of(rok ? plane : 0, p.C);
                 sc = p.bnv[c];
                 sh = p.bnv[p.C + c];
             }
@@ -236,14 +246,14 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
             if (wave < p.PPB) {
                 const int64_t plane = pl0 + wave;
                 float sc = 1.0f, sh = 0.0f;
-                if (plane < nplanes) bn_fold_wave(p.fold, p.C, (int)(plane % p.C), plane < p.C && band == 0, sc, sh);
+                if (plane < nplanes) bn_fold_wave(p.fold, p.C, chan_of(plane, p.C), plane < p.C && band == 0, sc, sh);
                 if (lane == 0) { bnl[wave] = sc; bnl[p.PPB + wave] = sh; }
             }
         } else {
             for (int pl = tid; pl < p.PPB; pl += NTHREADS) {
                 const int64_t plane = pl0 + pl;
                 float sc = 1.0f, sh = 0.0f;
-                if (plane < nplanes) bn_fold_thread(p.fold, p.C, (int)(plane % p.C), plane < p.C && band == 0, sc, sh);
+                if (plane < nplanes) bn_fold_thread(p.fold, p.C, chan_of(plane, p.C), plane < p.C && band == 0, sc, sh);
                 bnl[pl] = sc;
                 bnl[p.PPB + pl] = sh;
             }
@@ -254,7 +264,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
     for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
         const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
-        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * (K * K) + (idx - pl * (K * K))] : 0.0f;
+        wsm[idx] = plane < nplanes ? p.w[chan_of(plane, p.C) * (K * K) + (idx - pl * (K * K))] : 0.0f;
     }
     __syncthreads();
 
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
             for (int i = 0; i < K * K; ++i) wk[i] = wsm[pl * K * K + i];
             const float* tp = tile + pl * p.IRt * p.LW;
             for (int it = it0; it < items; it += itstep) {
-                const int r = it / p.XG, xg = it - r * p.XG;
+                const int r = fdiv(it, p.inv_xg), xg = it - r * p.XG;
                 const float* t0 = tp + (r * S) * p.LW + xg * 4 * S;
                 float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
             s = group_sum(s, lpp);
             q = group_sum(q, lpp);
             if (li == 0 && pok) {
-                const int c = (int)(plane % p.C);
+                const int c = chan_of(plane, p.C);
                 atomic_add_d(st + c, (double)s);
                 atomic_add_d(st + p.C + c, (double)q);
             }
@@ -355,7 +365,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
                 const int64_t plane = plb + pl;
                 const float* tp = tile + pl * p.IRt * p.LW;
                 for (int it = li; it < items; it += lpp) {
-                    const int r = it / p.XG, xg = it - r * p.XG;
+                    const int r = fdiv(it, p.inv_xg), xg = it - r * p.XG;
                     const int xo = xg * 4;
                     const uint32_t goff = (uint32_t)(plane * p.HO * p.WO + (int64_t)r * p.WO + xo) * 4u;
                     float g[4];
@@ -409,7 +419,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
         if (pok) {
             const float* tp = tile + pl * p.IRt * p.LW;
             for (int it = it0; it < items; it += itstep) {
-                const int r = it / p.XG, xg = it - r * p.XG;
+                const int r = fdiv(it, p.inv_xg), xg = it - r * p.XG;
                 const int xo = xg * 4;
                 const uint32_t goff = (uint32_t)(plane * p.HO * p.WO + (int64_t)(yo0 + r) * p.WO + xo) * 4u;
                 float g[4];
@@ -432,7 +442,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
                 }
             }
         }
-        const int c = (int)((pok ? plane : 0) % p.C);
+        const int c = chan_of(pok ? plane : 0, p.C);
         if (wpp == 1) {
 #pragma unroll
             for (int i = 0; i < K * K; ++i) {
@@ -454,7 +464,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
                 if (pgb + slot < p.PPB && pln < nplanes) {
                     float v = 0.0f;
                     for (int w = 0; w < wpp; ++w) v += red[(slot * wpp + w) * (K * K) + i];
-                    atomicAdd(p.out + (pln % p.C) * (K * K) + i, v);
+                    atomicAdd(p.out + chan_of(pln, p.C) * (K * K) + i, v);
                 }
             }
             __syncthreads();
@@ -484,7 +494,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
     for (int idx = tid; idx < p.PPB * K * K; idx += NTHREADS) {
         const int pl = idx / (K * K);
         const int64_t plane = pl0 + pl;
-        wsm[idx] = plane < nplanes ? p.w[(plane % p.C) * (K * K) + (K * K - 1 - (idx - pl * (K * K)))] : 0.0f;
+        wsm[idx] = plane < nplanes ? p.w[chan_of(plane, p.C) * (K * K) + (K * K - 1 - (idx - pl * (K * K)))] : 0.0f;
     }
     __syncthreads();
     const rsrc_t rxr = make_rsrc(p.x ? p.x : p.dy, p.x ? nplanes * p.H * p.W * 4 : 0);
@@ -501,7 +511,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
         const int pl = pg + lp;
         const int64_t plane = pl0 + pl;
         const bool pok = pl < p.PPB && plane < nplanes;
-        const int c = (int)((pok ? plane : 0) % p.C);
+        const int c = chan_of(pok ? plane : 0, p.C);
         float s1 = 0.0f, s2 = 0.0f;
         if (pok) {
             float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
@@ -511,7 +521,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
             for (int i = 0; i < K * K; ++i) wk[i] = wsm[pl * K * K + i];
             const float* tp = tile + pl * p.IRt * p.LW;
             for (int it = it0; it < items; it += itstep) {
-                const int r = it / p.XG, xg = it - r * p.XG;
+                const int r = fdiv(it, p.inv_xg), xg = it - r * p.XG;
                 const int ix = xg * 4;
                 const float* t0 = tp + r * p.LW + ix;
                 const int64_t off = plane * p.H * p.W + (int64_t)(iy0 + r) * p.W + ix;
@@ -607,7 +617,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s2_kernel(const DwP p) 
     for (int idx = tid; idx < p.PPB * K2; idx += NTHREADS) {
         const int pl = idx / K2;
         const int64_t plane = pl0 + pl;
-        wsm[idx] = p.w[((plane < nplanes ? plane : 0) % p.C) * K2 + (idx - pl * K2)];
+        wsm[idx] = p.w[chan_of(plane < nplanes ? plane : 0, p.C) * K2 + (idx - pl * K2)];
     }
     __syncthreads();
     const int A0 = ((e - qy) >> 1) - r0, B0 = ((p.PL - qx) >> 1) + 1;   // tile row / column of block (0, 0)'s reference tap
@@ -620,7 +630,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s2_kernel(const DwP p) 
     for (int pl = wave / wpp; pl < p.PPB; pl += 4 / wpp) {
         const int64_t plane = pl0 + pl;
         if (plane >= nplanes) break;
-        const int c = (int)(plane % p.C);
+        const int c = chan_of(plane, p.C);
         float s1 = 0.0f, s2 = 0.0f;
         float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
         if (p.pro != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
@@ -699,6 +709,7 @@ static size_t tile_rows(DwP& p, int ho, int wo, int (*irt_for_rt)(int, const DwP
     const int hw = ho * wo;
     p.LW = vec ? (lw + 3) & ~3 : lw | 1;     // vector layout: float4 rows; scalar layout: odd stride
     p.XG = cdiv(wo, 4);
+    p.inv_xg = 1.0f / (float)p.XG;
     size_t lds = 0;
     for (int target = target0;; target >>= 1) {
         if (hw <= target) { p.PPB = target / hw; if (p.PPB > 32) p.PPB = 32; p.RT = ho; }
