@@ -36,57 +36,101 @@ static T* ref_ptr(const Ctx& c, int64_t ref) {
 }
 static bool bad(const void* q) { return q == reinterpret_cast<const void*>(1); }
 
-// log-softmax of one pixel into lp[]; returns nothing else
-__device__ __forceinline__ void pixel_logp(const LossP& p, int b, int hw, float* lp) {
-    const float* src = p.logits + ((int64_t)b * p.C) * p.HW + hw;
+// pow(om, g) for the exponents the configs use (gamma = 2 in the benchmark recipe) without the general powf
+__device__ __forceinline__ float pow_gamma(float om, float g) {
+    if (g == 2.0f) return om * om;
+    if (g == 1.0f) return om;
+    if (g == 0.0f) return 1.0f;
+    return powf(om, g);
+}
+
+// log-softmax of one pixel: lp[c] = x[c] - logsumexp(x), e[c] = exp(x[c] - max) / sum (the softmax, reused by the backward).
+// CC > 0: the class count is a compile-time constant and everything stays in registers (CC = 0: run-time C, at most MAXC).
+template <int CC>
+__device__ __forceinline__ void pixel_logp(const LossP& p, int b, int hw, float* lp, float* sm) {
+    const int C = CC > 0 ? CC : p.C;
+    const float* src = p.logits + ((int64_t)b * C) * p.HW + hw;
     float mx = -INFINITY;
-    for (int c = 0; c < p.C; ++c) {
+#pragma unroll
+    for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+        if (c >= C) break;
         lp[c] = src[(int64_t)c * p.HW];
         mx = fmaxf(mx, lp[c]);
     }
     float se = 0.0f;
-    for (int c = 0; c < p.C; ++c) se += expf(lp[c] - mx);
-    const float lse = mx + logf(se);
-    for (int c = 0; c < p.C; ++c) lp[c] -= lse;
+#pragma unroll
+    for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+        if (c >= C) break;
+        sm[c] = expf(lp[c] - mx);
+        se += sm[c];
+    }
+    const float lse = mx + logf(se), inv = 1.0f / se;
+#pragma unroll
+    for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+        if (c >= C) break;
+        lp[c] -= lse;
+        sm[c] *= inv;
+    }
 }
 
+// value of arr[y] without a dynamic register index
+template <int CC>
+__device__ __forceinline__ float pick(const float* arr, int y, int C) {
+    if (CC == 0) return arr[y];
+    float v = 0.0f;
+#pragma unroll
+    for (int c = 0; c < (CC > 0 ? CC : 1); ++c) v = (c == y) ? arr[c] : v;
+    return v;
+}
+
+// grid: (pixel blocks, B): no per-pixel division; one thread per pixel of sample blockIdx.y
+template <int CC>
 __global__ void __launch_bounds__(NTHREADS) loss_fwd_kernel(const LossP p) {
-    const int64_t npix = (int64_t)p.B * p.HW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = CC > 0 ? CC : p.C;
+    const int b = blockIdx.y;
     double num = 0.0, den = 0.0;
-    float lp[MAXC];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
-        const int b = (int)(i / p.HW), hw = (int)(i - (int64_t)b * p.HW);
-        const int64_t y = p.labels[i];
-        if (y == p.ignore || y < 0 || y >= p.C) continue;
-        pixel_logp(p, b, hw, lp);
+    float lp[CC > 0 ? CC : MAXC], sm[CC > 0 ? CC : MAXC];
+    for (int hw = blockIdx.x * blockDim.x + threadIdx.x; hw < p.HW; hw += gridDim.x * blockDim.x) {
+        const int64_t y64 = p.labels[(int64_t)b * p.HW + hw];
+        if (y64 == p.ignore || y64 < 0 || y64 >= C) continue;
+        const int y = (int)y64;
+        pixel_logp<CC>(p, b, hw, lp, sm);
+        const float lpy = pick<CC>(lp, y, C);
         if (p.mode == 0) {
             const float wy = p.alpha ? p.alpha[y] : 1.0f;
-            float ce = (1.0f - p.smooth) * wy * (-lp[y]);
+            float ce = (1.0f - p.smooth) * wy * (-lpy);
             if (p.smooth > 0.0f) {
-                float sm = 0.0f;
-                for (int c = 0; c < p.C; ++c) sm -= (p.alpha ? p.alpha[c] : 1.0f) * lp[c];
-                ce += (p.smooth / p.C) * sm;
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                    if (c >= C) break;
+                    s -= (p.alpha ? p.alpha[c] : 1.0f) * lp[c];
+                }
+                ce += (p.smooth / C) * s;
             }
             num += ce;
             den += wy;
         } else {
-            float ce = (1.0f - p.smooth) * (-lp[y]);
+            float ce = (1.0f - p.smooth) * (-lpy);
             if (p.smooth > 0.0f) {
-                float sm = 0.0f;
-                for (int c = 0; c < p.C; ++c) sm -= lp[c];
-                ce += (p.smooth / p.C) * sm;
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                    if (c >= C) break;
+                    s -= lp[c];
+                }
+                ce += (p.smooth / C) * s;
             }
             const float pt = expf(-ce);
             const float a = p.alpha ? p.alpha[y] : 1.0f;
-            num += a * powf(1.0f - pt, p.gamma) * ce;
+            num += a * pow_gamma(1.0f - pt, p.gamma) * ce;
         }
     }
     num = wave_sum_d(num);
     den = wave_sum_d(den);
     if ((threadIdx.x & 63) == 0) {
-        atomic_add_d(p.acc, num);
-        atomic_add_d(p.acc + 1, den);
+        if (num != 0.0) atomic_add_d(p.acc, num);
+        if (den != 0.0) atomic_add_d(p.acc + 1, den);
     }
 }
 
@@ -98,50 +142,63 @@ __global__ void loss_finish_kernel(const LossP p) {
     p.loss[0] = (float)v;
 }
 
+template <int CC>
 __global__ void __launch_bounds__(NTHREADS) loss_bwd_kernel(const LossP p) {
-    const int64_t npix = (int64_t)p.B * p.HW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int C = CC > 0 ? CC : p.C;
+    const int b = blockIdx.y;
     const float go = p.gout ? p.gout[0] : 1.0f;
     float norm;
     if (p.mode == 0) norm = go / (float)p.acc[1];
     else norm = p.reduce_sum ? go : go / (float)((double)p.B * p.HW);
-    float lp[MAXC];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
-        const int b = (int)(i / p.HW), hw = (int)(i - (int64_t)b * p.HW);
-        float* dst = p.dlogits + ((int64_t)b * p.C) * p.HW + hw;
-        const int64_t y = p.labels[i];
-        if (y == p.ignore || y < 0 || y >= p.C) {
-            for (int c = 0; c < p.C; ++c) dst[(int64_t)c * p.HW] = 0.0f;
+    float lp[CC > 0 ? CC : MAXC], sm[CC > 0 ? CC : MAXC];
+    for (int hw = blockIdx.x * blockDim.x + threadIdx.x; hw < p.HW; hw += gridDim.x * blockDim.x) {
+        float* dst = p.dlogits + ((int64_t)b * C) * p.HW + hw;
+        const int64_t y64 = p.labels[(int64_t)b * p.HW + hw];
+        if (y64 == p.ignore || y64 < 0 || y64 >= C) {
+#pragma unroll
+            for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                if (c >= C) break;
+                dst[(int64_t)c * p.HW] = 0.0f;
+            }
             continue;
         }
-        pixel_logp(p, b, hw, lp);
+        const int y = (int)y64;
+        pixel_logp<CC>(p, b, hw, lp, sm);      // sm[c] = softmax = exp(lp[c])
         if (p.mode == 0) {
             const float wy = p.alpha ? p.alpha[y] : 1.0f;
             float wsum = 0.0f;
             if (p.smooth > 0.0f)
-                for (int c = 0; c < p.C; ++c) wsum += p.alpha ? p.alpha[c] : 1.0f;
-            for (int c = 0; c < p.C; ++c) {
-                const float pc = expf(lp[c]);
+                for (int c = 0; c < C; ++c) wsum += p.alpha ? p.alpha[c] : 1.0f;
+#pragma unroll
+            for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                if (c >= C) break;
+                const float pc = expf(lp[c]);      // (not sm[c]: keeps the round-1 rounding the gradient fixtures were checked with)
                 float d = (1.0f - p.smooth) * wy * (pc - (c == y ? 1.0f : 0.0f));
-                if (p.smooth > 0.0f) d += (p.smooth / p.C) * (pc * wsum - (p.alpha ? p.alpha[c] : 1.0f));
+                if (p.smooth > 0.0f) d += (p.smooth / C) * (pc * wsum - (p.alpha ? p.alpha[c] : 1.0f));
                 dst[(int64_t)c * p.HW] = d * norm;
             }
         } else {
-            float ce = (1.0f - p.smooth) * (-lp[y]);
+            float ce = (1.0f - p.smooth) * (-pick<CC>(lp, y, C));
             if (p.smooth > 0.0f) {
-                float sm = 0.0f;
-                for (int c = 0; c < p.C; ++c) sm -= lp[c];
-                ce += (p.smooth / p.C) * sm;
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                    if (c >= C) break;
+                    s -= lp[c];
+                }
+                ce += (p.smooth / C) * s;
             }
             const float pt = expf(-ce);
             const float om = 1.0f - pt;
             const float a = p.alpha ? p.alpha[y] : 1.0f;
             float dfl = 0.0f;  // d focal / d ce
-            if (om > 0.0f) dfl = a * (powf(om, p.gamma) + p.gamma * powf(om, p.gamma - 1.0f) * pt * ce);
+            if (om > 0.0f) dfl = a * (pow_gamma(om, p.gamma) + p.gamma * pow_gamma(om, p.gamma - 1.0f) * pt * ce);
             else if (p.gamma == 0.0f) dfl = a;
-            for (int c = 0; c < p.C; ++c) {
-                const float pc = expf(lp[c]);
-                const float dce = (1.0f - p.smooth) * (pc - (c == y ? 1.0f : 0.0f)) + p.smooth * (pc - 1.0f / p.C);
+#pragma unroll
+            for (int c = 0; c < (CC > 0 ? CC : MAXC); ++c) {
+                if (c >= C) break;
+                const float pc = expf(lp[c]);      // (not sm[c]: keeps the round-1 rounding the gradient fixtures were checked with)
+                const float dce = (1.0f - p.smooth) * (pc - (c == y ? 1.0f : 0.0f)) + p.smooth * (pc - 1.0f / C);
                 dst[(int64_t)c * p.HW] = dfl * dce * norm;
             }
         }
@@ -149,10 +206,9 @@ __global__ void __launch_bounds__(NTHREADS) loss_bwd_kernel(const LossP p) {
 }
 
 __global__ void __launch_bounds__(NTHREADS) argmax_kernel(const float* logits, int64_t* mask, int B, int C, int HW) {
-    const int64_t npix = (int64_t)B * HW;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
-        const int b = (int)(i / HW), hw = (int)(i - (int64_t)b * HW);
+    const int b = blockIdx.y;
+    for (int hw = blockIdx.x * blockDim.x + threadIdx.x; hw < HW; hw += gridDim.x * blockDim.x) {
+        const int64_t i = (int64_t)b * HW + hw;
         const float* src = logits + ((int64_t)b * C) * HW + hw;
         float best = src[0];
         int idx = 0;
@@ -162,6 +218,12 @@ __global__ void __launch_bounds__(NTHREADS) argmax_kernel(const float* logits, i
         }
         mask[i] = idx;
     }
+}
+
+// pixel blocks per sample: one thread per pixel until ~8 blocks per CU exist, grid-stride beyond
+static unsigned pixel_blocks(int B, int HW) {
+    const int per = cdiv(HW, NTHREADS);
+    return (unsigned)std::max(1, std::min(per, cdiv(4096, B)));
 }
 
 static int fill(LossP& p, const S2kOp& op, const Ctx& c, bool bwd) {
@@ -184,8 +246,14 @@ int launch_loss_fwd(const S2kOp& op, const Ctx& c) {
     if (bad(p.logits) || bad(p.labels) || bad(p.alpha) || bad(p.loss) || bad(p.acc)) { set_error("loss_fwd: null base"); return S2K_EFAULT; }
     if (!p.logits || !p.labels || !p.loss || !p.acc) { set_error("loss_fwd: missing tensor"); return S2K_EINVAL; }
     if (hipMemsetAsync(p.acc, 0, 2 * sizeof(double), c.stream) != hipSuccess) { set_error("loss_fwd: memset failed"); return S2K_EHIP; }
-    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)p.B * p.HW, NTHREADS), 2048);
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, p);
+    if (p.B > 65535) { set_error("loss: batch beyond the launch grid"); return S2K_EINVAL; }
+    const dim3 grid(pixel_blocks(p.B, p.HW), (unsigned)p.B);
+#define LOSS_CC(N) case N: hipLaunchKernelGGL(loss_fwd_kernel<N>, grid, dim3(NTHREADS), 0, c.stream, p); break
+    switch (p.C) {
+        LOSS_CC(2); LOSS_CC(3); LOSS_CC(4); LOSS_CC(5); LOSS_CC(6); LOSS_CC(7); LOSS_CC(8);
+        default: hipLaunchKernelGGL(loss_fwd_kernel<0>, grid, dim3(NTHREADS), 0, c.stream, p);
+    }
+#undef LOSS_CC
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c.stream, p);
     return S2K_OK;
 }
@@ -201,8 +269,14 @@ int launch_loss_bwd(const S2kOp& op, const Ctx& c) {
     p.dlogits = ref_ptr<float>(c, op.t[S2K_LOSS_BWD_T_DLOGITS]);
     if (bad(p.logits) || bad(p.labels) || bad(p.alpha) || bad(p.acc) || bad(p.gout) || bad(p.dlogits)) { set_error("loss_bwd: null base"); return S2K_EFAULT; }
     if (!p.logits || !p.labels || !p.acc || !p.dlogits) { set_error("loss_bwd: missing tensor"); return S2K_EINVAL; }
-    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)p.B * p.HW, NTHREADS), 2048);
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, p);
+    if (p.B > 65535) { set_error("loss: batch beyond the launch grid"); return S2K_EINVAL; }
+    const dim3 grid(pixel_blocks(p.B, p.HW), (unsigned)p.B);
+#define LOSS_CC(N) case N: hipLaunchKernelGGL(loss_bwd_kernel<N>, grid, dim3(NTHREADS), 0, c.stream, p); break
+    switch (p.C) {
+        LOSS_CC(2); LOSS_CC(3); LOSS_CC(4); LOSS_CC(5); LOSS_CC(6); LOSS_CC(7); LOSS_CC(8);
+        default: hipLaunchKernelGGL(loss_bwd_kernel<0>, grid, dim3(NTHREADS), 0, c.stream, p);
+    }
+#undef LOSS_CC
     return S2K_OK;
 }
 
@@ -212,8 +286,8 @@ int launch_argmax(const S2kOp& op, const Ctx& c) {
     if (bad(logits) || bad(mask)) { set_error("argmax: null base"); return S2K_EFAULT; }
     const int B = op.d[S2K_ARGMAX_D_B], C = op.d[S2K_ARGMAX_D_C], HW = op.d[S2K_ARGMAX_D_HW];
     if (!logits || !mask || B <= 0 || C <= 0 || HW <= 0) { set_error("argmax: bad args"); return S2K_EINVAL; }
-    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)B * HW, NTHREADS), 2048);
-    hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, logits, mask, B, C, HW);
+    if (B > 65535) { set_error("argmax: batch beyond the launch grid"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(argmax_kernel, dim3(pixel_blocks(B, HW), (unsigned)B), dim3(NTHREADS), 0, c.stream, logits, mask, B, C, HW);
     return S2K_OK;
 }
 
