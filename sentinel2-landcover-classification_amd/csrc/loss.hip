@@ -126,9 +126,17 @@ __global__ void __launch_bounds__(NTHREADS) loss_fwd_kernel(const LossP p) {
             num += a * pow_gamma(1.0f - pt, p.gamma) * ce;
         }
     }
+    // one atomic pair per WORKGROUP: the two sums live at one address each, and same-address f64 atomics execute one after the
+    // other at the memory side (16 k waves adding there took 200 us of a kernel whose data streams in 15)
+    __shared__ double red[8];
     num = wave_sum_d(num);
     den = wave_sum_d(den);
-    if ((threadIdx.x & 63) == 0) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave] = num; red[4 + wave] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num = (red[0] + red[1]) + (red[2] + red[3]);
+        den = (red[4] + red[5]) + (red[6] + red[7]);
         if (num != 0.0) atomic_add_d(p.acc, num);
         if (den != 0.0) atomic_add_d(p.acc + 1, den);
     }
@@ -220,10 +228,10 @@ __global__ void __launch_bounds__(NTHREADS) argmax_kernel(const float* logits, i
     }
 }
 
-// pixel blocks per sample: one thread per pixel until ~8 blocks per CU exist, grid-stride beyond
+// pixel blocks per sample: one thread per pixel until ~4 blocks per CU exist, grid-stride beyond
 static unsigned pixel_blocks(int B, int HW) {
     const int per = cdiv(HW, NTHREADS);
-    return (unsigned)std::max(1, std::min(per, cdiv(4096, B)));
+    return (unsigned)std::max(1, std::min(per, cdiv(1024, B)));
 }
 
 static int fill(LossP& p, const S2kOp& op, const Ctx& c, bool bwd) {

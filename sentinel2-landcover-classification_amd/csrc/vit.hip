@@ -590,9 +590,16 @@ __global__ void __launch_bounds__(256) mae_loss_rows_kernel(const PatchP p) {
         }
     }
     if (!BWD) {
+        // one atomic pair per workgroup (same-address f64 atomics execute one after the other at the memory side)
+        __shared__ double red[8];
         num = wave_sum_d(num);
         den = wave_sum_d(den);
-        if ((threadIdx.x & 63) == 0) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[wave] = num; red[4 + wave] = den; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            num = (red[0] + red[1]) + (red[2] + red[3]);
+            den = (red[4] + red[5]) + (red[6] + red[7]);
             if (num != 0.0) atomic_add_d(p.acc, num);
             if (den != 0.0) atomic_add_d(p.acc + 1, den);
         }
