@@ -36,7 +36,8 @@ __device__ __forceinline__ bool get_task(int HW, int64_t nplanes, Task& t) {
     const int chunks = (HW + CHUNK - 1) / CHUNK;
     const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (task >= nplanes * chunks) return false;
-    t.plane = task / chunks;
+    // (tasks fit 32 bits - task_blocks() checks - and a 64-bit division is ~150 instructions per wave)
+    t.plane = (int64_t)((uint32_t)task / (uint32_t)chunks);
     const int ck = (int)(task - t.plane * chunks);
     t.start = ck * CHUNK;
     t.count = min(CHUNK, HW - t.start);
@@ -45,6 +46,7 @@ __device__ __forceinline__ bool get_task(int HW, int64_t nplanes, Task& t) {
 
 static unsigned task_blocks(int HW, int64_t nplanes) {
     const int chunks = (HW + CHUNK - 1) / CHUNK;
+    if (nplanes * chunks >= 0xffffffffll) return 0;          // (a launch of 0 blocks fails loudly in check_launch)
     return (unsigned)cdiv64(nplanes * chunks, 4);
 }
 
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, 
         if (plane >= nplanes) return;
         start = 0; count = HW;
     }
-    const int c = (int)(plane % C);
+    const int c = (int)((uint32_t)plane % (uint32_t)C);
     float scale = 1.0f, shift = 0.0f;
     if (MODE == 0 && fold.stats) bn_fold_wave(fold, C, c, plane < C, scale, shift);   // BN_FINALIZE folded in (one wave per plane)
     else if (MODE != 2 && pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(NTHREADS) se_bn_sums_kernel(const float* g, co
     const int lane = threadIdx.x & 63;
     const int64_t plane = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (plane >= nplanes) return;
-    const int c = (int)(plane % C);
+    const int c = (int)((uint32_t)plane % (uint32_t)C);
     const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
     const int64_t base = plane * HW;
     float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
@@ -785,8 +787,8 @@ __global__ void __launch_bounds__(NTHREADS) bn_bwd_reduce_kernel(const float* g,
     Task t;
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
-    const int c = (int)(t.plane % C);
-    const int b = (int)(t.plane / C);
+    const int c = (int)((uint32_t)t.plane % (uint32_t)C);
+    const int b = (int)((uint32_t)t.plane / (uint32_t)C);
     const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
     float mul = mulbc ? mulbc[t.plane] : 1.0f;
     if (noise) mul *= floorf(keep + noise[b]) / keep;
@@ -910,7 +912,7 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     Task t;
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
-    const int c = (int)(t.plane % C);
+    const int c = (int)((uint32_t)t.plane % (uint32_t)C);
     float k0, k1, k2;  // out = k0*a + k1*y + k2
     float gmul = 1.0f, gadd = 0.0f, bscale = 1.0f, bshift = 0.0f;
     if (MODE == 3) {
