@@ -705,15 +705,16 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_b_kernel(const float* dgp,
     const int64_t total = (int64_t)C * Q;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (C * Q fits 32 bits - the launchers cap Q at 8192 and C at ~16 k - and a 64-bit division per element cost more than the sum)
     for (int64_t e = t0; e < total; e += stride) {  // dw2[c][j], j fastest
-        const int cc = (int)(e / Q), j = (int)(e - (int64_t)cc * Q);
+        const int cc = (int)((uint32_t)e / (uint32_t)Q), j = (int)(e - (int64_t)cc * Q);
         float s = 0.0f;
 #pragma unroll 8
         for (int b = 0; b < B; ++b) s = fmaf(dgp[(int64_t)b * C + cc], hs[(int64_t)b * Q + j], s);
         dw2[e] += s;
     }
     for (int64_t e = t0; e < total; e += stride) {  // dw1[j][c], c fastest
-        const int j = (int)(e / C), cc = (int)(e - (int64_t)j * C);
+        const int j = (int)((uint32_t)e / (uint32_t)C), cc = (int)(e - (int64_t)j * C);
         float s = 0.0f;
 #pragma unroll 8
         for (int b = 0; b < B; ++b) s = fmaf(dhp[(int64_t)b * Q + j], pool[(int64_t)b * C + cc], s);
