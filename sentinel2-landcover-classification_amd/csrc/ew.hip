@@ -269,6 +269,43 @@ __global__ void __launch_bounds__(NTHREADS) plane_reduce_kernel(const float* g, 
     }
 }
 
+// Large planes of few channels (the 128x128 stages: 24 - 144 channels, 768 - 4608 planes): one WORKGROUP per plane - four waves
+// split it and combine through LDS.  One wave per plane left three quarters of the SIMDs without a wave and each wave with
+// 64 dependent iterations (40 us for a 50 MB tensor).
+__global__ void __launch_bounds__(NTHREADS) se_pool_big_kernel(const float* y, const float* bnv, float* out, int C, int HW, int pro,
+                                                               const BnFold fold) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t plane = blockIdx.x;
+    const int c = (int)((uint32_t)plane % (uint32_t)C);
+    float scale = 1.0f, shift = 0.0f;
+    if (fold.stats) bn_fold_wave(fold, C, c, plane < C && wave == 0, scale, shift);
+    else if (pro != S2K_PRO_NONE) { scale = bnv[c]; shift = bnv[C + c]; }
+    const float4* y4 = reinterpret_cast<const float4*>(y + plane * HW);
+    const int n4 = HW >> 2;
+    float s0 = 0.0f, s1 = 0.0f;
+    int i = threadIdx.x;
+    for (; i + NTHREADS < n4; i += 2 * NTHREADS) {
+        float4 a = y4[i], b = y4[i + NTHREADS];
+        a.x = apply_pro(a.x, pro, scale, shift); a.y = apply_pro(a.y, pro, scale, shift);
+        a.z = apply_pro(a.z, pro, scale, shift); a.w = apply_pro(a.w, pro, scale, shift);
+        b.x = apply_pro(b.x, pro, scale, shift); b.y = apply_pro(b.y, pro, scale, shift);
+        b.z = apply_pro(b.z, pro, scale, shift); b.w = apply_pro(b.w, pro, scale, shift);
+        s0 += (a.x + a.y) + (a.z + a.w);
+        s1 += (b.x + b.y) + (b.z + b.w);
+    }
+    for (; i < n4; i += NTHREADS) {
+        float4 a = y4[i];
+        a.x = apply_pro(a.x, pro, scale, shift); a.y = apply_pro(a.y, pro, scale, shift);
+        a.z = apply_pro(a.z, pro, scale, shift); a.w = apply_pro(a.w, pro, scale, shift);
+        s0 += (a.x + a.y) + (a.z + a.w);
+    }
+    const float s = wave_sum(s0 + s1);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[plane] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW;
+}
+
 // Small planes (HW <= 256, the 16x16 and 8x8 stages where C is in the hundreds or thousands): one wave per CHANNEL walks
 // the batch - LPP = pow2ceil(HW / 4) lanes hold one plane as float4s, 64 / LPP planes (samples) per pass.  {scale, shift}
 // (from BNV, or from the statistics when BN_FINALIZE is folded in) are formed once per channel instead of once per (b, c)
@@ -325,6 +362,10 @@ int launch_se_pool(const S2kOp& op, const Ctx& c) {
     if (fold.stats && !pro) { set_error("se_pool: FSTATS without a prologue"); return S2K_EINVAL; }
     {
         const int B = op.d[S2K_SE_POOL_D_B], C = op.d[S2K_SE_POOL_D_C], HW = op.d[S2K_SE_POOL_D_HW];
+        if (HW >= 4096 && (HW & 3) == 0 && (int64_t)B * C <= 8192) {
+            hipLaunchKernelGGL(se_pool_big_kernel, dim3((unsigned)(B * C)), dim3(NTHREADS), 0, c.stream, y, bnv, pool, C, HW, pro, fold);
+            return S2K_OK;
+        }
         if (HW <= 256 && (HW & 3) == 0 && B > 1) {
             int lpp = 1;
             while (4 * lpp < HW) lpp <<= 1;
@@ -396,6 +437,50 @@ __global__ void __launch_bounds__(NTHREADS) se_bn_sums_kernel(const float* g, co
     }
 }
 
+// SE_BN_SUMS on large planes of few channels: one workgroup per plane (see se_pool_big_kernel)
+__global__ void __launch_bounds__(NTHREADS) se_bn_sums_big_kernel(const float* g, const float* y, const float* bnv, float* dgate, float* ps,
+                                                                  int C, int HW, int64_t nplanes) {
+    __shared__ float red[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t plane = blockIdx.x;
+    const int c = (int)((uint32_t)plane % (uint32_t)C);
+    const float scale = bnv[c], shift = bnv[C + c], mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
+    auto acc = [&](float d, float yy) {
+        const float u = fmaf(yy, scale, shift);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        const float ap = sg * (1.0f + u * (1.0f - sg)), xh = (yy - mean) * invstd;
+        const float t = d * ap;
+        p0 = fmaf(d, u * sg, p0);
+        p1 += t;
+        p2 += ap;
+        p3 = fmaf(t, xh, p3);
+        p4 = fmaf(ap, xh, p4);
+    };
+    const float4* g4 = reinterpret_cast<const float4*>(g + plane * HW);
+    const float4* y4 = reinterpret_cast<const float4*>(y + plane * HW);
+    const int n4 = HW >> 2;
+    int i = threadIdx.x;
+    for (; i + NTHREADS < n4; i += 2 * NTHREADS) {
+        const float4 d0 = g4[i], y0 = y4[i], d1 = g4[i + NTHREADS], y1 = y4[i + NTHREADS];
+        acc(d0.x, y0.x); acc(d0.y, y0.y); acc(d0.z, y0.z); acc(d0.w, y0.w);
+        acc(d1.x, y1.x); acc(d1.y, y1.y); acc(d1.z, y1.z); acc(d1.w, y1.w);
+    }
+    for (; i < n4; i += NTHREADS) {
+        const float4 d0 = g4[i], y0 = y4[i];
+        acc(d0.x, y0.x); acc(d0.y, y0.y); acc(d0.z, y0.z); acc(d0.w, y0.w);
+    }
+    p0 = wave_sum_hi(p0); p1 = wave_sum_hi(p1); p2 = wave_sum_hi(p2); p3 = wave_sum_hi(p3); p4 = wave_sum_hi(p4);
+    if (lane == 63) { red[wave][0] = p0; red[wave][1] = p1; red[wave][2] = p2; red[wave][3] = p3; red[wave][4] = p4; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int k = threadIdx.x;
+        const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (k == 0) dgate[plane] = v;
+        else ps[(int64_t)(k - 1) * nplanes + plane] = v;
+    }
+}
+
 // SE_BN_SUMS on small planes (<= 64 elements): one wave per channel (and batch chunk), 16 lanes per plane, four planes per pass,
 // the loads of four passes in flight; the five plane sums are group reductions (one per four planes instead of one per plane)
 __global__ void __launch_bounds__(NTHREADS) se_bn_sums_small_kernel(const float* g, const float* y, const float* bnv, float* dgate,
@@ -463,6 +548,10 @@ int launch_se_bn_sums(const S2kOp& op, const Ctx& c) {
         set_error("se_bn_sums: bad args (SiLU only)"); return S2K_EINVAL;
     }
     const int64_t nplanes = (int64_t)B * C;
+    if (HW >= 4096 && (HW & 3) == 0 && nplanes <= 8192) {
+        hipLaunchKernelGGL(se_bn_sums_big_kernel, dim3((unsigned)nplanes), dim3(NTHREADS), 0, c.stream, g, y, bnv, dgate, ps, C, HW, nplanes);
+        return S2K_OK;
+    }
     if (HW <= 64 && (HW & 3) == 0 && B > 1) {
         int lpp = 1;
         while (4 * lpp < HW) lpp <<= 1;

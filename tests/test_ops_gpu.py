@@ -458,7 +458,7 @@ def test_bn_residual(B, C, HW, ident, noise):
     c.run("BN_RESIDUAL", ["xout"], 1e-6, Y=y, BNV=bnv, IDENT=idt, NOISE=nz, XOUT=out, B=B, C=C, HW=HW, KEEP=0.55)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (11, 130, 64), (3, 7, 36)])
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (11, 130, 64), (3, 7, 36), (3, 5, 4100 * 4)])   # (last: workgroup per plane)
 def test_se_pool_bwd_reduce_channel_sum(B, C, HW):
     c = Case(10)
     y, bnv = c.t("y", (B, C, HW)), c.bnv("bnv", C)
@@ -628,8 +628,8 @@ def test_convt_wgrad_gather_reads_past_2gib():
           H=H2, W=H2, KH=2, KW=2, STRIDE=2, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_GATHER2X2)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 5, 4100), (6, 70, 64), (35, 9, 16), (4, 300, 36)])   # (<= 64: channel-per-wave kernels)
-def test_se_bn_two_pass_stages(B, C, HW):
+@pytest.mark.parametrize("B,C,HW", [(2, 24, 256), (3, 10, 49), (1, 5, 4100), (6, 70, 64), (35, 9, 16), (4, 300, 36), (2, 6, 128 * 129)])
+def test_se_bn_two_pass_stages(B, C, HW):          # (<= 64 elements: channel-per-wave kernels; >= 4096: workgroup per plane)
     """SE_BN_SUMS (one pass: dgate + the four plane sums), SE_BN_COMBINE (per-channel BatchNorm-backward sums once the SE
     factors are known) and the recomputing form of BN_BWD_APPLY; together they equal SE_BWD_REDUCE + BN_BWD_REDUCE + APPLY."""
     c = Case(21)
@@ -714,7 +714,7 @@ def test_dwconv_fwd_with_folded_bn_finalize(geo):
     c.run("DWCONV_FWD", ["y", "stats", "bnv", "frm", "frv"], 1e-4, sum0=("stats",), X=x, BNV=bnv, WT=w, Y=y, STATS=st, PRO=2, NREP=nrep, **fold, **g)
 
 
-@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (2, 3000, 64), (7, 100, 64), (33, 9, 16), (5, 300, 196)])
+@pytest.mark.parametrize("B,C,HW", [(2, 48, 256), (3, 20, 49), (1, 5, 9000), (2, 3000, 64), (7, 100, 64), (33, 9, 16), (5, 300, 196), (2, 7, 8192)])
 def test_se_pool_and_bn_residual_with_folded_bn_finalize(B, C, HW):
     c = Case(32)
     y = c.t("y", (B, C, HW))
