@@ -408,11 +408,19 @@ def main() -> None:
             del model, opt
             torch.cuda.empty_cache()
             for what in ("mae", "seg_frozen", "seg_unfrozen"):
-                extra["prithvi_" + what] = prithvi_workload(what, dev, peaks)
+                try:        # an extra key must never cost the headline line
+                    extra["prithvi_" + what] = prithvi_workload(what, dev, peaks)
+                except Exception as e:  # noqa: BLE001
+                    print(f"bench.py: prithvi_{what} failed: {e!r}", file=sys.stderr, flush=True)
+                    extra["prithvi_" + what] = {"error": repr(e)[:300]}
                 torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             print(f"bench.py: GPU legs done ({world * B * args.steps / dt:.1f} tiles/s); timing the CPU oracle", file=sys.stderr, flush=True)
-            cpu = cpu_baseline(args.version, C, H, ncls)
+            try:
+                cpu = cpu_baseline(args.version, C, H, ncls)
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: cpu_baseline failed: {e!r}", file=sys.stderr, flush=True)
+                cpu = {"error": repr(e)[:300]}
         tiles = world * B * args.steps
         line = {
             "metric": "Sentinel-2 256x256x13 tiles/sec fwd+bwd", "value": round(tiles / dt, 2), "unit": "tiles/s",
