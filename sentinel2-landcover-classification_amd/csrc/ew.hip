@@ -821,6 +821,85 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_b_kernel(const float* dgp,
     }
 }
 
+// Phases A1 + A2 in one launch for the layers whose squeeze width fits a wave (Q <= 64, 28 of the 39 blocks of a b5): one
+// workgroup of 16 waves per sample; the two-kernel form costs two launches for microseconds of arithmetic.  (The same merge of
+// the FORWARD pair was slower: its first Linear wants Q / 4 workgroups per sample, not one.)
+__global__ void __launch_bounds__(1024) se_fc_bwd_small_kernel(float* dgate, const float* gate, float* hpre, const float* w1, const float* w2,
+                                                               float* hs, float* dpool, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sdg = smem;              // [C]
+    float* part = smem + C;         // [16][64]
+    float* dhs = part + 16 * 64;    // [64] dhp of this sample
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < C; i += 1024) {
+        const float g = gate[(int64_t)b * C + i];
+        const float v = dgate[(int64_t)b * C + i] * g * (1.0f - g);
+        sdg[i] = v;
+        dgate[(int64_t)b * C + i] = v;                  // DGATE <- d(pre-sigmoid), as phase A2 leaves it
+    }
+    __syncthreads();
+    const int j = lane;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (j < Q) {
+        int i = wave;
+        for (; i + 112 < C; i += 128) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = w2[(int64_t)(i + 16 * u) * Q + j];
+            s0 = fmaf(w[0], sdg[i], s0);
+            s1 = fmaf(w[1], sdg[i + 16], s1);
+            s2 = fmaf(w[2], sdg[i + 32], s2);
+            s3 = fmaf(w[3], sdg[i + 48], s3);
+            s0 = fmaf(w[4], sdg[i + 64], s0);
+            s1 = fmaf(w[5], sdg[i + 80], s1);
+            s2 = fmaf(w[6], sdg[i + 96], s2);
+            s3 = fmaf(w[7], sdg[i + 112], s3);
+        }
+        for (; i < C; i += 16) s0 = fmaf(w2[(int64_t)i * Q + j], sdg[i], s0);
+    }
+    part[wave * 64 + lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0) {
+        float dhp = 0.0f;
+        if (j < Q) {
+            float dh = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) dh += part[w * 64 + lane];
+            const float hp = hpre[(int64_t)b * Q + j];
+            hs[(int64_t)b * Q + j] = silu_f(hp);
+            dhp = dh * act_grad(hp, S2K_PRO_SILU);
+            hpre[(int64_t)b * Q + j] = dhp;             // HPRE now holds dhp
+        }
+        dhs[lane] = dhp;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        int jj = 0;
+        for (; jj + 8 <= Q; jj += 8) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = w1[(int64_t)(jj + u) * C + c];
+            t0 = fmaf(w[0], dhs[jj], t0);
+            t1 = fmaf(w[1], dhs[jj + 1], t1);
+            t2 = fmaf(w[2], dhs[jj + 2], t2);
+            t3 = fmaf(w[3], dhs[jj + 3], t3);
+            t0 = fmaf(w[4], dhs[jj + 4], t0);
+            t1 = fmaf(w[5], dhs[jj + 5], t1);
+            t2 = fmaf(w[6], dhs[jj + 6], t2);
+            t3 = fmaf(w[7], dhs[jj + 7], t3);
+        }
+        for (; jj + 4 <= Q; jj += 4) {
+            t0 = fmaf(w1[(int64_t)jj * C + c], dhs[jj], t0);
+            t1 = fmaf(w1[(int64_t)(jj + 1) * C + c], dhs[jj + 1], t1);
+            t2 = fmaf(w1[(int64_t)(jj + 2) * C + c], dhs[jj + 2], t2);
+            t3 = fmaf(w1[(int64_t)(jj + 3) * C + c], dhs[jj + 3], t3);
+        }
+        for (; jj < Q; ++jj) t0 = fmaf(w1[(int64_t)jj * C + c], dhs[jj], t0);
+        dpool[(int64_t)b * C + c] = (t0 + t1) + (t2 + t3);
+    }
+}
+
 int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
     float* dgate = ref_ptr<float>(c, op.t[S2K_SE_FC_BWD_T_DGATE]);
     const float* gate = ref_ptr<const float>(c, op.t[S2K_SE_FC_BWD_T_GATE]);
@@ -842,8 +921,13 @@ int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
     }
     if (Q > 8192 || B > 65535) { set_error("se_fc_bwd: C/Q too large"); return S2K_EINVAL; }
     if ((size_t)(C + 1024) * 4 > 64000) { set_error("se_fc_bwd: C too large"); return S2K_EINVAL; }
+    if (Q <= 64) {
+        hipLaunchKernelGGL(se_fc_bwd_small_kernel, dim3(B), dim3(1024), (size_t)(C + 1024 + 64) * sizeof(float), c.stream, dgate, gate, hpre, w1, w2,
+                           hs, dpool, C, Q);
+    } else {
     hipLaunchKernelGGL(se_fc_bwd_a1_kernel, dim3(cdiv(Q, 64), B), dim3(1024), (C + 1024) * sizeof(float), c.stream, dgate, gate, hpre, w2, hs, B, C, Q);
     hipLaunchKernelGGL(se_fc_bwd_a2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, dgate, gate, hpre, w1, dpool, B, C, Q);
+    }
     if (!params) return S2K_OK;
     const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
     hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);
