@@ -10,7 +10,13 @@ only), and - N = 1 only, skipped with --no-prithvi - the Prithvi workloads of BA
 configs[3] / [4] as extra keys (`prithvi_mae`, `prithvi_seg_frozen`, `prithvi_seg_unfrozen`); the
 headline `value` is always configs[1].
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]       (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment), or called plainly as `python bench.py --gpus N ...`: the parent process then
+starts N rank processes itself BEFORE it touches the GPU (it never initialises HIP), relays rank 0's single JSON line and
+exits with the worst child exit code - the way Lightning starts the reference's ranks from `pl.Trainer(devices=N)`
+(/root/reference/src/train_segmentation.py:273-280).
 """
 from __future__ import annotations
 
@@ -295,6 +301,96 @@ def prithvi_workload(what: str, dev, peaks, steps=8, warmup=3) -> dict:
             "batch": B, "dtype": "f32", "step_algorithmic_tflops": round(alg_tf, 1), "step_frac_of_mfma_peak": round(alg_tf / PEAK_F32_MFMA_TFLOPS, 4), "adam_ms": round(time_adam(opt, dev), 4), "loss": round(float(loss.detach()), 6), "roofline": make_roofline(kernels, peaks, traffic_workload=False)}
 
 
+def launch_ranks(n: int, argv: list[str], script: str | None = None) -> int:
+    """`python bench.py --gpus N` with no rank environment: start N fresh rank processes (one per GPU) of this same script and
+    relay their output.  This parent must not have initialised the GPU (it only imported torch) and never does: replacing or
+    forking a process that holds a HIP context is what takes a node down.  Returns the worst child exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0's stdout is filtered (below): its one JSON line IS this program's output; the other ranks print nothing there
+        procs.append(subprocess.Popen([sys.executable, script or str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    worst = 0
+    try:
+        # libraries chat on stdout too (gloo: "[Gloo] Rank 0 is connected to ..."): only the result line goes to this program's
+        # stdout, everything else rank 0 printed there is passed on through stderr
+        for ln in procs[0].stdout:
+            is_result = False
+            if ln.lstrip().startswith("{"):
+                try:
+                    is_result = isinstance(json.loads(ln), dict)
+                except ValueError:
+                    pass
+            (sys.stdout if is_result else sys.stderr).write(ln)
+            (sys.stdout if is_result else sys.stderr).flush()
+        for p in procs:
+            rc = p.wait()
+            worst = rc if abs(rc) > abs(worst) else worst
+            if rc != 0:         # a dead rank leaves the others waiting in a collective: end them (exact PIDs, ours)
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    except BaseException:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        raise
+    return worst if worst >= 0 else 1
+
+
+def time_steps(step, n: int, dist, dev) -> float:
+    """Seconds for n steps, bracketed by barrier + synchronize on both sides, MAX over ranks."""
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64) if dist.get_backend() == "nccl" else torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms: float, calls: list) -> dict:
+    """What the gradient all-reduce costs (SURVEY.md §8d evidence for configs[2]): bucket count and bytes per step, the time
+    it adds to the step (`ms_exposed` = step with the reducer - the same segmented step with the hook replaced by a no-op,
+    i.e. what the overlap did NOT hide), and the bus bandwidth of the same buckets reduced back to back on an otherwise idle
+    GPU (2 (N-1)/N x bytes / time, the nccl-tests convention)."""
+    grads = model._grad_buffer()
+    buckets = [(lo, hi) for lo, hi in calls if hi > lo]
+    nbytes = 4 * sum(hi - lo for lo, hi in buckets)
+    iters = 5
+
+    def alone():
+        for lo, hi in buckets:
+            ddp.on_segment(lo, hi, grads)
+        ddp.finish()
+    alone()
+    dt = time_steps(alone, iters, dist, dev) / iters
+    bus = 2.0 * (world - 1) / world * nbytes / dt / 1e9
+    return {"buckets": len(buckets), "bytes": nbytes, "bucket_bytes": [4 * (hi - lo) for lo, hi in buckets],
+            "ms_exposed": round(step_ms - noop_ms, 3), "ms_step_with_reducer": round(step_ms, 3), "ms_step_noop_hook": round(noop_ms, 3),
+            "ms_alone": round(dt * 1e3, 3), "bus_gbps": round(bus, 1), "overlap_fraction": round(max(0.0, 1.0 - max(step_ms - noop_ms, 0.0) / (dt * 1e3)), 3),
+            "backend": dist.get_backend(), "op": "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,12 +405,14 @@ def main() -> None:
     ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1 only; the headline is unaffected)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called as the driver calls it (`python bench.py --gpus N ...`): become the launcher; no GPU call before or after
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # one rank per GPU; a rehearsal of the N-rank code path on a single-GPU box maps every rank onto device 0
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
@@ -366,24 +464,56 @@ def main() -> None:
         opt.step()
         return loss
 
+    last = {}
+
+    def timed_step():
+        last["loss"] = step()
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = time_steps(timed_step, args.steps, dist, dev)       # EXACTLY args.steps steps, barrier + synchronize on both sides, MAX over ranks
+    loss = last["loss"]
+    step_ms = dt / args.steps * 1e3
+
+    # ---- outside the timed region: what the all-reduce costs, and N = 1 on the SAME plan ---------------------------------
+    allreduce, same_plan = None, None
+    if ddp is not None:
+        # (a) the same segmented, tape-order backward with the bucket hook replaced by a no-op: no collective at all.  Its rate
+        #     is "N = 1 running the program the N > 1 ranks run" (FlatGradReducer switches the deferral of the decoder's weight
+        #     gradients off, ddp.py), the fair denominator of a weak-scaling efficiency.
+        calls = []
+        model._bwd_segment_hook = lambda lo, hi, grads: calls.append((lo, hi))
+        n_extra = max(3, min(args.steps, 10))
+        step()
+        calls.clear()
+        step()
+        buckets = list(calls)
+        noop_dt = time_steps(step, n_extra, dist, dev)
+        noop_ms = noop_dt / n_extra * 1e3
+        same_plan = round(B * n_extra / noop_dt, 2)
+        model._bwd_segment_hook = ddp.on_segment
+        try:
+            allreduce = allreduce_report(model, ddp, dist, dev, world, step_ms, noop_ms, buckets)
+        except Exception as e:  # noqa: BLE001
+            allreduce = {"error": repr(e)[:300]}
+    elif not args.no_profile and rank == 0:
+        # N = 1: the default plan defers the decoder's weight gradients (faster alone); also time the tape-order plan that the
+        # data-parallel ranks run, so that N > 1 lines can be compared with either
+        saved = dict(model._engines)
+        try:
+            model._defer_wgrads = False
+            model._engines.clear()
+            model._bwd_segment_hook = lambda lo, hi, grads: None
+            n_extra = max(3, min(args.steps, 10))
+            step(); step()
+            same_plan = round(B * n_extra / time_steps(step, n_extra, None, dev), 2)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: tape-order plan leg failed: {e!r}", file=sys.stderr, flush=True)
+        finally:
+            model._defer_wgrads = None
+            model._bwd_segment_hook = None
+            model._engines.clear()
+            model._engines.update(saved)        # the default (deferring) plan: the one the timed region ran and the profile leg reads
     loss_val = float(loss.item())
 
     roofline, kernels, cpu, peaks, adam_ms, extra = None, None, None, None, None, {}
@@ -442,7 +572,11 @@ def main() -> None:
                                                           "mfma_clock_mhz": round(peaks["mfma_clock_mhz"]),
                                                           "stream_copy_gbps": round(peaks["copy_gbps"], 1),
                                                           "spec": {"mfma_f32_tflops": PEAK_F32_MFMA_TFLOPS, "hbm_gbps": PEAK_HBM_GBS}},
-            "kernels": kernels, "loss": round(loss_val, 6), **extra,
+            "kernels": kernels, "loss": round(loss_val, 6),
+            # tiles/s of ONE GPU running the plan the data-parallel ranks run (tape-order weight gradients, segmented backward,
+            # no collective): the like-for-like N = 1 of a weak-scaling efficiency
+            "n1_same_plan_tiles_per_s": same_plan,
+            "allreduce": allreduce, **extra,
         }
         print(json.dumps(line))
     if dist is not None:

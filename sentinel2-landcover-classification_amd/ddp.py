@@ -49,6 +49,16 @@ class FlatGradReducer:
 
     def finish(self) -> None:
         """Make the reduced gradients visible to the compute stream (call before the optimiser)."""
+        mod = self.module
+        if getattr(mod, "_method_grads_unreduced", False):
+            # gradients from separately called methods (MaskedAutoencoderViT.forward_encoder / _decoder / _loss,
+            # EfficientNet.encode / forward): several autograd nodes added their local, already 1/world-scaled gradients to the
+            # flat buffer; nothing was final before the last of them, so the trainable range is reduced here in one collective
+            # (frozen / never-used ranges hold zeros and simply ride along)
+            grads = mod._grad_buffer()
+            self.on_segment(0, grads.numel(), grads)
+            mod._method_grads_unreduced = False
+        mod._bucket_reduced = False
         for w in self.pending:
             w.wait()
         self.pending.clear()

@@ -167,6 +167,7 @@ class _UnetFunction(torch.autograd.Function):
             else:
                 if accumulate:
                     raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+                _note_bucket_reduction(module)
                 for (a, b, lo, hi) in eng.bwd_marks:
                     _lib.run(eng.bwd, bases, st, a, b)
                     hook(lo, hi, grads)
@@ -175,7 +176,21 @@ class _UnetFunction(torch.autograd.Function):
             module._grad_buffer().add_(grads)
         if not live:
             module._publish_grads(module._no_grad_params)
+        if dx is not None and scale != 1.0:
+            # the 1/world of the data-parallel mean belongs to the PARAMETER gradients only: whatever sits in front of the
+            # module (an input adapter under its own DDP, a saliency map) must see d loss_rank / d x, as with torch DDP
+            dx.mul_(1.0 / scale)
         return dx, None, None, None, None
+
+
+def _note_bucket_reduction(module) -> None:
+    """Bookkeeping for ddp.FlatGradReducer: this backward hands its gradients to the bucket hook segment by segment.  The
+    separately callable methods (vit_engine._MethodFunction) instead ADD local gradients to the flat buffer and leave the
+    reduction to FlatGradReducer.finish(); both in one backward would reduce the bucketed part twice."""
+    if getattr(module, "_method_grads_unreduced", False):
+        raise RuntimeError("one backward mixes the fused forward with separately called methods under a data-parallel reducer: "
+                           "call ddp.finish() between them, or use one of the two paths per step")
+    module._bucket_reduced = True
 
 
 def run_unet(module, x: torch.Tensor) -> torch.Tensor:

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import Workspace, WorkspacePool
+from .engine import Workspace, WorkspacePool, _note_bucket_reduction
 
 _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
 
@@ -123,6 +123,7 @@ class _VitFunction(torch.autograd.Function):
             else:
                 if accumulate:
                     raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+                _note_bucket_reduction(module)
                 lo_min = eng.plan.trainable_lo
                 for (a, b, lo, hi) in eng.bwd_marks:
                     _lib.run(eng.bwd, bases, st, a, b)
@@ -132,6 +133,8 @@ class _VitFunction(torch.autograd.Function):
             module._grad_buffer().add_(grads)
         if not live:
             module._publish_grads(module._no_grad_params)
+        if dx is not None and scale != 1.0:
+            dx.mul_(1.0 / scale)       # the data-parallel 1/world applies to parameter gradients only (engine.py)
         return dx, None, None, None, None, None
 
 
@@ -253,6 +256,19 @@ class _MethodFunction(torch.autograd.Function):
         if lease.space is None:
             raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
         dev = module._flat_params.device
+        # Data-parallel reducer attached (ddp.FlatGradReducer): several method nodes (encoder, decoder, loss) run in one
+        # backward pass and each ADDS to the flat gradient buffer, so no bucket is final until the last of them has run.
+        # The 1/world of the mean is applied where a node's parameter gradients are added to the flat buffer (NOT to the
+        # upstream gradient: along a chain of nodes it would be applied once per node, and input gradients must stay
+        # d loss_rank / d input), the module is marked, and FlatGradReducer.finish() all-reduces the trainable range in one
+        # collective before the optimiser reads it.
+        reducing = getattr(module, "_bwd_segment_hook", None) is not None
+        scale = getattr(module, "_grad_scale", 1.0) if reducing else 1.0
+        if reducing:
+            if getattr(module, "_bucket_reduced", False):
+                raise RuntimeError("one backward mixes the fused forward with separately called methods under a data-parallel "
+                                   "reducer: call ddp.finish() between them, or use one of the two paths per step")
+            module._method_grads_unreduced = True
         dout = torch.zeros(plan.dout_bytes + 256, dtype=torch.uint8, device=dev)
         for name, g in zip(plan.outputs, gouts):
             if g is not None and name in plan.douts:
@@ -268,7 +284,7 @@ class _MethodFunction(torch.autograd.Function):
         scratch.zero_()
         _lib.run(eng.bwd, eng.bases(module, lease.space, ctx.xbuf, ctx.out, ctx.noise, dout=dout, grads=scratch, dx=dx), _stream(dev))
         lease.release()
-        main.add_(scratch)
+        main.add_(scratch, alpha=scale)
         if not live or getattr(eng, "publish_all", False):
             module._publish_grads(set() if getattr(eng, "publish_all", False) else module._no_grad_params)
         grads_in = tuple(_view(dx, plan.dins[n]).clone() if n in plan.dins else None for n in ctx.names)

@@ -57,6 +57,11 @@ def run_shard(model, case, x, y, noise, loss_fn, lo, hi, dev):
         model.train(case == "unet_train")
         model.drop_connect_noise = noise[:, lo:hi].contiguous() if case == "unet_train" else None
         loss = loss_fn(model(xs), y[lo:hi].to(dev))
+    elif case == "mae_methods":
+        # the reference's forward written out by a caller (prithvi.py:352-356): three autograd nodes in one backward
+        model.masking_noise = noise[lo:hi].contiguous()
+        latent, mask, ids = model.forward_encoder(xs, 0.75)
+        loss = model.forward_loss(xs, model.forward_decoder(latent, ids), mask)
     else:
         model.masking_noise = noise[lo:hi].contiguous()
         loss, _, _ = model(xs, mask_ratio=0.75)
@@ -66,16 +71,22 @@ def run_shard(model, case, x, y, noise, loss_fn, lo, hi, dev):
 
 def main():
     rank, world, port, outdir, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    if backend == "nccl":       # RCCL: one communicator per device, bound at init (what bench.py does for N > 1)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from s2lc_amd.ddp import FlatGradReducer
 
-        dev = torch.device("cuda:0")
         model, x, y, noise, loss_fn = build_case(case, seed=5 + rank)      # different weights per rank: the broadcast must fix that
         model.to(dev)
         red = FlatGradReducer(model, dist)
@@ -94,7 +105,7 @@ def main():
         loss = run_shard(model, case, x, y, noise, loss_fn, rank * per, (rank + 1) * per, dev)
         red.finish()
         torch.cuda.synchronize()
-        torch.save(dict(rank=rank, grads=model._grad_buffer().detach().cpu(), w0=w0, loss=float(loss), calls=calls,
+        torch.save(dict(rank=rank, backend=dist.get_backend(), grads=model._grad_buffer().detach().cpu(), w0=w0, loss=float(loss), calls=calls,
                         bufs=model._flat_bufs.detach().cpu()), os.path.join(outdir, f"{case}.r{rank}.pt"))
     finally:
         dist.destroy_process_group()

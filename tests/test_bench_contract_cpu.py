@@ -73,3 +73,23 @@ def test_cpu_description_and_stage_work():
     kind, fl, by = bench.stage_work(prog.pack()[0], D)
     assert kind == "WGRAD" and fl == 2.0 * 8 * 16 * 32 and by == 4.0 * (2 * 8 * 16 + 2 * 16 * 16 + 8 * 16)
     assert isinstance(np.asarray(prog.pack()), np.ndarray)
+
+
+def test_launcher_starts_one_process_per_rank_and_returns_the_worst_exit_code(tmp_path, capfd):
+    """`python bench.py --gpus N` (no rank environment) becomes a launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT, only rank 0 on stdout, worst exit code returned (stand-in rank script: no GPU here)."""
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+                      "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+                      "print('[Gloo] chatter from rank', r)\n"
+                      "print('{\"metric\": \"m\", \"rank\": %d}' % r)\n"
+                      "sys.exit(int(sys.argv[1]) if r == 2 else 0)\n")
+    assert bench.launch_ranks(3, ["0"], script=str(script)) == 0
+    cap = capfd.readouterr()
+    lines = [ln for ln in cap.out.splitlines() if ln.strip()]
+    assert lines == ['{"metric": "m", "rank": 0}']              # rank 0's result line only: ONE JSON line on stdout
+    assert "[Gloo] chatter from rank 0" in cap.err and "rank 1" not in cap.err
+    assert bench.launch_ranks(3, ["7"], script=str(script)) == 7

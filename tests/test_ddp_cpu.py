@@ -74,7 +74,16 @@ def _worker(rank, world, port, outdir):
         for hi, lo in zip(cuts, cuts[1:]):
             red.on_segment(lo, hi, grads)
         red.finish()
-        torch.save((rank, grads.clone(), local, w0), os.path.join(outdir, f"r{rank}.pt"))
+        # the separately callable methods (vit_engine._MethodFunction) add local, 1/world-scaled gradients to the flat buffer
+        # and only mark the module: finish() must then reduce the whole buffer itself, exactly once
+        local2 = torch.randn(grads.shape, generator=g)
+        grads2 = local2 * m._grad_scale
+        m._flat_grads = grads2
+        m._method_grads_unreduced = True
+        red.finish()
+        assert not m._method_grads_unreduced
+        red.finish()            # nothing pending, nothing marked: must not reduce again
+        torch.save((rank, grads.clone(), local, w0, grads2.clone(), local2), os.path.join(outdir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -92,6 +101,8 @@ def test_flat_grad_reducer_averages_like_ddp_gloo(tmp_path):
     out = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
     out.sort(key=lambda t: t[0])
     mean = (out[0][2] + out[1][2]) / 2
-    for rank, reduced, _, w0 in out:
+    mean2 = (out[0][5] + out[1][5]) / 2
+    for rank, reduced, _, w0, reduced2, _ in out:
         assert torch.allclose(reduced, mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(reduced2, mean2, rtol=1e-6, atol=1e-7)
     assert torch.equal(out[0][3], out[1][3])  # identical weights after the broadcast

@@ -181,6 +181,81 @@ def _rehearse(case, tmp_path, world=2):
     return sorted(res, key=lambda d: d["rank"])
 
 
+def test_method_path_under_the_reducer_is_averaged_once(tmp_path):
+    """MaskedAutoencoderViT.forward_encoder -> forward_decoder -> forward_loss under a FlatGradReducer (three autograd nodes
+    per backward): the 1/world factor is applied once per parameter gradient, FlatGradReducer.finish() reduces the
+    flat buffer, and the result equals the single-process gradients of the concatenated batch."""
+    world = 2
+    res = _rehearse("mae_methods", tmp_path, world)
+    model, x, y, noise, loss_fn = build_case("mae_methods", seed=5)
+    assert torch.equal(res[0]["grads"], res[1]["grads"])
+    assert res[0]["grads"].abs().max().item() > 0
+    model.to(DEV)
+    run_shard(model, "mae", x, y, noise, loss_fn, 0, x.shape[0], DEV)          # fused forward, whole batch, no reducer
+    rel = _close(res[0]["grads"].to(DEV), _flat_grads(model), 6e-5)
+    print(f"mae_methods: 2-rank averaged gradients vs single-process reference: max rel err {rel:.2e}")
+
+
+def test_input_gradient_is_not_scaled_by_the_data_parallel_mean():
+    """the 1/world factor folded into the upstream gradient belongs to the parameter gradients; dX handed upstream
+    must stay d loss_rank / d x."""
+    model, x, y, noise, loss_fn = build_case("unet_eval", seed=5)
+    model.to(DEV).eval()
+    outs = []
+    for scale in (1.0, 0.5):
+        model._grad_scale = scale
+        for p in model.parameters():
+            p.grad = None
+        xs = x[:2].to(DEV).requires_grad_(True)
+        loss_fn(model(xs), y[:2].to(DEV)).backward()
+        outs.append((xs.grad.clone(), _flat_grads(model)))
+    assert outs[0][0].abs().max().item() > 0
+    _close(outs[1][0], outs[0][0], 2e-6)
+    _close(outs[1][1], 0.5 * outs[0][1], 2e-6)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` as the driver calls it (no rank environment): the parent starts two fresh rank processes
+    before touching the GPU and relays rank 0's single JSON line (gloo here: both ranks share the one GPU of this box)."""
+    import json
+    import os
+
+    env = dict(os.environ, S2K_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-prithvi",
+                        "--no-cpu-baseline", "--version", "b0", "--bands", "4", "--size", "64", "--batch", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["config"]["parallelism"] == "dp2" and doc["config"]["global_batch"] == 4
+    assert doc["value"] > 0 and doc["scaling"] == "weak" and doc["steps"] == 2
+    ar = doc["allreduce"]
+    assert ar["buckets"] >= 1 and ar["bytes"] > 0 and ar["backend"] == "gloo" and "ms_exposed" in ar and ar["bus_gbps"] > 0
+    assert doc["n1_same_plan_tiles_per_s"] > 0
+
+
+def test_rccl_world_size_one_reducer(tmp_path):
+    """RCCL itself, once: a fresh child initialises the "nccl" backend (= RCCL on ROCm) with world size 1, runs the product
+    FlatGradReducer (async all-reduce of flat-buffer views issued from the side stream, finish()) around a U-Net backward
+    and must reproduce the gradients of the run without a reducer."""
+    import os
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "ddp_worker.py"), "0", "1", env["MASTER_PORT"], str(tmp_path), "unet_train", "nccl"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = torch.load(tmp_path / "unet_train.r0.pt")
+    assert res["backend"] == "nccl" and len(res["calls"]) >= 3
+    model, x, y, noise, loss_fn = build_case("unet_train", seed=5)
+    model.to(DEV)
+    model._defer_wgrads = False
+    run_shard(model, "unet_train", x, y, noise, loss_fn, 0, x.shape[0], DEV)
+    _close(res["grads"].to(DEV), _flat_grads(model), 2e-6)
+
+
 @pytest.mark.parametrize("case", ["unet_eval", "unet_train", "mae"])
 def test_two_rank_rehearsal_matches_ddp_semantics(case, tmp_path):
     world = 2

@@ -95,7 +95,8 @@ def test_seg_matches_reference_fixture(tag):
         assert np.array_equal(got_mask, ref_mask)
     else:   # identical except where the reference's own top-2 margin is inside fp32 noise
         assert (got_mask != ref_mask).mean() < 1e-4
-    ce = torch.nn.functional.cross_entropy(logits, y.to(DEV), ignore_index=0)
+    from s2lc_amd.losses import CrossEntropyLoss
+    ce = CrossEntropyLoss(ignore_index=0)(logits, y.to(DEV))        # the PRODUCT loss (what bench.py's seg legs run), not torch's
     assert abs(ce.item() - g["loss_ce"][0]) < 2e-4 * abs(g["loss_ce"][0])
     if not train:
         return

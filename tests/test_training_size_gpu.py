@@ -1,0 +1,332 @@
+"""GPU parity at the TRAINING sizes of BASELINE.json ("training-size parity"): the plans the benchmark runs —
+256-pixel thin weight-gradient stages, per-CU pixel splits, decoder weight gradients deferred onto the side stream, split-K on
+the 8x8 maps, hd-64 attention backward inside the 12-layer model — checked end to end against fixtures generated from the
+imported reference (tests/golden/make_golden_r3.py) and against the CPU oracle run here on the same inputs.
+
+  configs[1]  efficientnet-unet-b5 13x256x256, TRAIN mode, bs 8 (reference fixture + fp32 oracle, every logit), and bs 32
+              through a size-independent property (a batch of 4 copies of those 8 tiles has the same batch statistics, so
+              logits, loss and gradients must equal the bs-8 run's) + which kernels the bs-32 plan selects;
+  configs[3]  PrithviSegmentationNet on Prithvi-100M, bs 1, train mode, unfrozen, through the PRODUCT CrossEntropyLoss,
+              gradients against the reference's and a float64 oracle;
+  configs[4]  Prithvi-100M MAE, bs 2, mask 0.75, gradients against the reference's and a float64 oracle.
+(reference: /root/reference/src/train_segmentation.py:129-147, train_mae_prithvi.py:118-133)"""
+import numpy as np
+import pytest
+import torch
+
+import s2lc_amd  # noqa: F401
+from oracle import detgen, losses_ref
+from oracle import efficientnet_unet_ref as R
+from oracle import prithvi_ref as P
+from tests.helpers import PRITHVI_FULL, load, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+NCLS = 4
+
+
+def _mask_report(mask_gpu: np.ndarray, mask_ref: np.ndarray, logits_ref: torch.Tensor, record_property, tag: str) -> str:
+    """Exact equality of the class masks is RECORDED (junit property + returned text for assertion messages) — and where it
+    does not hold, every differing pixel must be one whose reference top-2 margin is inside fp32 noise."""
+    diff = mask_gpu != mask_ref
+    n = int(diff.sum())
+    msg = f"{tag}: class mask bit-exact vs the reference: {n == 0} ({n} of {mask_ref.size} pixels differ)"
+    record_property(f"mask_exact:{tag}", n == 0)
+    record_property(f"mask_diff_pixels:{tag}", n)
+    print(msg)
+    if n:
+        top2 = logits_ref.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1]).numpy()
+        assert diff.mean() < 1e-4 and margin[diff].max() < 1e-4 * max(1.0, float(logits_ref.abs().max())), \
+            msg + f"; largest reference margin at a differing pixel {margin[diff].max():.3e}"
+    return msg
+
+
+def _unet(seed):
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+    net = R.build("b5", 13, NCLS)
+    sd = detgen.fill_state(R.state_shapes(net), seed=seed)
+    model = EfficientnetUnet(EfficientNetConfig("b5", 13, NCLS, class_distribution=[1.0 / NCLS] * NCLS))
+    model.load_state_dict(sd)
+    return model, net, sd
+
+
+@pytest.fixture(scope="module")
+def unet_bs8():
+    """One bs-8 training step of configs[1]'s network on the GPU and on the fp32 CPU oracle (shared by the tests below)."""
+    from s2lc_amd.losses import CrossEntropyLoss, FocalLoss, class_mask
+    from tests.test_plan_cpu import oracle_grads
+
+    tag, B, H, seed = "b5_256x13_train_bs8", 8, 256, 9
+    model, net, sd = _unet(seed)
+    x = detgen.normal(f"{tag}.x", (B, 13, H, H), seed=seed)
+    y = detgen.labels(f"{tag}.y", (B, H, H), NCLS, seed=seed)
+    noise = detgen.uniform(f"{tag}.dc", (len(net.blocks), B), 0.0, 1.0, seed=seed)
+    model.to(DEV).train()
+    bufs0 = model._flat_bufs.clone()
+    model.drop_connect_noise = noise
+    logits = model(x.to(DEV))
+    fl = FocalLoss(torch.ones(NCLS), 2.0, 0.0, ignore_index=0)(logits, y.to(DEV))
+    ce = CrossEntropyLoss(ignore_index=0)(logits.detach(), y.to(DEV))
+    fl.backward()
+    torch.cuda.synchronize()
+    sd32, logits32, _, newbuf32 = oracle_grads(net, sd, x, y, noise, NCLS, torch.float32)     # the reference's arithmetic: fp32 CPU
+    return dict(tag=tag, model=model, net=net, sd=sd, x=x, y=y, noise=noise, logits=logits.detach().cpu(), focal=fl.item(), ce=ce.item(),
+                mask=class_mask(logits.detach()).cpu().to(torch.uint8).numpy(), grads=model._grad_buffer().detach().clone(),
+                bufs0=bufs0, bufs1=model._flat_bufs.detach().clone(), sd32=sd32, logits32=logits32, newbuf32=newbuf32)
+
+
+def test_unet_b5_256x13_train_bs8_matches_reference_and_oracle(unet_bs8, record_property):
+    c = unet_bs8
+    g = load(f"unet_{c['tag']}.npz")
+    lc = c["logits"]
+    # the reference itself (subsample + whole-tensor check values), then every logit against the fp32 CPU oracle
+    e_ref = rel_err(sub(lc, 4096), g["logits_sub"])
+    e_or = rel_err(lc.numpy(), c["logits32"].numpy())
+    print(f"{c['tag']}: logits rel err vs reference subsample {e_ref:.2e}, vs fp32 oracle (every element) {e_or:.2e}")
+    assert e_ref < 1e-3 and e_or < 1e-3
+    assert abs(float(lc.double().abs().sum()) - g["logits_ck"][1]) < 1e-4 * g["logits_ck"][1]
+    assert abs(c["focal"] - g["loss_focal"][0]) < 1e-4 * abs(g["loss_focal"][0])
+    assert abs(c["ce"] - g["loss_ce"][0]) < 1e-4 * abs(g["loss_ce"][0])
+    _mask_report(c["mask"], g["mask"], c["logits32"], record_property, c["tag"])
+    # BatchNorm running statistics: the reference's three probed layers, then EVERY buffer against the oracle
+    new_sd = c["model"].state_dict()
+    for key in g.files:
+        if key.startswith("rm:"):
+            assert rel_err(new_sd[key[3:] + ".running_mean"].cpu().numpy(), g[key]) < 1e-4, key
+        if key.startswith("rv:"):
+            assert rel_err(new_sd[key[3:] + ".running_var"].cpu().numpy(), g[key]) < 1e-4, key
+        if key.startswith("nbt:"):
+            assert int(new_sd[key[4:] + ".num_batches_tracked"]) == int(g[key][0]) == int(c["sd"][key[4:] + ".num_batches_tracked"]) + 1
+    for k, v in c["newbuf32"].items():
+        if k.endswith(("running_mean", "running_var")):
+            assert rel_err(new_sd[k].cpu().numpy(), v.numpy()) < 1e-4, k
+    # Gradients, train-mode BatchNorm: fp32 noise (ReLU / BN sign flips, tests/test_unet_gpu.py) is far smaller here than on the
+    # 64x64 bs-2 fixtures (the deepest maps hold 8 x 8 x 8 = 512 values per channel, not 8), so the bars are absolute:
+    # against the reference's subsamples and against the fp32 oracle, per tensor relative to the tensor's own largest gradient
+    named = dict(c["model"].named_parameters())
+    sd32 = c["sd32"]
+    scale = max(v.grad.abs().max().item() for v in sd32.values() if getattr(v, "grad", None) is not None)
+    errs = []
+    for name, p in named.items():
+        ref = sd32[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        if ref.abs().max().item() < 1e-9 * scale:       # conv bias in front of train-mode BN: analytically zero
+            assert p.grad.abs().max().item() <= 1e-6 * scale, name
+            continue
+        denom = max(ref.abs().max().item(), 1e-4 * scale)
+        errs.append(((p.grad.cpu() - ref).abs().max().item() / denom, name))
+    errs.sort(reverse=True)
+    e = np.array([x[0] for x in errs])
+    print(f"{c['tag']}: gradient error vs fp32 oracle: median {np.median(e):.2e}, p90 {np.percentile(e, 90):.2e}, worst {errs[0][0]:.2e} "
+          f"({errs[0][1]}); {len(errs)} tensors")
+    record_property("grad_err_median", float(np.median(e)))
+    record_property("grad_err_worst", float(errs[0][0]))
+    assert np.median(e) < 2e-3 and np.percentile(e, 90) < 1e-2 and errs[0][0] < 5e-2, errs[:5]
+    for key in g.files:
+        if key.startswith("grad:"):
+            name = key[5:]
+            denom = max(float(g["gradck:" + name][2]), 1e-4 * scale)
+            eg = float(np.abs(sub(named[name].grad, 512).astype(np.float64) - g[key]).max()) / denom
+            assert eg < 5e-2, (name, eg)
+    tot = sum(p.grad.double().pow(2).sum().item() for p in named.values() if p.grad is not None)
+    assert abs(tot - float(g["grad_total_sq"][0])) < 2e-3 * float(g["grad_total_sq"][0]), (tot, float(g["grad_total_sq"][0]))
+
+
+def test_unet_bs32_plan_uses_the_benchmark_kernels_and_equals_the_bs8_step(unet_bs8):
+    """BASELINE.json configs[1] at its full batch: (i) the bs-32 256x256 plan selects what the benchmark runs; (ii) one training
+    step on a batch of 4 copies of the bs-8 tiles.  Every BatchNorm sees the same batch mean / variance as at bs 8, so logits
+    repeat, the loss is the same and the gradients are the bs-8 gradients (sum of 4 equal contributions x 1/4) — a property of
+    the arithmetic that holds at any size, checked here against the bs-8 GPU run AND the fp32 CPU oracle."""
+    from s2lc_amd import _lib
+    from s2lc_amd.losses import FocalLoss
+    from s2lc_amd.plan import opdefs as D
+
+    c = unet_bs8
+    rep, B, H = 4, 32, 256
+    model, net, sd = _unet(9)
+    model.to(DEV).train()
+    x = c["x"].repeat(rep, 1, 1, 1).to(DEV)
+    y = c["y"].repeat(rep, 1, 1).to(DEV)
+    model.drop_connect_noise = c["noise"].repeat(1, rep)
+    logits = model(x)
+    loss = FocalLoss(torch.ones(NCLS), 2.0, 0.0, ignore_index=0)(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    bufs32 = model._flat_bufs.detach().clone()      # (the profiling pass below runs the forward program again)
+    # ---- (i) plan choices -------------------------------------------------------------------------------------------
+    eng = next(e for e in model._engines.values() if e.bwd is not None)
+    plan = eng.plan
+    kinds = [k for k, _ in plan.bwd.ops]
+    first_enc = next(i for i, k in enumerate(kinds) if k in ("DWCONV_DGRAD", "SE_BN_SUMS", "SE_FC_BWD"))
+    model._defer_wgrads = False                                     # the tape-order plan, for comparison (no engine built)
+    tape = model._make_plan(B, H, H, True)
+    model._defer_wgrads = None
+    tkinds = [k for k, _ in tape.bwd.ops]
+    t_first = next(i for i, k in enumerate(tkinds) if k in ("DWCONV_DGRAD", "SE_BN_SUMS", "SE_FC_BWD"))
+    n_dec, n_dec_tape = kinds[:first_enc].count("WGRAD"), tkinds[:t_first].count("WGRAD")
+    assert n_dec_tape >= 12 and n_dec <= n_dec_tape - 6, (n_dec, n_dec_tape)      # the large decoder weight gradients are deferred
+    side = sum(1 for _, f in plan.bwd.ops if f.get("_flags", 0) & D.FLAG_SIDE)
+    assert side >= 100, side                                                        # weight-gradient family on the side stream
+    splitk = sum(1 for prog in (plan.fwd, plan.bwd) for k, f in prog.ops if k == "CONV" and f.get("SCRATCH") is not None)
+    assert splitk >= 10, splitk                                                     # split-K 1x1 convs on the 8x8 / 16x16 maps
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(plan.logits_shape, device=DEV)
+    nz = c["noise"].repeat(1, rep).to(DEV)
+    dout = torch.zeros(plan.logits_shape, device=DEV)
+    scratch = torch.zeros_like(model._flat_params)
+    variants = {}
+    for prog, bases in ((eng.fwd, eng.bases(model, x, out, noise=nz)), (eng.bwd, eng.bases(model, x, None, dout=dout, noise=nz, grads=scratch))):
+        ms, var = _lib.profile_variants(prog, bases, st)
+        for rec, v in zip(prog, var):
+            k = D.NAME_OF[int(rec["kind"])]
+            if k in ("CONV", "WGRAD"):
+                variants[(k, int(v))] = variants.get((k, int(v)), 0) + 1
+    print("bs-32 plan kernel selection (stage kind, producer/consumer variant) -> launches:", variants)
+    assert variants.get(("CONV", 1), 0) >= 50 and variants.get(("WGRAD", 1), 0) >= 45, variants
+    # ---- (ii) the replicated-batch property ---------------------------------------------------------------------------
+    lg = logits.detach().cpu()
+    for r in range(rep):
+        assert rel_err(lg[8 * r:8 * r + 8].numpy(), c["logits"].numpy()) < 2e-4, r
+    assert rel_err(lg[:8].numpy(), c["logits32"].numpy()) < 1e-3
+    assert abs(loss.item() - c["focal"]) < 2e-5 * abs(c["focal"])
+    # (model.backward above ran before profile_variants wrote into `scratch`: the module's gradient buffer is untouched)
+    g32, g8 = model._grad_buffer().detach(), c["grads"]
+    n2 = (g32.double() - g8.double()).pow(2).sum().sqrt().item() / g8.double().pow(2).sum().sqrt().item()
+    r2 = g32.double().pow(2).sum().item() / g8.double().pow(2).sum().item()
+    print(f"bs 32 (4 x the bs-8 batch) vs bs 8: |g32 - g8| / |g8| = {n2:.2e}, |g32|^2 / |g8|^2 = {r2:.6f}, loss {loss.item():.6f} vs {c['focal']:.6f}")
+    assert n2 < 2e-2 and abs(r2 - 1.0) < 2e-3
+    # running mean: identical update; running variance: the unbiased n / (n - 1) factor differs (n = B x H x W per layer), at most
+    # 512/511 vs 2048/2047 on the 8x8 maps
+    L = model._layout
+    for name, (off, shape) in L.bufs.items():
+        n = int(np.prod(shape))
+        a, b = bufs32[off:off + n].cpu(), c["bufs1"][off:off + n].cpu()
+        tol = 1e-4 if name.endswith("running_mean") else 2e-3
+        assert rel_err(a.numpy(), b.numpy()) < tol, name
+
+
+def test_unet_b5_256x13_evalgrad_bs4_matches_reference():
+    """The well-conditioned gradient fixture (eval-mode BatchNorm, tests/test_parity_r2_gpu.py) at the benchmark's tile shape:
+    every weight tensor within 1e-3 of the reference's own gradients."""
+    from tests.test_parity_r2_gpu import test_eval_mode_gradients_match_reference as check
+
+    check("b5_256x13_evalgrad_bs4", "b5", 13, 256, 4, 33)
+
+
+def _grad_table(model, sd64, floor_rel=1e-3):
+    scale = max(v.grad.abs().max().item() for v in sd64.values() if getattr(v, "grad", None) is not None)
+    errs = []
+    for name, p in model.named_parameters():
+        ref = sd64[name].grad
+        if ref is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, name
+            continue
+        assert p.grad is not None, name
+        g = p.grad.detach().cpu().double()
+        errs.append(((g - ref).abs().max().item() / max(ref.abs().max().item(), floor_rel * scale), name))
+    errs.sort(reverse=True)
+    return errs, scale
+
+
+def test_prithvi_100m_mae_bs2_gradients_match_reference(record_property):
+    """configs[4]'s model at full size with gradients: Prithvi-100M MAE, bs 2, mask 0.75 — the hd-64 attention backward inside
+    12 encoder + 8 decoder layers, against the imported reference's gradients and a float64 oracle (2e-3)."""
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+
+    tag, B, ratio, seed = "full_bs2_grads", 2, 0.75, 15
+    g = load(f"prithvi_mae_{tag}.npz")
+    cfg = P.MaeCfg(**PRITHVI_FULL)
+    sd = detgen.fill_state(P.mae_state_shapes(cfg), seed=seed)
+    sd["pos_embed"] = P.sincos_pos_embed(cfg.embed_dim, cfg.grid)
+    sd["decoder_pos_embed"] = P.sincos_pos_embed(cfg.decoder_embed_dim, cfg.grid)
+    x = detgen.normal(f"{tag}.x", (B, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), seed=seed)
+    noise = detgen.uniform(f"{tag}.noise", (B, cfg.num_patches), 0.0, 1.0, seed=seed)
+    model = MaskedAutoencoderViT(**PRITHVI_FULL)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    model.masking_noise = noise
+    loss, pred, mask = model(x.to(DEV), mask_ratio=ratio)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(mask.cpu().to(torch.uint8).numpy(), g["mask"])
+    assert rel_err(sub(pred.detach().cpu(), 4096), g["pred_sub"]) < 1e-3
+    assert abs(loss.item() - g["loss"][0]) < 1e-4 * abs(g["loss"][0])
+    named = dict(model.named_parameters())
+    for key in g.files:          # the reference's own gradients
+        if key.startswith("grad:"):
+            e = rel_err(sub(named[key[5:]].grad.cpu(), 512), g[key])
+            assert e < 2e-3, (key, e)
+    tot = sum(p.grad.double().pow(2).sum().item() for p in named.values() if p.grad is not None)
+    assert abs(tot - float(g["grad_total_sq"][0])) < 2e-3 * float(g["grad_total_sq"][0])
+    sd64 = {k: v.detach().double().requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+    l64, _, _ = P.mae_forward(sd64, cfg, x.double(), ratio, noise.double())
+    l64.backward()
+    errs, _ = _grad_table(model, sd64)
+    print(f"prithvi-100M MAE bs 2: gradient error vs float64 oracle: worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    record_property("grad_err_worst", float(errs[0][0]))
+    assert errs[0][0] < 2e-3, errs[:5]
+
+
+def test_prithvi_100m_seg_bs1_train_unfrozen_through_product_loss(record_property):
+    """configs[3]'s model, the step as benchmarked: PrithviSegmentationNet (Prithvi-100M, unfrozen) in train mode -> PRODUCT
+    CrossEntropyLoss(ignore_index=0) -> product backward; logits / loss / class mask / BatchNorm buffers against the imported
+    reference, gradients against the reference's subsamples and a float64 oracle."""
+    from s2lc_amd.losses import CrossEntropyLoss, class_mask
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+
+    tag, B, fcn_out, seed = "full_train_unfrozen_bs1", 1, 256, 25
+    g = load(f"prithvi_seg_{tag}.npz")
+    m = P.MaeCfg(**PRITHVI_FULL)
+    cfg = P.SegCfg(mae=m, num_classes=NCLS, fcn_out_channels=fcn_out, fcn_num_convs=1, fcn_dropout=0.1, frozen_backbone=False)
+    sd = detgen.fill_state(P.seg_state_shapes(cfg), seed=seed)
+    sd["backbone.pos_embed"] = P.sincos_pos_embed(m.embed_dim, m.grid)
+    sd["backbone.decoder_pos_embed"] = P.sincos_pos_embed(m.decoder_embed_dim, m.grid)
+    x = detgen.normal(f"{tag}.x", (B, m.in_chans, m.num_frames, m.img_size, m.img_size), seed=seed)
+    y = detgen.labels(f"{tag}.y", (B, m.img_size, m.img_size), NCLS, seed=seed)
+    noise = detgen.uniform(f"{tag}.noise", (B, m.num_patches), 0.0, 1.0, seed=seed)
+    drop_u = detgen.uniform(f"{tag}.drop", (B, fcn_out), 0.0, 1.0, seed=seed)
+    bb = MaskedAutoencoderViT(**PRITHVI_FULL, _decoder=False, _flat=False)
+    net = PrithviSegmentationNet(PrithviSegmentationNetConfig(1, NCLS, fcn_out, 1, 0.1, False), backbone=bb)
+    net.load_state_dict(sd)
+    net.to(DEV).train()
+    net.masking_noise, net.dropout_noise = noise, drop_u
+    logits = net(x.to(DEV))
+    ce = CrossEntropyLoss(ignore_index=0)(logits, y.to(DEV))          # the product loss, as bench.py's prithvi_seg_* legs
+    ce.backward()
+    torch.cuda.synchronize()
+    assert rel_err(sub(logits.detach().cpu(), 4096), g["logits_sub"]) < 1e-3
+    assert abs(ce.item() - g["loss_ce"][0]) < 1e-4 * abs(g["loss_ce"][0]), (ce.item(), g["loss_ce"][0])
+    sd64 = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            v = v.detach().double()
+            if not k.endswith(("pos_embed", "running_mean", "running_var")):
+                v.requires_grad_(True)
+        sd64[k] = v
+    lg64 = P.seg_forward(sd64, cfg, x.double(), noise.double(), training=True, drop_u=drop_u.double(), new_buffers={})
+    losses_ref.cross_entropy(lg64, y, ignore_index=0).backward()
+    _mask_report(class_mask(logits.detach()).cpu().to(torch.uint8).numpy(), g["mask"], lg64.detach().float(), record_property, tag)
+    named = dict(net.named_parameters())
+    scale = max(float(g[k][2]) for k in g.files if k.startswith("gradck:"))
+    for key in g.files:
+        if key.startswith("grad:") and key != "grad:head.net.0.bias":       # (bias in front of train-mode BN: exact zero here)
+            name = key[5:]
+            denom = max(float(g["gradck:" + name][2]), 1e-3 * scale)
+            e = float(np.abs(sub(named[name].grad.cpu(), 512).astype(np.float64) - g[key]).max()) / denom
+            assert e < 2e-2, (name, e)
+    errs, s64 = _grad_table(net, sd64)
+    errs = [x for x in errs if x[1] != "head.net.0.bias"]
+    assert named["head.net.0.bias"].grad.abs().max().item() < 1e-5 * s64
+    print(f"prithvi-100M seg bs 1 unfrozen: gradient error vs float64 oracle: worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    record_property("grad_err_worst", float(errs[0][0]))
+    assert errs[0][0] < 2e-2 and errs[len(errs) // 2][0] < 2e-3, errs[:5]
+    st = net.state_dict()
+    assert rel_err(st["head.net.1.running_mean"].cpu().numpy(), g["rm:head.net.1"]) < 1e-4
+    assert rel_err(st["head.net.1.running_var"].cpu().numpy(), g["rv:head.net.1"]) < 1e-4
+    assert int(st["head.net.1.num_batches_tracked"]) == int(g["nbt:head.net.1"][0])
