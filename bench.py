@@ -43,7 +43,8 @@ UNET_B5_LAYERWISE_TILES_PER_S = 2154.0
 PRITHVI_GFLOP_PER_SAMPLE = {"mae": 59.8, "seg_frozen": 804.0, "seg_unfrozen": 875.0}
 
 
-KERNEL_OF = {("CONV", 0): "conv_igemm_kernel", ("CONV", 1): "conv_pc_kernel", ("WGRAD", 0): "wgrad_kernel", ("WGRAD", 1): "wgrad_pc_kernel"}
+KERNEL_OF = {("CONV", 0): "conv_igemm_kernel", ("CONV", 1): "conv_pc_kernel", ("WGRAD", 0): "wgrad_kernel", ("WGRAD", 1): "wgrad_pc_kernel",
+             ("CONV", 2): "conv_bf16_kernel", ("WGRAD", 2): "wgrad_bf16_kernel"}      # variant 2: bf16 MFMA operands (bf16-mixed plans only)
 
 
 def stage_work(rec, D):
@@ -403,6 +404,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1 only; the headline is unaffected)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"],
+                    help="arithmetic of the HEADLINE run (default f32, the parity path; bf16-mixed is otherwise reported as the extra key `bf16_mixed`)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -439,6 +442,7 @@ def main() -> None:
     torch.manual_seed(42)  # identical initial weights on every rank (configs/segmentation.py:103 seed)
     model = EfficientnetUnet(EfficientNetConfig(args.version, args.bands, ncls, class_distribution=[0.25] * ncls))
     model.to(dev).train()
+    model.precision = args.precision
     opt = FlatAdam(model, lr=1.5e-6, weight_decay=0.05)  # BASE_CONFIG lr / weight_decay
     loss_fn = FocalLoss(torch.ones(ncls), 2.0, 0.0, ignore_index=0)
     ddp = None
@@ -559,7 +563,7 @@ def main() -> None:
         line = {
             "metric": "Sentinel-2 256x256x13 tiles/sec fwd+bwd", "value": round(tiles / dt, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16-mixed", "data": "synthetic",
             "config": {"workload": f"efficientnet-unet-{args.version} {C}x{H}x{H} bs{B}/GPU focal(g=2) train step "
                                    f"(fwd+loss+bwd{'+allreduce' if world > 1 else ''}+adam)",
                        "global_batch": world * B, "parallelism": f"dp{world}"},

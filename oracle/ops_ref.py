@@ -119,6 +119,17 @@ def op_weight_pack(m: Mem, o):
         dst[:K, :, :M] = src.permute(1, 2, 0)
 
 
+def _bf16_operands(m: Mem, o) -> bool:
+    """bf16-MIXED stage (S2kOp.flags & FLAG_BF16): the two MFMA operands - the activated inputs and the weights - are rounded to
+    bf16 (round-to-nearest-even), products and sums stay f32.  Not applied in `wide` (float64) emulation: that mode checks the
+    planner's algebra, not the arithmetic."""
+    return bool(o.get("_flags", 0) & 4) and not m.wide
+
+
+def _r16(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
 def op_conv(m: Mem, o):
     B, C1, C2, H, W, M = o["B"], o["C1"], o["C2"], o["H"], o["W"], o["M"]
     KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
@@ -137,6 +148,8 @@ def op_conv(m: Mem, o):
     if o["FLIP"]:
         wv = wv.flip(2)
     wv = wv.reshape(M, Ct, KH, KW)
+    if _bf16_operands(m, o):
+        x, wv = _r16(x), _r16(wv)
     y = F.conv2d(_pad_to(x, o["PAD_T"], o["PAD_L"], KH, KW, S, Ho, Wo), wv, None, S)
     bias = m.view(o["BIAS"], (M // 4 if mode == 1 else M,))
     YC = o["YC"]
@@ -167,6 +180,8 @@ def op_wgrad(m: Mem, o):
     T = KH * KW
     P = _pro(m.view(o["P"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
     Q = _pro(m.view(o["Q"], (B, C, H, W)), m.view(o["BNVQ"], (4, C)), m.view(o["GATEQ"], (B, C)), o["PROQ"], C)
+    if _bf16_operands(m, o):
+        P, Q = _r16(P), _r16(Q)
     if mode == 2:
         Qg = _unshuffle2(Q).view(B, C, 4, Ho * Wo)
         dW = torch.einsum("bmp,bctp->tmc", P.reshape(B, M, Ho * Wo).double(), Qg.double())
@@ -785,6 +800,7 @@ def unpack(packed: np.ndarray, opdefs) -> list[tuple[str, dict]]:
             o[k] = int(rec["d"][j])
         for j, k in enumerate(f):
             o[k] = float(rec["f"][j])
+        o["_flags"] = int(rec["flags"])
         out.append((kind, o))
     return out
 

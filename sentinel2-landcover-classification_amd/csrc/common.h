@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/s2k.h"
@@ -246,15 +247,16 @@ inline int tune_int(const char* name, int dflt) {
 // 1 = the producer/consumer kernel (conv_pc_kernel / wgrad_pc_kernel).
 extern thread_local int g_s2k_variant;
 
-// hipFuncSetAttribute acts on the current device: remember per device whether a kernel's attribute has been set.
+// hipFuncSetAttribute acts on the current device: run a kernel's attribute call once per device.  std::call_once makes every
+// other host thread WAIT until the first caller's attribute call has returned (include/s2k.h allows concurrent calls: a second
+// thread must not launch a > 64 KB dynamic-LDS kernel before the attribute has landed).
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool first() {
+    std::once_flag flags[64];
+    template <typename F>
+    void run(F&& f) {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) { f(); return; }
+        std::call_once(flags[d], f);
     }
 };
 

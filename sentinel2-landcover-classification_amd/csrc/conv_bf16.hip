@@ -1,0 +1,427 @@
+// Implicit-GEMM convolution on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16), f32 accumulate: the bf16-MIXED mode
+// (reported separately from the f32 parity path; the reference itself trains with precision="bf16",
+// /root/reference/src/configs/segmentation.py:146,153).  Same stage record, same operand tensors (raw f32 NCHW activations with
+// the BatchNorm + activation (+ SE gate) prologue applied on load, channel concat as two source pointers), same f32 epilogue
+// (bias, residual, accumulate, BatchNorm batch statistics in f64) as igemm.hip / igemm_pc.hip; only the two MFMA operands are
+// rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32): weights once per step by WEIGHT_PACK, activations when a tile is
+// written to LDS.  Replaces the same reference code (efficientnet_unet.py:168-176,288-297,319-372 under autocast).
+//
+// Why the structure differs from the f32 kernels: a f32 MFMA occupies its SIMD's issue port for its whole 64 cycles, so the
+// f32 kernels split waves into MFMA-only consumers and loaders.  The bf16 MFMA does 8x the work per instruction and blocks
+// vector issue for 8 of its 32 cycles: every wave can load, convert and multiply.  What bounds these kernels is HBM / L2
+// bandwidth (the activations are still f32 in memory), so:
+//   * 4 waves per workgroup (2 x 2 or 1 x 4 over the output tile), 2-3 workgroups per CU hide each other's barriers;
+//   * ONE LDS image, register-staged prefetch: the next K chunk's global loads are issued before the MFMAs of the current
+//     chunk and written (prologue, bf16 rounding, transposition) after them;
+//   * LDS images are fragment-shaped: A = weights [octet][tap][m][8 channels], B = activations [octet][pixel slot][8 channels],
+//     so a lane's MFMA operand (8 consecutive k of its row / column) is ONE ds_read_b128 and consecutive lanes read consecutive
+//     16-byte slots (conflict-free);
+//   * the f32 NCHW -> [pixel][8 channels] transposition happens in registers: a staging thread owns one channel OCTET of one
+//     pixel quad (1x1: eight 16-byte loads) or of one halo element (3x3: eight dword loads) and writes 16-byte slots; the slots
+//     of a 1x1 tile are XOR-swizzled so that the four slots a thread writes do not collide with its neighbours' banks.
+#include <algorithm>
+
+#include "common.h"
+#include "igemm.h"
+
+namespace s2k {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// 1x1 tiles: physical 16-byte slot of logical pixel slot s (a staging thread writes slots 4j .. 4j+3: without the swizzle the
+// eight lanes of a ds_write_b128 group hit two 16-byte columns of the 128-byte bank window, 4-way)
+__device__ __forceinline__ int swz(int s) { return s ^ ((s >> 3) & 3); }
+
+// PRO: S2K_PRO_NONE / RELU / SILU / AFFINE (1x1), NONE / RELU (3x3).  GATE: SE gate [B][C1] multiplies the activated value (1x1).
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE>
+__global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
+    constexpr bool PIX = BMODE == BM_PIX;
+    constexpr int NT = 256;
+    constexpr int WVN = 4 / WVM;
+    constexpr int BM = WVM * WM * 32, BN = WVN * WN * 32;
+    constexpr int TT = PIX ? 1 : 9;
+    constexpr int NO = KCH / 8;                              // channel octets per chunk
+    constexpr int WS = XW + 2, IR = R + 2;                   // 3x3 stride-1 halo tile
+    constexpr int USED = PIX ? BN : IR * WS;                 // B slots per octet
+    constexpr int A_UNITS = NO * TT * BM;                    // 16-byte units
+    constexpr int B_UNITS = NO * USED;
+    constexpr int NA = (A_UNITS + NT - 1) / NT;
+    constexpr int B_ITEMS = PIX ? (BN / 4) * NO : B_UNITS;   // staging items: (pixel quad | halo element) x octet
+    constexpr int NBI = (B_ITEMS + NT - 1) / NT;
+    static_assert(KCH % 16 == 0, "a k-step is 16 channels");
+    static_assert(PIX || R * XW <= BN, "3x3 tile");
+    static_assert(PIX || (!GATE && (PRO == S2K_PRO_NONE || PRO == S2K_PRO_RELU)), "3x3: BatchNorm + ReLU prologue at most");
+    extern __shared__ __attribute__((aligned(16))) u32x4 smem_b[];
+    u32x4* As = smem_b;
+    u32x4* Bs = smem_b + A_UNITS;
+    float* tab = reinterpret_cast<float*>(Bs + B_UNITS);     // [2][Ctp] scale / shift of every (concat) channel, zero beyond Ctot
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, p.n_tiles);
+    const int mt = tile % p.n_mtiles, nt = tile / p.n_mtiles;
+    const int m0 = mt * BM;
+    const int HWo = p.HO * p.WO;
+    const int nchunks = (p.Ctot + KCH - 1) / KCH;
+    const int Ctp = nchunks * KCH;
+    const int tx = PIX ? 0 : nt % p.tiles_x;
+    const int ty = PIX ? 0 : (nt / p.tiles_x) % p.tiles_y;
+    const int sb = PIX ? 0 : nt / (p.tiles_x * p.tiles_y);
+    const int y0 = ty * R, x0 = tx * XW;
+    const int MP = p.w_st;                                   // packed row count (M rounded up to 128)
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wtb);
+
+    // ---- staging geometry: fixed for the whole K loop ---------------------------------------------------------------------
+    uint32_t bvoff[NBI];        // byte offset of the item's pixel quad / halo element in a channel plane (image-relative), or OOB
+    float bound[PIX ? 1 : NBI]; // 3x3: +inf inside the image, 0 in the zero padding
+    int b_dst[NBI];             // LDS unit of the item (pixel quad: first of its 4 slots, unswizzled)
+    int b_co[NBI];              // octet of the item
+    int gate_b[PIX ? NBI : 1];  // 1x1: image of the pixel quad (SE gate row)
+    int img_b = 0;
+    if (PIX) {
+        const bool img_local = (p.HW % BN) == 0;
+        if (img_local) img_b = (nt * BN) / p.HW;
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it = tid + NT * i;
+            const int j4 = it % (BN / 4), co = it / (BN / 4);
+            const int n = nt * BN + 4 * j4;
+            const bool ok = it < B_ITEMS && n < p.Ntot;
+            const int nn = ok ? n : 0;
+            const int b = nn / p.HW, pp = nn - b * p.HW;
+            bvoff[i] = ok ? (uint32_t)((int64_t)(b - img_b) * p.C1 * p.HW + pp) * 4u : BUF_OOB;
+            b_dst[i] = co * BN + 4 * j4;
+            b_co[i] = co;
+            gate_b[PIX ? i : 0] = b;
+        }
+    } else {
+        img_b = sb;
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            const int it = tid + NT * i;
+            const int e = it % USED, co = it / USED;
+            const int iy = y0 - p.PT + e / WS, ix = x0 - p.PL + e % WS;
+            const bool ok = it < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            bvoff[i] = ok ? (uint32_t)(iy * p.W + ix) * 4u : BUF_OOB;
+            bound[PIX ? 0 : i] = ok ? __builtin_inff() : 0.0f;
+            b_dst[i] = co * USED + e;
+            b_co[i] = co;
+        }
+    }
+    const int64_t x1_img = (int64_t)p.C1 * p.HW, x2_img = (int64_t)p.C2 * p.HW;
+    const rsrc_t rx1 = make_rsrc(p.x1 + img_b * x1_img, (p.B - img_b) * x1_img * 4);
+    const rsrc_t rx2 = make_rsrc(p.x2 ? p.x2 + img_b * x2_img : p.x1, p.x2 ? (p.B - img_b) * x2_img * 4 : 0);
+    const uint32_t cs4 = (uint32_t)p.HW * 4u;
+
+    // ---- prologue table -----------------------------------------------------------------------------------------------------
+    if (PRO != S2K_PRO_NONE) {
+        for (int c = tid; c < Ctp; c += NT) {
+            float sc = 0.0f, sh = 0.0f;
+            if (c < p.C1) { sc = p.bnv1[c]; sh = p.bnv1[p.C1 + c]; }
+            else if (c < p.Ctot) { sc = p.bnv2[c - p.C1]; sh = p.bnv2[p.C2 + c - p.C1]; }
+            tab[c] = sc;
+            tab[Ctp + c] = sh;
+        }
+    }
+
+    u32x4 areg[NA];
+    f32x4 bq[PIX ? NBI : 1][8];          // 1x1: eight channels x four pixels per item
+    float bs[PIX ? 1 : NBI][8];          // 3x3: eight channels of one halo element per item
+    float greg[(PIX && GATE) ? NBI : 1][8];
+
+    auto fetch = [&](int c0) {
+        // A: units u = (o * TT + tap) * BM + row, contiguous rows of the packed bf16 weights [octet][tap][MP][8]
+        const int ob0 = c0 >> 3;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int u = tid + NT * i;
+            const int row = u % BM, ot = u / BM;             // ot = o * TT + tap
+            if (A_UNITS % NT == 0 || u < A_UNITS) areg[i] = wsrc[((int64_t)ob0 * TT + ot) * MP + m0 + row];
+        }
+        if (PIX) {
+#pragma unroll
+            for (int i = 0; i < NBI; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = min(c0 + 8 * b_co[i] + q, p.Ctot - 1);   // channels past Ctot meet zero rows of the packed weights
+                    bq[PIX ? i : 0][q] = bload4(rx1, bvoff[i] + (uint32_t)c * cs4);
+                    if (GATE) greg[(PIX && GATE) ? i : 0][q] = p.gate1[gate_b[PIX ? i : 0] * p.C1 + c];
+                }
+        } else {
+            const bool first = c0 < p.C1;                    // a chunk never straddles the two sources (host: C1 % KCH == 0)
+            const int cb = first ? c0 : c0 - p.C1, cn = first ? p.C1 : p.C2;
+#pragma unroll
+            for (int i = 0; i < NBI; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = min(cb + 8 * b_co[i] + q, cn - 1);
+                    bs[PIX ? 0 : i][q] = first ? bload(rx1, bvoff[i] + (uint32_t)c * cs4) : bload(rx2, bvoff[i] + (uint32_t)c * cs4);
+                }
+        }
+    };
+    auto commit = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int u = tid + NT * i;
+            if (A_UNITS % NT == 0 || u < A_UNITS) As[u] = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            if (B_ITEMS % NT != 0 && tid + NT * i >= B_ITEMS) continue;
+            float sc[8], sh[8];
+            if (PRO != S2K_PRO_NONE) {
+                const f32x4* ts = reinterpret_cast<const f32x4*>(tab + c0 + 8 * b_co[i]);
+                const f32x4* th = reinterpret_cast<const f32x4*>(tab + Ctp + c0 + 8 * b_co[i]);
+                const f32x4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sc[q] = s0[q]; sc[4 + q] = s1[q]; sh[q] = h0[q]; sh[4 + q] = h1[q]; }
+            }
+            if (PIX) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float x = bq[PIX ? i : 0][q][e];
+                        if (PRO != S2K_PRO_NONE) x = apply_pro_c<PRO>(x, sc[q], sh[q]);
+                        if (GATE) x *= greg[(PIX && GATE) ? i : 0][q];
+                        v[q] = x;
+                    }
+                    u32x4 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                    const int s = (b_dst[i] % BN) + e;
+                    Bs[(b_dst[i] - (b_dst[i] % BN)) + swz(s)] = w;
+                }
+            } else {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float x = bs[PIX ? 0 : i][q];            // padding slots were loaded as 0
+                    if (PRO == S2K_PRO_RELU) x = __builtin_amdgcn_fmed3f(fmaf(x, sc[q], sh[q]), 0.0f, bound[PIX ? 0 : i]);   // the reference pads ACTIVATED maps
+                    v[q] = x;
+                }
+                u32x4 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                Bs[b_dst[i]] = w;
+            }
+        }
+    };
+
+    // ---- consumer geometry ------------------------------------------------------------------------------------------------------
+    const int wm0 = (wave / WVN) * (WM * 32), wn0 = (wave % WVN) * (WN * 32);
+    int bslot[WN];
+#pragma unroll
+    for (int rn = 0; rn < WN; ++rn) {
+        const int j = wn0 + rn * 32 + l31;
+        if (PIX) bslot[rn] = swz(j);
+        else bslot[rn] = (j < R * XW) ? (j / XW) * WS + (j % XW) : 0;
+    }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    fetch(0);
+    __syncthreads();                                             // prologue table complete
+    commit(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) fetch((ch + 1) * KCH);             // in flight during the MFMAs below
+        // k-step (tap, s): 16 channels = octets 2 s and 2 s + 1; lane half lh takes octet 2 s + lh
+#pragma unroll
+        for (int tap = 0; tap < TT; ++tap) {
+            const int toff = PIX ? 0 : (tap / 3) * WS + (tap % 3);
+#pragma unroll
+            for (int s = 0; s < NO / 2; ++s) {
+                bf16x8 a[WM], b[WN];
+#pragma unroll
+                for (int rm = 0; rm < WM; ++rm)
+                    a[rm] = __builtin_bit_cast(bf16x8, As[((2 * s) * TT + tap) * BM + lh * (TT * BM) + wm0 + rm * 32 + l31]);
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn)
+                    b[rn] = __builtin_bit_cast(bf16x8, Bs[(2 * s) * USED + lh * USED + bslot[rn] + toff]);
+#pragma unroll
+                for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+                    for (int rn = 0; rn < WN; ++rn)
+                        acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm], b[rn], acc[rm][rn], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                         // every wave is done reading the image
+        if (ch + 1 < nchunks) {
+            commit((ch + 1) * KCH);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: f32, as igemm_pc.hip ----------------------------------------------------------------------------------------
+    bool cval[WN];
+    int64_t ycol[WN];
+#pragma unroll
+    for (int rn = 0; rn < WN; ++rn) {
+        const int j = wn0 + rn * 32 + l31;
+        if (PIX) {
+            const int n = nt * BN + j;
+            cval[rn] = n < p.Ntot;
+            const int nn = cval[rn] ? n : 0;
+            const int b = nn / p.HW, pp = nn - b * p.HW;
+            ycol[rn] = (int64_t)b * p.YC * HWo + pp;
+        } else {
+            const int r = j / XW, xx = j % XW;
+            cval[rn] = (j < R * XW) && (y0 + r < p.HO) && (x0 + xx < p.WO);
+            ycol[rn] = (int64_t)sb * p.YC * HWo + (int64_t)(y0 + r) * p.WO + (x0 + xx);
+        }
+    }
+    float* srow = reinterpret_cast<float*>(smem_b);              // [WVN wave columns][2][BM]  (the image is dead: barrier above)
+    const int wn_idx = wave % WVN;
+#pragma unroll
+    for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const int gm = m0 + row;
+            const bool rok = gm < p.M;
+            const float bsv = (p.bias && rok) ? p.bias[gm] : 0.0f;
+            float s = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int rn = 0; rn < WN; ++rn) {
+                float v = acc[rm][rn][reg] + bsv;
+                if (rok && cval[rn]) {
+                    float* dst = p.y + ycol[rn] + (int64_t)gm * HWo;
+                    if (p.res) v += p.res[ycol[rn] + (int64_t)gm * HWo];
+                    if (p.beta) v += *dst;
+                    *dst = v;
+                    s += v;
+                    q += v * v;
+                }
+            }
+            if (p.stats) {
+                s = half_sum_hi(s);
+                q = half_sum_hi(q);
+                if (l31 == 31) {   // each (wave column, row) slot has exactly one writer
+                    srow[(wn_idx * 2 + 0) * BM + row] = rok ? s : 0.0f;
+                    srow[(wn_idx * 2 + 1) * BM + row] = rok ? q : 0.0f;
+                }
+            }
+        }
+    if (p.stats) {
+        __syncthreads();
+        // partial sums of the wave columns added in a FIXED order (BatchNorm statistics stay reproducible), then one f64 atomic
+        // pair per row per workgroup into the statistics replica of this tile
+        double* st = p.stats + (int64_t)(tile % p.nrep) * 2 * p.M;
+        for (int i = tid; i < 2 * BM; i += NT) {
+            const int row = i % BM, which = i / BM, gm = m0 + row;
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WVN; ++w) tot += srow[(w * 2 + which) * BM + row];
+            if (gm < p.M) atomic_add_d(st + which * p.M + gm, (double)tot);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE>
+static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
+    constexpr bool PIX = BMODE == BM_PIX;
+    constexpr int WVN = 4 / WVM;
+    constexpr int BM = WVM * WM * 32, BN = WVN * WN * 32;
+    constexpr int TT = PIX ? 1 : 9;
+    constexpr int NO = KCH / 8;
+    constexpr int USED = PIX ? BN : (R + 2) * (XW + 2);
+    constexpr size_t img = (size_t)(NO * TT * BM + NO * USED) * 16;
+    static_assert(img <= 160 * 1024, "LDS image");
+    static_assert((size_t)WVN * 2 * BM * sizeof(float) <= img, "statistics rows fit in the image");
+    p.n_mtiles = cdiv(p.M, BM);
+    const int nchunks = cdiv(p.Ctot, KCH);
+    const size_t lds = img + (PRO != S2K_PRO_NONE ? (size_t)2 * nchunks * KCH * sizeof(float) : 0);
+    if (lds > 160 * 1024) return 1;
+    {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
+        const bool local = !PIX || (p.HW % BN) == 0;
+        const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
+        const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
+        if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
+    }
+    const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
+    if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
+    p.n_tiles = (int)blocks;
+    p.splits = 1;
+    auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE>;
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    g_s2k_variant = 2;
+    return S2K_OK;
+}
+
+// tile height by M: 32-row tiles (1 x 4 waves over 256 pixels) for thin layers, 64 rows when 128 would pad M by more than 12 %
+template <int BMODE, int KCH, int R, int XW, int PRO, bool GATE>
+static int launch_b16_bm(ConvP& p, int n128, int n256, hipStream_t st) {
+    if (p.M <= 32) return 1;     // thin tiles are instantiated separately (their pixel tile differs)
+    const bool big = p.M > 64 && (double)cdiv(p.M, 128) * 128 / p.M <= 1.12;
+    (void)n256;
+    if (big) return launch_b16<BMODE, 2, 2, 2, KCH, R, XW, PRO, GATE>(p, n128, st);
+    return launch_b16<BMODE, 2, 1, 2, KCH, R, XW, PRO, GATE>(p, n128, st);
+}
+
+template <int KCH, int PRO, bool GATE>
+static int launch_b16_pix(ConvP& p, hipStream_t st) {
+    if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 256), st);
+    return launch_b16_bm<BM_PIX, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 128), 0, st);
+}
+
+// S2K_OK = launched, 1 = not one of its shapes (the caller takes the f32 kernels), < 0 = error
+int launch_conv_bf16(ConvP& p, hipStream_t st) {
+    if (!p.wtb || p.mode != S2K_MODE_CONV || p.S != 1 || p.HO != p.H || p.WO != p.W) return 1;
+    const int T = p.KH * p.KW;
+    if (T == 1) {
+        if (p.C2 != 0 || (p.HW & 3) || p.PT || p.PL) return 1;
+        if (p.gate1) {
+            if (p.pro1 == S2K_PRO_SILU) return launch_b16_pix<64, S2K_PRO_SILU, true>(p, st);
+            return 1;
+        }
+        switch (p.pro1) {
+            case S2K_PRO_NONE: return launch_b16_pix<64, S2K_PRO_NONE, false>(p, st);
+            case S2K_PRO_RELU: return launch_b16_pix<64, S2K_PRO_RELU, false>(p, st);
+            case S2K_PRO_SILU: return launch_b16_pix<64, S2K_PRO_SILU, false>(p, st);
+            case S2K_PRO_AFFINE: return launch_b16_pix<64, S2K_PRO_AFFINE, false>(p, st);
+            default: return 1;
+        }
+    }
+    if (T != 9 || p.KH != 3 || p.PT != 1 || p.PL != 1 || p.gate1) return 1;
+    if (p.pro1 != S2K_PRO_NONE && p.pro1 != S2K_PRO_RELU) return 1;
+    if (p.C2 > 0 && (p.pro2 != p.pro1 || (p.C1 % 16) != 0)) return 1;
+    auto tiles = [&](int r, int xw) {
+        p.R = r; p.XW = xw; p.IR = r + 2; p.IC = xw + 2; p.WS = xw + 2; p.CS = p.IR * p.WS;
+        p.tiles_x = cdiv(p.WO, xw);
+        p.tiles_y = cdiv(p.HO, r);
+        return p.B * p.tiles_x * p.tiles_y;
+    };
+    const bool relu = p.pro1 == S2K_PRO_RELU;
+#define B16_3X3(RR, XX) { const int n = tiles(RR, XX); \
+        return relu ? launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_RELU, false>(p, n, 0, st) \
+                    : launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_NONE, false>(p, n, 0, st); }
+    if (p.M <= 32) {
+        if (p.WO < 64 || p.WO % 64 != 0) return 1;
+        const int n = tiles(4, 64);
+        return relu ? launch_b16<BM_SPATIAL, 1, 1, 2, 16, 4, 64, S2K_PRO_RELU, false>(p, n, st)
+                    : launch_b16<BM_SPATIAL, 1, 1, 2, 16, 4, 64, S2K_PRO_NONE, false>(p, n, st);
+    }
+    if (p.WO >= 64 && p.WO % 64 == 0) B16_3X3(2, 64)
+    if (p.WO == 32) B16_3X3(4, 32)
+    if (p.WO == 16) B16_3X3(8, 16)
+    if (p.WO == 56 || p.WO == 112 || p.WO == 224) B16_3X3(2, 56)
+    if (p.WO == 28) B16_3X3(4, 28)
+    if (p.WO == 14) B16_3X3(8, 14)
+#undef B16_3X3
+    return 1;
+}
+
+}  // namespace s2k

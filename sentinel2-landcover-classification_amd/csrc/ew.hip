@@ -149,6 +149,37 @@ __global__ void __launch_bounds__(NTHREADS) weight_pack_kernel(const int* table,
     for (int ki = wave; ki < 64; ki += 4) dp[(int64_t)(kk0 + ki) * MP + m0 + lane] = tile[ki][lane];
 }
 
+// bf16-mixed plans: a second copy of every packed entry, rounded to bf16 (RNE) in the fragment order of the bf16 MFMA kernels,
+// [KP/8][T][MP][8] (eight consecutive input channels of one (tap, output row) are one 16-byte unit = one lane's MFMA A operand).
+// Reads the f32 pack the kernel above has just written (L2-hot, lanes along m), one 16-byte store per thread.
+__global__ void __launch_bounds__(NTHREADS) weight_pack_bf16_kernel(const int* table, int n_entries, const float* packed, uint4* dst16) {
+    const int64_t e0 = (int64_t)blockIdx.x * (NTHREADS * 8);       // first f32 element of this block's units
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)table[mid * 12 + 11] <= e0) lo = mid; else hi = mid - 1;
+    }
+    const int* r = table + lo * 12;
+    const int T = r[4], MP = r[9];
+    const int64_t v = ((e0 - r[11]) >> 3) + threadIdx.x;           // unit inside the entry: (ob * T + tap) * MP + m
+    const int m = (int)(v % MP);
+    const int64_t ot = v / MP;
+    const int tap = (int)(ot % T);
+    const int64_t ob = ot / T;
+    const float* sp = packed + r[1];
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = sp[((ob * 8 + q) * T + tap) * MP + m];
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    uint4 w;
+    { f2 a = {x[0], x[1]}; w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2)); }
+    { f2 a = {x[2], x[3]}; w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2)); }
+    { f2 a = {x[4], x[5]}; w.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2)); }
+    { f2 a = {x[6], x[7]}; w.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2)); }
+    dst16[(r[1] >> 3) + v] = w;                                   // ushort offset r[1] of the bf16 region = unit r[1] / 8
+}
+
 int launch_weight_pack(const S2kOp& op, const Ctx& c) {
     const int* table = ref_ptr<const int>(c, op.t[S2K_WEIGHT_PACK_T_TABLE]);
     const float* src = ref_ptr<const float>(c, op.t[S2K_WEIGHT_PACK_T_SRC]);
@@ -160,6 +191,12 @@ int launch_weight_pack(const S2kOp& op, const Ctx& c) {
         set_error("weight_pack: bad args (total must be a multiple of 4096: MP % 128 == 0, KP % 64 == 0)"); return S2K_EINVAL;
     }
     hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)(total >> 12)), dim3(NTHREADS), 0, c.stream, table, n, src, dst, total);
+    const int64_t b16 = op.n[S2K_WEIGHT_PACK_N_BF16_BASE];
+    if (b16 > 0) {
+        if (b16 & 15) { set_error("weight_pack: BF16_BASE must be a multiple of 16 bytes"); return S2K_EINVAL; }
+        hipLaunchKernelGGL(weight_pack_bf16_kernel, dim3((unsigned)(total / (NTHREADS * 8))), dim3(NTHREADS), 0, c.stream, table, n,
+                           dst, reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + b16));
+    }
     return S2K_OK;
 }
 

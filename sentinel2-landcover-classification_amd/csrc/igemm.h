@@ -9,6 +9,7 @@ enum { BM_PIX = 0, BM_SPATIAL = 1 };
 
 struct ConvP {
     const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
+    const void* wtb;     // bf16 copy of the packed weights ([KP/8][T][MP][8], WEIGHT_PACK BF16_BASE) when the stage carries S2K_FLAG_BF16, else null
     float* y;
     float* scratch;      // split-K partial tiles [splits][Y layout] (deep, short-N layers), or null
     int splits, chunks_per_split;
@@ -29,5 +30,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // igemm_pc.hip: S2K_OK = launched, 1 = not one of its shapes (the caller takes the generic kernels), < 0 = error
 int launch_conv_pc(ConvP& p, hipStream_t st);
+// conv_bf16.hip (bf16-mixed plans only: p.wtb set): same return convention
+int launch_conv_bf16(ConvP& p, hipStream_t st);
 
 }  // namespace s2k

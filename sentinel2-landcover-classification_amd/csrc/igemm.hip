@@ -585,9 +585,7 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     if (BMODE == BM_SPATIAL && p.gate1) { set_error("conv: SE gate is only supported on 1x1 convs"); return S2K_EINVAL; }
     auto kern = conv_igemm_kernel<BMODE, TT, WM, WN, WVM, WVN, KCH, EPT, MINW, BVEC>;
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (lds > 160 * 1024) { set_error("conv: LDS %zu too large", lds); return S2K_EINVAL; }
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
         const bool local = BMODE == BM_SPATIAL || (p.HW % BN) == 0;
@@ -659,7 +657,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.stats = ref_ptr<double>(c, op.t[S2K_CONV_T_STATS]);
     p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
     p.scratch = ref_ptr<float>(c, op.t[S2K_CONV_T_SCRATCH]);
-    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch};
+    p.wtb = (op.flags & S2K_FLAG_BF16) ? ref_ptr<const void>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
+    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb};
     for (const void* q : ptrs)
         if (q == reinterpret_cast<const void*>(1)) { set_error("conv: tensor references a null base"); return S2K_EFAULT; }
     const int32_t* d = op.d;
@@ -707,6 +706,12 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.Ntot = (int)ntot;
 
     hipStream_t st = c.stream;
+    if (p.wtb) {   // bf16-mixed plan: the shapes of conv_bf16.hip round their MFMA operands to bf16; 1 = not one of its shapes
+        const int rc = launch_conv_bf16(p, st);
+        if (rc != 1) return rc;
+        p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
+        p.n_tiles = p.n_mtiles = 0;
+    }
     {   // the prologue-light, MFMA-bound shapes run on the producer / consumer kernels (igemm_pc.hip); 1 = not one of theirs
         const int rc = launch_conv_pc(p, st);
         if (rc != 1) return rc;

@@ -340,8 +340,7 @@ static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     p.splits = 1;
     auto kern = conv_pc_kernel<BMODE, WM, KCH, R, XW, PRO, THIN, NARROW>;
     static PerDeviceOnce attr_once;
-    if (attr_once.first())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, p);
     g_s2k_variant = 1;
     return S2K_OK;

@@ -22,6 +22,8 @@ struct WgradP {
 // wgrad_pc.hip: returns S2K_OK when it launched the stage, 1 when the shape is not one of its instantiations (the caller
 // then takes the generic kernel), or a negative error code
 int launch_wgrad_pc(WgradP& p, int mode, hipStream_t st);
+// wgrad_bf16.hip (stages carrying S2K_FLAG_BF16 in bf16-mixed plans): same return convention
+int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st);
 
 // bijective remap: consecutive logical tiles land on the same XCD (hardware deals blocks round-robin over the 8 XCDs;
 // which XCD is irrelevant, only that ids congruent mod 8 share one)

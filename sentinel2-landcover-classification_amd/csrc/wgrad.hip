@@ -404,9 +404,7 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     if (MODE == WG_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("wgrad: halo exceeds EPT"); return S2K_EINVAL; }
     if (MODE == WG_SPATIAL && p.R * p.XWe > NPJ) { set_error("wgrad: tile exceeds pixel slots"); return S2K_EINVAL; }
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     // Pixel splits.  The 9-tap kernels hold 144 accumulator registers (one workgroup per CU), the 1x1 / 2x2 kernels run
     // ~3 per CU: pick the split count whose workgroup count fills whole rounds of those slots (288 workgroups on 256
     // slots take two rounds: 1.8x the time of 256), preferring fewer splits (each ends in an atomic combine of its tile).
@@ -494,6 +492,11 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.exp = wg_exp;
     hipStream_t st = c.stream;
     const int64_t npix = (int64_t)p.B * p.HWp;
+    if (op.flags & S2K_FLAG_BF16) {   // bf16-mixed plan: the shapes of wgrad_bf16.hip round their MFMA operands to bf16; 1 = not one of them
+        const int rc = launch_wgrad_bf16(p, mode, st);
+        if (rc != 1) return rc;
+        p.R = p.XW = p.XWe = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = 0;
+    }
     {   // the MFMA-bound shapes run on the producer / consumer kernels (wgrad_pc.hip); 1 = not one of theirs
         const int rc = launch_wgrad_pc(p, mode, st);
         if (rc != 1) return rc;

@@ -1,0 +1,369 @@
+// Weight gradients of the dense convs on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16, f32 accumulate): the
+// bf16-MIXED mode (see conv_bf16.hip; reported separately from the f32 parity path).  Same stage record and arithmetic as
+// wgrad.hip / wgrad_pc.hip -  dW[tap][m][c] += sum_pix Ppro[m][pix] * Qpro[c][pix + tap]  - with the two MFMA operands rounded to
+// bf16 when a tile is written to LDS; partial sums of the pixel splits are added with f32 atomics as before.  Replaces the same
+// reference code (ATen convolution_backward grad_weight of efficientnet_unet.py:168-176,319-372 under autocast).
+//
+// The contraction runs over PIXELS, and both operands are pixel-contiguous in memory ([row][pixels], f32): a lane's MFMA operand
+// - 8 consecutive pixels of its row - is 32 contiguous bytes of global memory.  A staging thread loads them (two 16-byte
+// loads), applies the prologue (BatchNorm affine + activation (+ SE gate), per-row constants), rounds to bf16 and stores ONE
+// 16-byte unit [pixel octet][row]; lanes are laid out 8 rows x 8 octets per wave instruction, so a wave reads 8 rows x 256
+// contiguous bytes and the 8 lanes of a ds_write_b128 group write 8 consecutive units (conflict-free).
+//
+// 3x3 (stride 1, pad 1): the nine taps read the SAME aligned pixel octets of the three halo rows, shifted by -1 / 0 / +1
+// pixel.  A shift by one pixel is 16 bits inside the 4-dword fragment: v_alignbit_b32 between neighbouring dwords, with the
+// last dword of the octet to the left / the first of the octet to the right at the ends (the tile's halo columns are one-pixel
+// units).  Five v_alignbit per halo row and k-step give all three horizontal taps.
+//
+// With bf16 MFMAs a weight gradient is bound by HBM / L2 bandwidth (32 flop per byte at 128 x 128 tiles against 312 flop per
+// byte of the chip), so the kernel is built for bytes in flight: 4 waves per workgroup, no role split, 2-3 workgroups per CU.
+#include <algorithm>
+
+#include "common.h"
+#include "wgrad.h"
+
+namespace s2k {
+
+typedef __bf16 wb16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wb16x2 __attribute__((ext_vector_type(2)));
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t wu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t wpk(float lo, float hi) {
+    wf32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wb16x2));
+}
+__device__ __forceinline__ uint32_t shr16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }   // {hi, lo} >> 16
+
+// prologue of 8 consecutive pixels of one row -> one bf16 unit; `valid` = the pixels exist (zero padding / ragged tiles: the
+// reference pads ACTIVATED maps with zeros)
+__device__ __forceinline__ wu32x4 pro_unit(const f32x4& a, const f32x4& b, int pro, float sc, float sh, float gate, bool valid) {
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (pro != S2K_PRO_NONE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = apply_pro(v[i], pro, sc, sh);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= gate;
+    wu32x4 w = {wpk(v[0], v[1]), wpk(v[2], v[3]), wpk(v[4], v[5]), wpk(v[6], v[7])};
+    if (!valid) w = wu32x4{0u, 0u, 0u, 0u};
+    return w;
+}
+
+// waves 2 (m) x 2 (c), each WM x WN accumulator tiles of 32 x 32 per tap
+template <int MODE, int WM, int WN, int R, int XW>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
+    constexpr bool PIX = MODE == WG_PIX;
+    constexpr int NT = 256;
+    constexpr int T = PIX ? 1 : 9;
+    constexpr int BM = WM * 64, BC = WN * 64;
+    constexpr int XO = PIX ? 8 : XW / 8;             // pixel octets per tile row
+    constexpr int NPO = PIX ? 8 : R * XO;            // P octets per row m
+    constexpr int QR = PIX ? 1 : R + 2;              // Q rows of the tile (halo rows)
+    constexpr int QXO = PIX ? 8 : XO + 2;            // Q unit slots per row: left halo pixel, XO octets, right halo pixel
+    constexpr int NQO = PIX ? 8 : QR * XO;           // Q full octets per channel
+    constexpr int P_UNITS = NPO * BM;
+    constexpr int PRG = BM / 32, QRG = BC / 32;      // row groups (8 rows) per wave: wave w owns groups w, w + 4, ...
+    constexpr int POB = (NPO + 7) / 8, QOB = (NQO + 7) / 8;      // octet blocks (8 octets = one wave instruction's width)
+    constexpr int NHI = PIX ? 0 : (BC * QR * 2 + NT - 1) / NT;   // halo-pixel items per thread
+    static_assert(PIX || (XW % 8 == 0 && NPO % 2 == 0), "3x3 tile: whole octets, whole k-steps");
+    extern __shared__ __attribute__((aligned(16))) wu32x4 smem_w[];
+    wu32x4* Ps = smem_w;
+    wu32x4* Qs = smem_w + P_UNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int mc = p.n_mtiles * p.n_ctiles;
+    const int v = wg_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = v / mc, tl = v - split * mc;
+    const int mt = tl % p.n_mtiles, ct = tl / p.n_mtiles;
+    const int m0 = mt * BM, c0 = ct * BC;
+    const int tile_begin = split * p.tiles_per_split;
+    int tile_end = tile_begin + p.tiles_per_split;
+    if (tile_end > p.ntiles) tile_end = p.ntiles;
+
+    // ---- per-thread staging rows: fixed for the whole kernel (a wave instruction = 8 rows x 8 octets) -------------------------
+    const int r8 = lane & 7, o8 = lane >> 3;
+    int prow[PRG], qrow[QRG];
+    float psc[PRG], psh[PRG], qsc[QRG], qsh[QRG];
+#pragma unroll
+    for (int j = 0; j < PRG; ++j) {
+        prow[j] = min(m0 + (wave + 4 * j) * 8 + r8, p.M - 1);        // rows past M re-read the last one (discarded at the combine)
+        psc[j] = p.prop != S2K_PRO_NONE ? p.bnvp[prow[j]] : 1.0f;
+        psh[j] = p.prop != S2K_PRO_NONE ? p.bnvp[p.M + prow[j]] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < QRG; ++j) {
+        qrow[j] = min(c0 + (wave + 4 * j) * 8 + r8, p.C - 1);
+        qsc[j] = p.proq != S2K_PRO_NONE ? p.bnvq[qrow[j]] : 1.0f;
+        qsh[j] = p.proq != S2K_PRO_NONE ? p.bnvq[p.C + qrow[j]] : 0.0f;
+    }
+    const int64_t ntot = (int64_t)p.B * p.HWp;
+    const bool img_local = !PIX || (p.HWp % 64) == 0;
+    const uint32_t p_rstep = (uint32_t)p.HWp * 4u, q_rstep = (uint32_t)p.HWq * 4u;
+
+    f32x16 acc[T][WM][WN];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
+    const int wm0 = (wave >> 1) * (WM * 32), wc0 = (wave & 1) * (WN * 32);
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        // ================================================ stage ================================================================
+        int tb = 0, y0 = 0, x0 = 0;
+        if (PIX) {
+            if (img_local) tb = (int)(((int64_t)tile * 64) / p.HWp);
+        } else {
+            const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
+            tb = tile / (p.tiles_x * p.tiles_y);
+            y0 = ty * R; x0 = tx * XW;
+        }
+        const rsrc_t rp = make_rsrc(p.p + (int64_t)tb * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - tb) * p.M * p.HWp * 4);
+        const rsrc_t rq = make_rsrc(p.q + (int64_t)tb * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - tb) * p.C * p.HWq * 4);
+        // byte offset of pixel octet `oct` of the P / Q tile inside a row (image-relative), or "no such pixels"
+        auto p_off = [&](int oct, uint32_t& off, int& b) -> bool {
+            b = tb;
+            if (oct >= NPO) return false;
+            if (PIX) {
+                const int64_t n = (int64_t)tile * 64 + 8 * oct;
+                if (n >= ntot) return false;
+                b = (int)(n / p.HWp);
+                off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (n - (int64_t)b * p.HWp)) * 4u;
+                return true;
+            }
+            const int r = oct / XO, k = oct % XO;
+            off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * 4u;
+            return y0 + r < p.HO;
+        };
+        auto q_off = [&](int oct, uint32_t& off, int& b) -> bool {
+            b = tb;
+            if (oct >= NQO) return false;
+            if (PIX) {
+                const int64_t n = (int64_t)tile * 64 + 8 * oct;
+                if (n >= ntot) return false;
+                b = (int)(n / p.HWq);
+                off = (uint32_t)((int64_t)(b - tb) * p.C * p.HWq + (n - (int64_t)b * p.HWq)) * 4u;
+                return true;
+            }
+            const int hr = oct / XO, k = oct % XO;
+            const int iy = y0 - 1 + hr;
+            off = (uint32_t)(iy * p.W + x0 + 8 * k) * 4u;
+            return iy >= 0 && iy < p.H;
+        };
+        // one batch = octet blocks [OB0, OB1) of every row group of this wave: all loads first, then prologue + bf16 + LDS
+        auto stage_p = [&](auto ob0c, auto ob1c) {
+            constexpr int OB0 = decltype(ob0c)::value, OB1 = decltype(ob1c)::value, NB = OB1 - OB0;
+            f32x4 xa[NB][PRG], xb[NB][PRG];
+            bool ok[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                uint32_t off = 0;
+                int b;
+                ok[ob] = p_off((OB0 + ob) * 8 + o8, off, b);
+#pragma unroll
+                for (int j = 0; j < PRG; ++j) {
+                    const uint32_t a = ok[ob] ? off + (uint32_t)prow[j] * p_rstep : BUF_OOB;
+                    xa[ob][j] = bload4(rp, a);
+                    xb[ob][j] = bload4(rp, ok[ob] ? a + 16u : BUF_OOB);
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const int oct = (OB0 + ob) * 8 + o8;
+                if (oct < NPO)
+#pragma unroll
+                    for (int j = 0; j < PRG; ++j)
+                        Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pro_unit(xa[ob][j], xb[ob][j], p.prop, psc[j], psh[j], 1.0f, ok[ob]);
+            }
+        };
+        auto stage_q = [&](auto ob0c, auto ob1c) {
+            constexpr int OB0 = decltype(ob0c)::value, OB1 = decltype(ob1c)::value, NB = OB1 - OB0;
+            f32x4 xa[NB][QRG], xb[NB][QRG];
+            float g[NB][QRG];
+            bool ok[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                uint32_t off = 0;
+                int b;
+                ok[ob] = q_off((OB0 + ob) * 8 + o8, off, b);
+#pragma unroll
+                for (int j = 0; j < QRG; ++j) {
+                    const uint32_t a = ok[ob] ? off + (uint32_t)qrow[j] * q_rstep : BUF_OOB;
+                    xa[ob][j] = bload4(rq, a);
+                    xb[ob][j] = bload4(rq, ok[ob] ? a + 16u : BUF_OOB);
+                    g[ob][j] = (PIX && p.gateq && ok[ob]) ? p.gateq[(int64_t)b * p.C + qrow[j]] : 1.0f;
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const int oct = (OB0 + ob) * 8 + o8;
+                if (oct < NQO) {
+                    const int slot = PIX ? oct : (oct / XO) * QXO + 1 + (oct % XO);
+#pragma unroll
+                    for (int j = 0; j < QRG; ++j)
+                        Qs[slot * BC + (wave + 4 * j) * 8 + r8] = pro_unit(xa[ob][j], xb[ob][j], p.proq, qsc[j], qsh[j], g[ob][j], ok[ob]);
+                }
+            }
+        };
+        using std::integral_constant;
+        // batches sized so that a batch's loads (+ the accumulators) fit the register file: <= 8 (octet block, row group) items
+        stage_p(integral_constant<int, 0>{}, integral_constant<int, POB>{});
+        if constexpr (QOB * QRG <= 8) {
+            stage_q(integral_constant<int, 0>{}, integral_constant<int, QOB>{});
+        } else {
+            constexpr int H1 = QOB / 2;
+            stage_q(integral_constant<int, 0>{}, integral_constant<int, H1>{});
+            stage_q(integral_constant<int, H1>{}, integral_constant<int, QOB>{});
+        }
+        if constexpr (!PIX) {
+            // the tile's halo columns: one pixel left of octet 0 (element 7 of the unit left of it) and one right of the last octet
+#pragma unroll
+            for (int i = 0; i < NHI; ++i) {
+                const int idx = tid + NT * i;
+                const int c = idx % BC, rest = idx / BC;
+                const int side = rest & 1, hr = rest >> 1;
+                const int iy = y0 - 1 + hr, ix = side ? x0 + XW : x0 - 1;
+                const bool ok = idx < BC * QR * 2 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const int gc = min(c0 + c, p.C - 1);
+                float x = bload(rq, ok ? (uint32_t)(iy * p.W + ix) * 4u + (uint32_t)gc * q_rstep : BUF_OOB);
+                if (p.proq != S2K_PRO_NONE) x = apply_pro(x, p.proq, p.bnvq[gc], p.bnvq[p.C + gc]);
+                if (!ok) x = 0.0f;
+                if (idx < BC * QR * 2)
+                    Qs[(hr * QXO + (side ? XO + 1 : 0)) * BC + c] = side ? wu32x4{wpk(x, 0.0f), 0u, 0u, 0u} : wu32x4{0u, 0u, 0u, wpk(0.0f, x)};
+            }
+        }
+        __syncthreads();
+
+        // ================================================ multiply =============================================================
+#pragma unroll
+        for (int s = 0; s < NPO / 2; ++s) {
+            const int o = 2 * s + lh;                                   // this lane half's pixel octet
+            wb16x8 a[WM];
+#pragma unroll
+            for (int rm = 0; rm < WM; ++rm) a[rm] = __builtin_bit_cast(wb16x8, Ps[o * BM + wm0 + rm * 32 + l31]);
+            if constexpr (PIX) {
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn) {
+                    const wb16x8 b = __builtin_bit_cast(wb16x8, Qs[o * BC + wc0 + rn * 32 + l31]);
+#pragma unroll
+                    for (int rm = 0; rm < WM; ++rm)
+                        acc[0][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm], b, acc[0][rm][rn], 0, 0, 0);
+                }
+            } else {
+                const int r = o / XO, k = o % XO;
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const wu32x4* base = Qs + ((r + dy) * QXO + 1 + k) * BC + wc0 + rn * 32 + l31;
+                        const wu32x4 cur = base[0];
+                        const uint32_t pl = reinterpret_cast<const uint32_t*>(base - BC)[3];     // last dword of the unit to the left
+                        const uint32_t nf = reinterpret_cast<const uint32_t*>(base + BC)[0];     // first dword of the unit to the right
+                        const uint32_t s01 = shr16(cur[1], cur[0]), s12 = shr16(cur[2], cur[1]), s23 = shr16(cur[3], cur[2]);
+                        const wu32x4 left = {shr16(cur[0], pl), s01, s12, s23};                   // pixels x - 1 .. x + 6
+                        const wu32x4 right = {s01, s12, s23, shr16(nf, cur[3])};                  // pixels x + 1 .. x + 8
+                        const wb16x8 b0 = __builtin_bit_cast(wb16x8, left), b1 = __builtin_bit_cast(wb16x8, cur), b2 = __builtin_bit_cast(wb16x8, right);
+#pragma unroll
+                        for (int rm = 0; rm < WM; ++rm) {
+                            acc[dy * 3 + 0][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm], b0, acc[dy * 3 + 0][rm][rn], 0, 0, 0);
+                            acc[dy * 3 + 1][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm], b1, acc[dy * 3 + 1][rm][rn], 0, 0, 0);
+                            acc[dy * 3 + 2][rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rm], b2, acc[dy * 3 + 2][rm][rn], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- combine: wgs[t][m][c] += acc ------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+            for (int rn = 0; rn < WN; ++rn) {
+                const int gc = c0 + wc0 + rn * 32 + l31;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (gm < p.M && gc < p.C)
+                        atomicAdd(p.wgs + ((int64_t)t * p.M + gm) * p.CTOT + gc, acc[t][rm][rn][reg]);
+                }
+            }
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int MODE, int WM, int WN, int R, int XW>
+static int launch_wb16(WgradP& p, hipStream_t st) {
+    constexpr bool PIX = MODE == WG_PIX;
+    constexpr int BM = WM * 64, BC = WN * 64;
+    constexpr int XO = PIX ? 8 : XW / 8, NPO = PIX ? 8 : R * XO, QR = PIX ? 1 : R + 2, QXO = PIX ? 8 : XO + 2;
+    constexpr size_t lds = (size_t)(NPO * BM + QR * QXO * BC) * 16;
+    static_assert(lds <= 160 * 1024, "LDS image");
+    p.n_mtiles = cdiv(p.M, BM);
+    p.n_ctiles = cdiv(p.C, BC);
+    {   // 32-bit buffer offsets: one image below 2 GiB when tiles are image-local, else the whole tensor
+        const bool local = !PIX || (p.HWp % 64) == 0;
+        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
+        if (need >= 0x7ffffff0ll) return 1;
+    }
+    auto kern = wgrad_bf16_kernel<MODE, WM, WN, R, XW>;
+    static PerDeviceOnce attr_once;
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    // pixel splits: enough workgroups for ~3 per CU; each split ends in an atomic combine of its accumulator tiles, so at least
+    // 8 pixel tiles per split
+    const int mc = p.n_mtiles * p.n_ctiles;
+    int splits = std::max(1, (3 * 256) / mc);
+    splits = std::min(splits, std::max(1, p.ntiles / 8));
+    if (splits > 65535) splits = 65535;
+    p.tiles_per_split = cdiv(p.ntiles, splits);
+    splits = cdiv(p.ntiles, p.tiles_per_split);
+    hipLaunchKernelGGL(kern, dim3(mc * splits), dim3(256), lds, st, p);
+    g_s2k_variant = 2;
+    return S2K_OK;
+}
+
+template <int MODE, int R, int XW>
+static int launch_wb16_edges(WgradP& p, hipStream_t st) {
+    // tile edge per side: 128 unless it pads the side by more than 12 %
+    auto edge = [](int n) { return (n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64; };
+    const int em = edge(p.M), ec = edge(p.C);
+    (void)em; (void)ec;     // 3x3: nine accumulator tiles per wave already (64 x 64 workgroup tiles only)
+    if constexpr (MODE == WG_PIX) {
+        if (em == 128 && ec == 128) return launch_wb16<MODE, 2, 2, R, XW>(p, st);
+        if (em == 128) return launch_wb16<MODE, 2, 1, R, XW>(p, st);
+        if (ec == 128) return launch_wb16<MODE, 1, 2, R, XW>(p, st);
+    }
+    return launch_wb16<MODE, 1, 1, R, XW>(p, st);
+}
+
+// S2K_OK = launched, 1 = not one of its shapes (the caller takes the f32 kernels), < 0 = error
+int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
+    if (mode != S2K_MODE_CONV || p.S != 1 || p.H != p.HO || p.W != p.WO || p.gatep) return 1;
+    auto pro_ok = [](int pro) { return pro == S2K_PRO_NONE || pro == S2K_PRO_RELU || pro == S2K_PRO_SILU || pro == S2K_PRO_AFFINE || pro == S2K_PRO_GELU; };
+    if (!pro_ok(p.prop) || !pro_ok(p.proq)) return 1;
+    if (p.T == 1) {
+        if ((p.HWp & 7) || (int64_t)p.B * p.HWp < 512) return 1;
+        p.NP = 64;
+        p.ntiles = (int)cdiv64((int64_t)p.B * p.HWp, 64);
+        return launch_wb16_edges<WG_PIX, 1, 64>(p, st);
+    }
+    if (p.T != 9 || p.KH != 3 || p.KW != 3 || p.PT != 1 || p.PL != 1 || p.gateq || p.prop != S2K_PRO_NONE) return 1;
+    auto setup = [&](int r, int xw) {
+        p.R = r; p.XW = xw; p.XWe = xw;
+        p.tiles_x = p.WO / xw;
+        p.tiles_y = cdiv(p.HO, r);
+        p.ntiles = p.B * p.tiles_x * p.tiles_y;
+        p.NP = 0;
+    };
+    if (p.WO % 64 == 0) { setup(2, 64); return launch_wb16_edges<WG_SPATIAL, 2, 64>(p, st); }
+    if (p.WO == 32) { setup(4, 32); return launch_wb16_edges<WG_SPATIAL, 4, 32>(p, st); }
+    if (p.WO == 16) { setup(8, 16); return launch_wb16_edges<WG_SPATIAL, 8, 16>(p, st); }
+    return 1;
+}
+
+}  // namespace s2k

@@ -345,8 +345,7 @@ static int launch_pc2(WgradP& p, hipStream_t st) {
     if (lds > 160 * 1024) { set_error("wgrad: LDS %zu too large", lds); return S2K_EINVAL; }
     auto kern = wgrad_pc_kernel<MODE, T, WM, WN, WVM, WVN, WVK, NPJ, R, XWE, PROP, PROQ>;
     static PerDeviceOnce attr_once;
-    if (attr_once.first())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     // Pixel splits: one 8-wave workgroup per CU (LDS); pick the split count whose workgroup count fills whole rounds of the
     // 256 CUs, preferring fewer splits (each ends in an atomic combine of its accumulator tile).
     const int mc = p.n_mtiles * p.n_ctiles;

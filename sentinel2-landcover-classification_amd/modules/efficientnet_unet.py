@@ -287,7 +287,24 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
     # -- engine ---------------------------------------------------------------------------
     def _make_plan(self, B: int, H: int, W: int, training: bool, want_bwd: bool | None = None, want_dx: bool = False):
         return plan_unet(self.spec, B, H, W, training, self._layout, defer_wgrads=getattr(self, "_defer_wgrads", None),
-                         want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx)
+                         want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx,
+                         bf16=self.precision == "bf16-mixed")
+
+    @property
+    def precision(self) -> str:
+        """"f32" (default: exact-f32 MFMA everywhere, the parity path) or "bf16-mixed": dense convs and weight gradients may
+        round their MFMA operands to bf16 (f32 accumulation, f32 BatchNorm statistics / loss / master weights / Adam) - the
+        arithmetic class of the reference's own default `precision="bf16"` (configs/segmentation.py:146,153), reported
+        separately from the f32 results and never the default."""
+        return getattr(self, "_precision", "f32")
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("f32", "bf16-mixed"):
+            raise ValueError(f"precision must be 'f32' or 'bf16-mixed', got {value!r}")
+        if value != self.precision:
+            self._precision = value
+            self._engines.clear()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..engine import run_unet

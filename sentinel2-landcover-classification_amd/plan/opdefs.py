@@ -36,6 +36,10 @@ ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 2, 3, 4                   # same num
 ACT_MUL = 5                                                            # ACT_BWD only: multiply by X instead of act'(X)
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
 FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream fork / join)
+# S2kOp.flags of CONV / WGRAD, bf16-MIXED plans only: the stage MAY round its two MFMA operands to bf16 (f32 accumulate, f32
+# epilogue; csrc/conv_bf16.hip, wgrad_bf16.hip) when the shape is one of the bf16 kernels'; CONV then reads the bf16 weight
+# copy WTB that WEIGHT_PACK wrote (BF16_BASE).  Without the flag every stage computes in exact f32 (the parity path).
+FLAG_BF16 = 4
 
 # BN_FINALIZE folded into the first consumer of its {scale, shift} (a 5 us launch per BatchNorm otherwise: 126 per U-Net step):
 # the consumer's BNV becomes an OUTPUT computed from FSTATS (NREP replicas of {sum, sumsq}[C], FCOUNT elements per channel) with
@@ -53,7 +57,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # start}:  DST[dst_off + (kc*T + tap)*MP + m] = SRC[src_off + m*s_m + kc*s_k + (flip ? T-1-tap : tap)*s_t]
     # for m < M, kc < K, zero in the padding (MP = M rounded up to 128, KP = K rounded up to 64), so the
     # conv kernel copies A tiles with aligned 16-byte loads and needs no bounds checks.  Runs once per step.
-    "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL"], ["N_ENTRIES"], []),
+    # BF16_BASE > 0 (bf16-mixed plans): additionally DST_bytes[BF16_BASE + 2*dst_off ...] receives every entry as bf16 in the
+    # fragment order of the bf16 MFMA kernels, [KP/8][T][MP][8]: element ((kc/8 * T + tap) * MP + m) * 8 + kc % 8
+    "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL", "BF16_BASE"], ["N_ENTRIES"], []),
     # Implicit-GEMM convolution on f32 MFMA (fwd conv / convT fwd / conv dgrad / convT dgrad):
     #   Y[b][m][yo][xo] (+)= BIAS[m] + sum_{c,ky,kx} Wv[m][c][ky][kx] * Xpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     # with Wv[m][c][tap] = WT[m*W_SM + c*W_SK + (FLIP ? T-1-tap : tap)*W_ST] (the HIP kernel requires the
@@ -66,7 +72,8 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # A Linear over feature-major tokens [B][C][L] is this stage with H = 1, W = L.
     # SCRATCH (optional, >= 8 * B*YC*HO*WO floats): lets the kernel cut a long reduction over few output tiles into
     # split-K partials that a tail kernel adds in a fixed order (deep 8x8 / 16x16 layers: 160 tiles cannot fill 256 CUs).
-    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH"], [],
+    # WTB (with FLAG_BF16): the bf16 copy of WT written by WEIGHT_PACK (BF16_BASE)
+    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH", "WTB"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
               "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
     # Weight gradient on f32 MFMA, K = pixels:

@@ -795,7 +795,30 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         bwd = p.bwd
     pack_op(p.fwd, p.pack_rows["fwd"])
     attach_splitk_scratch()
+    if getattr(p, "bf16", False):
+        mark_bf16(p, bwd)
     return segments, bwd
+
+
+def mark_bf16(p: "_P", bwd) -> None:
+    """bf16-MIXED plan (reported separately from the f32 parity path; the reference's own default is precision="bf16",
+    configs/segmentation.py:146,153): every dense conv / Linear and every weight gradient MAY round its two MFMA operands to bf16
+    (FLAG_BF16; f32 accumulation, f32 BatchNorm statistics, loss, master weights and optimiser).  WEIGHT_PACK writes a bf16 copy
+    of every packed weight into a mirror region behind the f32 packs (BF16_BASE); which stages actually take the bf16 kernels is
+    the native launcher's decision (csrc/conv_bf16.hip, wgrad_bf16.hip: their shape lists), the others stay exact f32."""
+    base = (p.wpack.mark() + 255) // 256 * 256
+    for prog in (p.fwd, bwd):
+        if prog is None:
+            continue
+        for kind, f in prog.ops:
+            if kind == "WEIGHT_PACK":
+                f["BF16_BASE"] = base
+            elif kind == "CONV" and f.get("MODE") == D.MODE_CONV and isinstance(f.get("WT"), TRef) and f["WT"].base == D.BASE["WPACK"]:
+                f["_flags"] = f.get("_flags", 0) | D.FLAG_BF16
+                f["WTB"] = TRef(D.BASE["WPACK"], base + f["WT"].off // 2, f["WT"].shape, "i16", "bf16:" + f["WT"].name)
+            elif kind == "WGRAD" and f.get("MODE") == D.MODE_CONV:
+                f["_flags"] = f.get("_flags", 0) | D.FLAG_BF16
+    p.wpack.top = base + (base + 1) // 2 + 256
 
 
 def fold_bn_finalize(prog: Program) -> int:
@@ -902,14 +925,16 @@ def build_encoder_layout(spec: UnetSpec) -> ParamLayout:
 
 def plan_unet(spec: UnetSpec, B: int, H: int, W: int, training: bool, layout: ParamLayout | None = None,
               bucket_floats: int = 8 << 20, defer_wgrads: bool | None = None, want_bwd: bool | None = None,
-              want_dx: bool = False) -> UnetPlan:
+              want_dx: bool = False, bf16: bool = False) -> UnetPlan:
     """defer_wgrads: None = the S2K_DEFER_WGRAD default (on); False keeps the decoder's weight gradients where the tape emits
-    them, so that gradient buckets become final progressively (what the data-parallel reducer wants, see ddp.py)."""
+    them, so that gradient buckets become final progressively (what the data-parallel reducer wants, see ddp.py).
+    bf16: the bf16-mixed plan (mark_bf16)."""
     if H % 32 or W % 32:
         raise ValueError(f"EfficientnetUnet needs H, W multiples of 32, got {H}x{W}")
     layout = layout or build_layout(spec)
     p = _P(spec, layout, B, H, W, training, want_bwd)
     p.defer_wgrads = defer_wgrads
+    p.bf16 = bool(bf16)
     eps, mom = spec.bn_eps, spec.bn_momentum
     # want_dx: the caller's input requires a gradient (torch semantics: x.requires_grad) — it lands in the DX base
     x_in = Act(TRef(D.BASE["X"], 0, (B, spec.in_channels, H, W), "f32", "x"), spec.in_channels, H, W,

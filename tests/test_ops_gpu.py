@@ -51,20 +51,26 @@ class Case:
         invstd = torch.rand(C, generator=self.gen) + 0.7
         return self.t(name, (4, C), torch.stack([scale, shift, mean, invstd]))
 
-    def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0):
-        """WEIGHT_PACK record for one weight tensor living in this arena; returns (pre-op, packed ref, MP)."""
+    def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0, bf16=False):
+        """WEIGHT_PACK record for one weight tensor living in this arena; returns (pre-op, packed ref, MP) and, with bf16, the
+        reference of the bf16 copy as a fourth element."""
         MP, KP = (M + 127) // 128 * 128, (K + 63) // 64 * 64
         dst = self.t(f"packed{len(self.items)}", (KP * T, MP), "nan")
         row = [wt.off // 4 + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip, MP, KP, 0]
         tab = self.t(f"packtab{len(self.items)}", (1, 12), torch.tensor([row]), "i32")
         zero = self.arena.alloc("zero", (1,))  # offsets in the table are relative to SRC / DST = arena start
-        pre = ("WEIGHT_PACK", dict(TABLE=tab, SRC=zero.at(-(zero.off // 4)), DST=zero.at(-(zero.off // 4)),
-                                   TOTAL=KP * T * MP, N_ENTRIES=1))
-        return pre, dst, MP
+        fields = dict(TABLE=tab, SRC=zero.at(-(zero.off // 4)), DST=zero.at(-(zero.off // 4)), TOTAL=KP * T * MP, N_ENTRIES=1)
+        if not bf16:
+            return ("WEIGHT_PACK", fields), dst, MP
+        # the bf16 copy of an entry lives at DST bytes + BF16_BASE + 2 * dst_off (plan: a mirror region behind the f32 packs)
+        dst16 = self.t(f"packed16_{len(self.items)}", (KP * T * MP // 2,), "nan")
+        fields["BF16_BASE"] = dst16.off - dst.off // 2
+        return ("WEIGHT_PACK", fields), dst, MP, dst16
 
-    def run(self, kind, outputs, tol=1e-4, sum0=(), pre=(), **fields):
+    def run(self, kind, outputs, tol=1e-4, sum0=(), pre=(), want_variant=None, **fields):
         """sum0: outputs compared after summing their leading (statistics-replica) dimension.
-        pre: stage records to run first (e.g. WEIGHT_PACK)."""
+        pre: stage records to run first (e.g. WEIGHT_PACK).  want_variant: the kernel family the stage must have taken
+        (s2k_program_profile_variants: 0 generic, 1 producer / consumer, 2 bf16 MFMA)."""
         from s2lc_amd import _lib
 
         prog = Program()
@@ -78,6 +84,9 @@ class Case:
         gpu = cpu.cuda()
         _lib.run(packed, _lib.Bases().set("WS", gpu), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+        if want_variant is not None:       # on a second copy of the inputs (a profiled run executes the stages again)
+            _, var = _lib.profile_variants(packed, _lib.Bases().set("WS", cpu.cuda()), torch.cuda.current_stream().cuda_stream)
+            assert int(var[-1]) == want_variant, f"{kind}: kernel family {int(var[-1])}, expected {want_variant}"
         got = gpu.cpu()
         ops_ref.run_program(packed, {WS: cpu}, D)
         for name in outputs:
@@ -111,7 +120,10 @@ def test_mfma_lane_maps_exact():
 # CONV (implicit GEMM)
 # ---------------------------------------------------------------------------------------------------
 def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias, stats, beta=0, mode=0, flip=0,
-               strides=None, seed=0, tol=1e-4, yc=None):
+               strides=None, seed=0, tol=1e-4, yc=None, bf16=False):
+    """bf16: the stage carries FLAG_BF16 + the bf16 weight copy, must run on the bf16 MFMA kernels (csrc/conv_bf16.hip) and is
+    compared with the oracle on bf16-ROUNDED operands (f32 products and sums): what is left is f32 summation order, so the
+    tolerance stays 1e-4 - rounding of the operands is arithmetic the oracle states too, not kernel error."""
     c = Case(seed)
     T = k * k
     Ct = C1 + C2
@@ -139,10 +151,53 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     nrep = D.stats_replicas(M)
     st_ref = c.t("stats", (nrep, 2, M), "zeros", "f64") if stats else None
     outs = ["y"] + (["stats"] if stats else [])
-    pre, wp, MP = c.pack(wt, M, Ct, T, sm, sk, st, flip)
+    extra = {}
+    if bf16:
+        # An activated value within an ulp of a bf16 rounding boundary may round to the other neighbour on the GPU (its SiLU is
+        # v_exp + v_rcp, its BatchNorm affine one fma): one operand then differs by 2^-8 relative.  Over a long reduction a few
+        # such flips add up to ~1e-4 of the largest output; the bar for stages WITH a prologue is 1e-3 (the f32 summation-order
+        # bar of 1e-4 holds for prologue-free operands, which round identically on both sides).
+        if pro1 or pro2:
+            tol = max(tol, 1e-3)
+        pre, wp, MP, wp16 = c.pack(wt, M, Ct, T, sm, sk, st, flip, bf16=True)
+        extra = dict(WTB=wp16, _flags=D.FLAG_BF16, want_variant=2)
+    else:
+        pre, wp, MP = c.pack(wt, M, Ct, T, sm, sk, st, flip)
     c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
           BIAS=bs, Y=y, STATS=st_ref, B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho,
-          WO=Wo, PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=beta, YC=YC)
+          WO=Wo, PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=beta, YC=YC, **extra)
+
+
+# ---- bf16-mixed: the same stage records with FLAG_BF16 (csrc/conv_bf16.hip) -----------------------------------------------------------
+@pytest.mark.parametrize("B,C1,H,W,M,pro,gate,bias,stats,beta", [
+    (3, 24, 16, 16, 144, 0, False, False, True, 0),     # short K (24 of a 64-channel chunk), 128-row tiles
+    (2, 144, 16, 16, 40, 2, True, False, True, 0),      # project conv: BatchNorm + SiLU + SE gate prologue, 64-row tiles
+    (2, 40, 12, 20, 240, 0, False, False, True, 0),
+    (2, 1824, 8, 8, 304, 2, True, False, True, 0),      # deep project conv: 29 chunks, few pixels
+    (2, 32, 24, 24, 24, 3, False, True, False, 0),      # thin (M <= 32): 1 x 4 waves over 256 pixels, ReLU prologue, bias
+    (1, 13, 8, 8, 48, 0, False, False, True, 0),        # K tail (13 channels)
+    (4, 264, 64, 64, 200, 3, False, True, True, 0),     # K tail (264 = 4 x 64 + 8), ReLU prologue, bias
+    (6, 288, 1, 200, 320, 0, False, True, False, 1),    # a Linear over feature-major tokens (H = 1), accumulate into Y
+    (3, 256, 100, 100, 176, 1, False, False, True, 0),  # AFFINE prologue; tiles straddle images, ragged last tile
+    (2, 96, 20, 20, 96, 2, False, False, True, 0),      # SiLU prologue without a gate (MBConv expand output read by ... a 1x1)
+])
+def test_conv1x1_bf16(B, C1, H, W, M, pro, gate, bias, stats, beta):
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, pro, 0, gate, bias=bias, stats=stats, beta=beta, bf16=True)
+
+
+@pytest.mark.parametrize("B,C1,C2,H,W,M,pro,beta", [
+    (4, 32, 24, 64, 128, 64, 0, 0),      # (R, XW) = (2, 64): decoder concat conv (C1 a multiple of 16), two x tiles per row
+    (8, 64, 0, 32, 32, 128, 3, 0),       # (4, 32): BatchNorm + ReLU prologue, zero padding after the activation
+    (20, 72, 0, 16, 16, 192, 3, 1),      # (8, 16): K tail (72 = 4 x 16 + 8), accumulate
+    (4, 24, 0, 30, 56, 72, 0, 0),        # (2, 56) (224-pixel inputs), odd row count, K tail
+    (12, 32, 0, 28, 28, 64, 3, 0),       # (4, 28)
+    (40, 64, 0, 14, 14, 128, 0, 0),      # (8, 14)
+    (8, 32, 13, 64, 64, 32, 0, 0),       # thin (M <= 32): 4 x 64 pixel tiles; concat with the raw 13-band input (K tail in source 2)
+    (8, 32, 0, 64, 64, 32, 3, 0),        # thin, BatchNorm + ReLU prologue
+    (6, 64, 0, 62, 128, 24, 0, 1),       # thin, M = 24, ragged last tile row, accumulate
+])
+def test_conv3x3_bf16(B, C1, C2, H, W, M, pro, beta):
+    _conv_case(B, C1, C2, H, W, M, 3, 1, 1, 1, H, W, pro, pro if C2 else 0, False, bias=True, stats=(beta == 0), beta=beta, bf16=True)
 
 
 @pytest.mark.parametrize("B,C1,H,W,M,pro,gate", [
@@ -239,8 +294,13 @@ def test_conv_dgrad_1x1_and_gather():
 # ---------------------------------------------------------------------------------------------------
 # WGRAD
 # ---------------------------------------------------------------------------------------------------
-def _wgrad_case(B, M, C, CT, c_off, H, W, k, s, pt, pl, Ho, Wo, prop, proq, gateq, mode=0, seed=0, tol=2e-4):
+def _wgrad_case(B, M, C, CT, c_off, H, W, k, s, pt, pl, Ho, Wo, prop, proq, gateq, mode=0, seed=0, tol=2e-4, bf16=False):
+    """bf16: FLAG_BF16 - the stage must run on csrc/wgrad_bf16.hip and is compared with the oracle on bf16-ROUNDED operands
+    (see _conv_case for the tolerance of stages with a prologue)."""
     c = Case(seed)
+    extra = dict(_flags=D.FLAG_BF16, want_variant=2) if bf16 else {}
+    if bf16 and (prop or proq):
+        tol = max(tol, 1e-3)
     T = k * k
     P = c.t("p", (B, M, Ho, Wo))
     Q = c.t("q", (B, C, H, W))
@@ -249,7 +309,33 @@ def _wgrad_case(B, M, C, CT, c_off, H, W, k, s, pt, pl, Ho, Wo, prop, proq, gate
     gq = c.t("gateq", (B, C), "rand") if gateq else None
     wgs = c.t("wgs", (T, M, CT), "randn")  # accumulates on top of existing content
     c.run("WGRAD", ["wgs"], tol, P=P, BNVP=bp, GATEP=None, Q=Q, BNVQ=bq, GATEQ=gq, WGS=wgs.at(c_off), B=B, M=M, C=C,
-          CTOT=CT, H=H, W=W, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=prop, PROQ=proq, MODE=mode)
+          CTOT=CT, H=H, W=W, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=prop, PROQ=proq, MODE=mode, **extra)
+
+
+@pytest.mark.parametrize("B,M,C,H,W,prop,proq,gate", [
+    (5, 240, 250, 16, 16, 0, 0, False),      # 128 x 128 tiles, ragged on both sides
+    (8, 240, 72, 8, 8, 0, 2, True),          # 128 x 64, SiLU + SE gate on Q (a project conv's weight gradient)
+    (4, 40, 144, 16, 20, 0, 3, False),       # 64 x 128 (M = 40: one ragged 64-row tile), ReLU on Q
+    (3, 64, 64, 20, 20, 2, 0, False),        # 64 x 64, SiLU prologue on P (ConvTranspose weight gradient)
+    (2, 768, 384, 1, 520, 0, 0, False),      # a Linear over feature-major tokens: H = 1, W = tokens; tiles straddle images (520 = 8 x 65)
+    (4, 130, 130, 16, 16, 3, 0, False),      # 64-row tiles x 3, ReLU on P
+    (2, 24, 4, 64, 64, 0, 3, False),         # thin on both sides
+])
+def test_wgrad_1x1_bf16(B, M, C, H, W, prop, proq, gate):
+    _wgrad_case(B, M, C, C, 0, H, W, 1, 1, 0, 0, H, W, prop, proq, gate, bf16=True)
+
+
+@pytest.mark.parametrize("B,M,C,CT,c_off,H,W,proq", [
+    (2, 64, 64, 64, 0, 6, 64, 3),        # (R, XW) = (2, 64), BatchNorm + ReLU on Q: zero padding after the activation
+    (1, 128, 88, 88, 0, 10, 128, 0),     # (2, 64), two x tiles per row (the halo columns come from the neighbouring tile), ragged c tile
+    (2, 72, 40, 104, 64, 12, 32, 3),     # (4, 32), channel slice of a concat conv (CTOT > C), ragged m / c tiles
+    (2, 256, 64, 64, 0, 16, 16, 0),      # (8, 16): 4 m-tiles
+    (3, 64, 128, 128, 0, 10, 16, 3),     # (8, 16), H not a multiple of R
+    (1, 32, 13, 45, 32, 10, 128, 0),     # 13 of 64 columns used, channel slice of a concat conv
+    (2, 24, 32, 32, 0, 5, 64, 3),        # M below one tile, odd height (last tile has one row)
+])
+def test_wgrad_3x3_bf16(B, M, C, CT, c_off, H, W, proq):
+    _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False, bf16=True)
 
 
 @pytest.mark.parametrize("B,M,C,H,W,proq,gate", [(2, 40, 144, 16, 16, 2, True), (3, 144, 24, 12, 12, 0, False),
