@@ -41,7 +41,8 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 __device__ __forceinline__ int swz(int s) { return s ^ ((s >> 3) & 3); }
 
 // PRO: S2K_PRO_NONE / RELU / SILU / AFFINE (1x1), NONE / RELU (3x3).  GATE: SE gate [B][C1] multiplies the activated value (1x1).
-template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE>
+// SCATTER (1x1): S2K_MODE_CONVT_SCATTER - rows m = (co, dy, dx) are stored to Y[b][co][2y + dy][2x + dx] (ConvTranspose2d k2 s2).
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     constexpr bool PIX = BMODE == BM_PIX;
     constexpr int NT = 256;
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     constexpr int NBI = (B_ITEMS + NT - 1) / NT;
     static_assert(KCH % 16 == 0, "a k-step is 16 channels");
     static_assert(PIX || R * XW <= BN, "3x3 tile");
-    static_assert(PIX || (!GATE && (PRO == S2K_PRO_NONE || PRO == S2K_PRO_RELU)), "3x3: BatchNorm + ReLU prologue at most");
+    static_assert(PIX || (!GATE && !SCATTER && (PRO == S2K_PRO_NONE || PRO == S2K_PRO_RELU)), "3x3: BatchNorm + ReLU prologue at most");
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_b[];
     u32x4* As = smem_b;
     u32x4* Bs = smem_b + A_UNITS;
@@ -273,12 +274,39 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
             cval[rn] = n < p.Ntot;
             const int nn = cval[rn] ? n : 0;
             const int b = nn / p.HW, pp = nn - b * p.HW;
-            ycol[rn] = (int64_t)b * p.YC * HWo + pp;
+            if (SCATTER) {
+                const int yy = pp / p.W, xq = pp - yy * p.W;
+                ycol[rn] = (int64_t)b * p.YC * 4 * p.HW + (int64_t)(2 * yy) * (2 * p.W) + 2 * xq;
+            } else {
+                ycol[rn] = (int64_t)b * p.YC * HWo + pp;
+            }
         } else {
             const int r = j / XW, xx = j % XW;
             cval[rn] = (j < R * XW) && (y0 + r < p.HO) && (x0 + xx < p.WO);
             ycol[rn] = (int64_t)sb * p.YC * HWo + (int64_t)(y0 + r) * p.WO + (x0 + xx);
         }
+    }
+    if (SCATTER) {
+        // registers 4q .. 4q+3 of a lane are the 2 x 2 output patch (dy, dx) of one output channel co = row / 4
+        const int64_t plane = 4 * (int64_t)p.HW;
+#pragma unroll
+        for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gm = m0 + wm0 + rm * 32 + 8 * q + 4 * lh;
+                if (gm < p.M) {
+                    const int co = gm >> 2;
+                    const float bsv = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+                    for (int rn = 0; rn < WN; ++rn)
+                        if (cval[rn]) {
+                            float* dst = p.y + ycol[rn] + (int64_t)co * plane;
+                            *reinterpret_cast<float2*>(dst) = make_float2(acc[rm][rn][4 * q + 0] + bsv, acc[rm][rn][4 * q + 1] + bsv);
+                            *reinterpret_cast<float2*>(dst + 2 * p.W) = make_float2(acc[rm][rn][4 * q + 2] + bsv, acc[rm][rn][4 * q + 3] + bsv);
+                        }
+                }
+            }
+        return;
     }
     float* srow = reinterpret_cast<float*>(smem_b);              // [WVN wave columns][2][BM]  (the image is dead: barrier above)
     const int wn_idx = wave % WVN;
@@ -328,7 +356,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE>
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
 static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr bool PIX = BMODE == BM_PIX;
     constexpr int WVN = 4 / WVM;
@@ -353,7 +381,7 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
     p.n_tiles = (int)blocks;
     p.splits = 1;
-    auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE>;
+    auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE, SCATTER>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
@@ -361,26 +389,39 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     return S2K_OK;
 }
 
-// tile height by M: 32-row tiles (1 x 4 waves over 256 pixels) for thin layers, 64 rows when 128 would pad M by more than 12 %
-template <int BMODE, int KCH, int R, int XW, int PRO, bool GATE>
-static int launch_b16_bm(ConvP& p, int n128, int n256, hipStream_t st) {
-    if (p.M <= 32) return 1;     // thin tiles are instantiated separately (their pixel tile differs)
+// tile height by M: 64 rows when 128 would pad M by more than 12 % (32-row tiles, 1 x 4 waves over 256 pixels, are instantiated
+// by the callers: their pixel tile differs)
+template <int BMODE, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
+static int launch_b16_bm(ConvP& p, int n128, hipStream_t st) {
+    if (p.M <= 32) return 1;
     const bool big = p.M > 64 && (double)cdiv(p.M, 128) * 128 / p.M <= 1.12;
-    (void)n256;
-    if (big) return launch_b16<BMODE, 2, 2, 2, KCH, R, XW, PRO, GATE>(p, n128, st);
-    return launch_b16<BMODE, 2, 1, 2, KCH, R, XW, PRO, GATE>(p, n128, st);
+    if (big) return launch_b16<BMODE, 2, 2, 2, KCH, R, XW, PRO, GATE, SCATTER>(p, n128, st);
+    return launch_b16<BMODE, 2, 1, 2, KCH, R, XW, PRO, GATE, SCATTER>(p, n128, st);
 }
 
 template <int KCH, int PRO, bool GATE>
 static int launch_b16_pix(ConvP& p, hipStream_t st) {
     if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 256), st);
-    return launch_b16_bm<BM_PIX, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 128), 0, st);
+    // few pixels (the 8 x 8 / 16 x 16 maps of the deep blocks): 128-pixel tiles would leave most CUs without a workgroup and each
+    // of the few with a long serial K loop; 64 x 64 tiles give 4x the workgroups
+    const int n128 = cdiv(p.Ntot, 128);
+    if ((int64_t)n128 * cdiv(p.M, 128) < 200) return launch_b16<BM_PIX, 2, 1, 1, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 64), st);
+    return launch_b16_bm<BM_PIX, KCH, 1, 64, PRO, GATE>(p, n128, st);
 }
 
 // S2K_OK = launched, 1 = not one of its shapes (the caller takes the f32 kernels), < 0 = error
 int launch_conv_bf16(ConvP& p, hipStream_t st) {
-    if (!p.wtb || p.mode != S2K_MODE_CONV || p.S != 1 || p.HO != p.H || p.WO != p.W) return 1;
+    if (!p.wtb || p.S != 1 || p.HO != p.H || p.WO != p.W) return 1;
     const int T = p.KH * p.KW;
+    if (p.mode == S2K_MODE_CONVT_SCATTER) {
+        // ConvTranspose2d(k2, s2) forward: a 1x1 contraction with rows (co, dy, dx) and a scattering epilogue
+        if (T != 1 || p.C2 != 0 || (p.HW & 3) || p.gate1 || p.M <= 32 || (p.M & 3)) return 1;
+        const int n128 = cdiv(p.Ntot, 128);
+        if (p.pro1 == S2K_PRO_RELU) return launch_b16_bm<BM_PIX, 64, 1, 64, S2K_PRO_RELU, false, true>(p, n128, st);
+        if (p.pro1 == S2K_PRO_SILU) return launch_b16_bm<BM_PIX, 64, 1, 64, S2K_PRO_SILU, false, true>(p, n128, st);
+        return 1;
+    }
+    if (p.mode != S2K_MODE_CONV) return 1;
     if (T == 1) {
         if (p.C2 != 0 || (p.HW & 3) || p.PT || p.PL) return 1;
         if (p.gate1) {
@@ -406,8 +447,8 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
     };
     const bool relu = p.pro1 == S2K_PRO_RELU;
 #define B16_3X3(RR, XX) { const int n = tiles(RR, XX); \
-        return relu ? launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_RELU, false>(p, n, 0, st) \
-                    : launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_NONE, false>(p, n, 0, st); }
+        return relu ? launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_RELU, false>(p, n, st) \
+                    : launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_NONE, false>(p, n, st); }
     if (p.M <= 32) {
         if (p.WO < 64 || p.WO % 64 != 0) return 1;
         const int n = tiles(4, 64);

@@ -50,20 +50,26 @@ __device__ __forceinline__ wu32x4 pro_unit(const f32x4& a, const f32x4& b, int p
     return w;
 }
 
-// waves 2 (m) x 2 (c), each WM x WN accumulator tiles of 32 x 32 per tap
-template <int MODE, int WM, int WN, int R, int XW>
+// The four waves are arranged WVM (m) x WVC (c) x WVK (k): each computes WM x WN accumulator tiles of 32 x 32 per tap over the
+// k-steps s = wk, wk + WVK, ... of a pixel tile.  WVK > 1 (thin layers: a 32-channel side leaves one 32 x 32 tile per tap) splits the
+// pixels of a tile over waves; every wave adds its partial sums in the combine.
+// Pixel tile: 1x1: XW consecutive pixels (R = 1); 3x3: R rows x XW pixels.
+template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW>
 __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
     constexpr bool PIX = MODE == WG_PIX;
     constexpr int NT = 256;
     constexpr int T = PIX ? 1 : 9;
-    constexpr int BM = WM * 64, BC = WN * 64;
-    constexpr int XO = PIX ? 8 : XW / 8;             // pixel octets per tile row
-    constexpr int NPO = PIX ? 8 : R * XO;            // P octets per row m
+    constexpr int WVK = 4 / (WVM * WVC);
+    constexpr int BM = WVM * WM * 32, BC = WVC * WN * 32;
+    constexpr int NPJ = PIX ? XW : R * XW;           // pixels per tile
+    constexpr int XO = XW / 8;                       // pixel octets per tile row
+    constexpr int NPO = PIX ? XO : R * XO;           // P octets per row m
     constexpr int QR = PIX ? 1 : R + 2;              // Q rows of the tile (halo rows)
-    constexpr int QXO = PIX ? 8 : XO + 2;            // Q unit slots per row: left halo pixel, XO octets, right halo pixel
-    constexpr int NQO = PIX ? 8 : QR * XO;           // Q full octets per channel
+    constexpr int QXO = PIX ? XO : XO + 2;           // Q unit slots per row: left halo pixel, XO octets, right halo pixel
+    constexpr int NQO = PIX ? XO : QR * XO;          // Q full octets per channel
+    static_assert(WVM * WVC * WVK == 4 && (NPO / 2) % WVK == 0, "wave grid");
     constexpr int P_UNITS = NPO * BM;
-    constexpr int PRG = BM / 32, QRG = BC / 32;      // row groups (8 rows) per wave: wave w owns groups w, w + 4, ...
+    constexpr int PRG = BM / 32, QRG = BC / 32;      // row groups (8 rows) per wave: wave w owns groups w, w + 4, ...  (BM, BC >= 32)
     constexpr int POB = (NPO + 7) / 8, QOB = (NQO + 7) / 8;      // octet blocks (8 octets = one wave instruction's width)
     constexpr int NHI = PIX ? 0 : (BC * QR * 2 + NT - 1) / NT;   // halo-pixel items per thread
     static_assert(PIX || (XW % 8 == 0 && NPO % 2 == 0), "3x3 tile: whole octets, whole k-steps");
@@ -98,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
         qsh[j] = p.proq != S2K_PRO_NONE ? p.bnvq[p.C + qrow[j]] : 0.0f;
     }
     const int64_t ntot = (int64_t)p.B * p.HWp;
-    const bool img_local = !PIX || (p.HWp % 64) == 0;
+    const bool img_local = !PIX || (p.HWp % NPJ) == 0;
     const uint32_t p_rstep = (uint32_t)p.HWp * 4u, q_rstep = (uint32_t)p.HWq * 4u;
 
     f32x16 acc[T][WM][WN];
@@ -110,13 +116,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
-    const int wm0 = (wave >> 1) * (WM * 32), wc0 = (wave & 1) * (WN * 32);
+    const int wk = wave % WVK, wmn = wave / WVK;
+    const int wm0 = (wmn / WVC) * (WM * 32), wc0 = (wmn % WVC) * (WN * 32);
 
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         // ================================================ stage ================================================================
         int tb = 0, y0 = 0, x0 = 0;
         if (PIX) {
-            if (img_local) tb = (int)(((int64_t)tile * 64) / p.HWp);
+            if (img_local) tb = (int)(((int64_t)tile * NPJ) / p.HWp);
         } else {
             const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
             tb = tile / (p.tiles_x * p.tiles_y);
@@ -129,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
             b = tb;
             if (oct >= NPO) return false;
             if (PIX) {
-                const int64_t n = (int64_t)tile * 64 + 8 * oct;
+                const int64_t n = (int64_t)tile * NPJ + 8 * oct;
                 if (n >= ntot) return false;
                 b = (int)(n / p.HWp);
                 off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (n - (int64_t)b * p.HWp)) * 4u;
@@ -143,7 +150,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
             b = tb;
             if (oct >= NQO) return false;
             if (PIX) {
-                const int64_t n = (int64_t)tile * 64 + 8 * oct;
+                const int64_t n = (int64_t)tile * NPJ + 8 * oct;
                 if (n >= ntot) return false;
                 b = (int)(n / p.HWq);
                 off = (uint32_t)((int64_t)(b - tb) * p.C * p.HWq + (n - (int64_t)b * p.HWq)) * 4u;
@@ -211,13 +218,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
         };
         using std::integral_constant;
         // batches sized so that a batch's loads (+ the accumulators) fit the register file: <= 8 (octet block, row group) items
-        stage_p(integral_constant<int, 0>{}, integral_constant<int, POB>{});
+        if constexpr (POB * PRG <= 8) {
+            stage_p(integral_constant<int, 0>{}, integral_constant<int, POB>{});
+        } else {
+            constexpr int H1 = POB / 2;
+            stage_p(integral_constant<int, 0>{}, integral_constant<int, H1>{});
+            stage_p(integral_constant<int, H1>{}, integral_constant<int, POB>{});
+        }
         if constexpr (QOB * QRG <= 8) {
             stage_q(integral_constant<int, 0>{}, integral_constant<int, QOB>{});
-        } else {
+        } else if constexpr (QOB * QRG <= 16) {
             constexpr int H1 = QOB / 2;
             stage_q(integral_constant<int, 0>{}, integral_constant<int, H1>{});
             stage_q(integral_constant<int, H1>{}, integral_constant<int, QOB>{});
+        } else {
+            constexpr int H1 = QOB / 3, H2 = 2 * QOB / 3;
+            stage_q(integral_constant<int, 0>{}, integral_constant<int, H1>{});
+            stage_q(integral_constant<int, H1>{}, integral_constant<int, H2>{});
+            stage_q(integral_constant<int, H2>{}, integral_constant<int, QOB>{});
         }
         if constexpr (!PIX) {
             // the tile's halo columns: one pixel left of octet 0 (element 7 of the unit left of it) and one right of the last octet
@@ -240,7 +258,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
 
         // ================================================ multiply =============================================================
 #pragma unroll
-        for (int s = 0; s < NPO / 2; ++s) {
+        for (int s0 = 0; s0 < NPO / 2; s0 += WVK) {
+            const int s = s0 + wk;                                      // this wave's k-step (16 pixels)
             const int o = 2 * s + lh;                                   // this lane half's pixel octet
             wb16x8 a[WM];
 #pragma unroll
@@ -297,21 +316,32 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int MODE, int WM, int WN, int R, int XW>
+template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW>
 static int launch_wb16(WgradP& p, hipStream_t st) {
     constexpr bool PIX = MODE == WG_PIX;
-    constexpr int BM = WM * 64, BC = WN * 64;
-    constexpr int XO = PIX ? 8 : XW / 8, NPO = PIX ? 8 : R * XO, QR = PIX ? 1 : R + 2, QXO = PIX ? 8 : XO + 2;
+    constexpr int BM = WVM * WM * 32, BC = WVC * WN * 32;
+    constexpr int NPJ = PIX ? XW : R * XW;
+    constexpr int XO = XW / 8, NPO = PIX ? XO : R * XO, QR = PIX ? 1 : R + 2, QXO = PIX ? XO : XO + 2;
     constexpr size_t lds = (size_t)(NPO * BM + QR * QXO * BC) * 16;
     static_assert(lds <= 160 * 1024, "LDS image");
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
+    if (PIX) {
+        p.NP = NPJ;
+        p.ntiles = (int)cdiv64((int64_t)p.B * p.HWp, NPJ);
+    } else {
+        p.R = R; p.XW = XW; p.XWe = XW;
+        p.tiles_x = p.WO / XW;
+        p.tiles_y = cdiv(p.HO, R);
+        p.ntiles = p.B * p.tiles_x * p.tiles_y;
+        p.NP = 0;
+    }
     {   // 32-bit buffer offsets: one image below 2 GiB when tiles are image-local, else the whole tensor
-        const bool local = !PIX || (p.HWp % 64) == 0;
+        const bool local = !PIX || (p.HWp % NPJ) == 0;
         const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
         if (need >= 0x7ffffff0ll) return 1;
     }
-    auto kern = wgrad_bf16_kernel<MODE, WM, WN, R, XW>;
+    auto kern = wgrad_bf16_kernel<MODE, WVM, WVC, WM, WN, R, XW>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     // pixel splits: enough workgroups for ~3 per CU; each split ends in an atomic combine of its accumulator tiles, so at least
@@ -327,42 +357,34 @@ static int launch_wb16(WgradP& p, hipStream_t st) {
     return S2K_OK;
 }
 
-template <int MODE, int R, int XW>
-static int launch_wb16_edges(WgradP& p, hipStream_t st) {
-    // tile edge per side: 128 unless it pads the side by more than 12 %
-    auto edge = [](int n) { return (n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64; };
-    const int em = edge(p.M), ec = edge(p.C);
-    (void)em; (void)ec;     // 3x3: nine accumulator tiles per wave already (64 x 64 workgroup tiles only)
-    if constexpr (MODE == WG_PIX) {
-        if (em == 128 && ec == 128) return launch_wb16<MODE, 2, 2, R, XW>(p, st);
-        if (em == 128) return launch_wb16<MODE, 2, 1, R, XW>(p, st);
-        if (ec == 128) return launch_wb16<MODE, 1, 2, R, XW>(p, st);
-    }
-    return launch_wb16<MODE, 1, 1, R, XW>(p, st);
-}
-
 // S2K_OK = launched, 1 = not one of its shapes (the caller takes the f32 kernels), < 0 = error
 int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
     if (mode != S2K_MODE_CONV || p.S != 1 || p.H != p.HO || p.W != p.WO || p.gatep) return 1;
     auto pro_ok = [](int pro) { return pro == S2K_PRO_NONE || pro == S2K_PRO_RELU || pro == S2K_PRO_SILU || pro == S2K_PRO_AFFINE || pro == S2K_PRO_GELU; };
     if (!pro_ok(p.prop) || !pro_ok(p.proq)) return 1;
+    // tile edge per side: 32 for thin layers, 128 (1x1 only) unless it pads the side by more than 12 %, else 64
+    auto edge = [](int n) { return n <= 32 ? 32 : ((n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64); };
+    const int em = edge(p.M), ec = edge(p.C);
     if (p.T == 1) {
         if ((p.HWp & 7) || (int64_t)p.B * p.HWp < 512) return 1;
-        p.NP = 64;
-        p.ntiles = (int)cdiv64((int64_t)p.B * p.HWp, 64);
-        return launch_wb16_edges<WG_PIX, 1, 64>(p, st);
+        // thin sides: the waves split the pixels of 256-pixel tiles instead of the (single) accumulator tile
+        if (em == 32 && ec == 32) return launch_wb16<WG_PIX, 1, 1, 1, 1, 1, 256>(p, st);
+        if (em == 32) return launch_wb16<WG_PIX, 1, 2, 1, 1, 1, 128>(p, st);          // 32 x 64, two waves per k-step
+        if (ec == 32) return launch_wb16<WG_PIX, 2, 1, 1, 1, 1, 128>(p, st);          // 64 x 32
+        if (em == 128 && ec == 128) return launch_wb16<WG_PIX, 2, 2, 2, 2, 1, 64>(p, st);
+        if (em == 128) return launch_wb16<WG_PIX, 2, 2, 2, 1, 1, 64>(p, st);
+        if (ec == 128) return launch_wb16<WG_PIX, 2, 2, 1, 2, 1, 64>(p, st);
+        return launch_wb16<WG_PIX, 2, 2, 1, 1, 1, 64>(p, st);
     }
     if (p.T != 9 || p.KH != 3 || p.KW != 3 || p.PT != 1 || p.PL != 1 || p.gateq || p.prop != S2K_PRO_NONE) return 1;
-    auto setup = [&](int r, int xw) {
-        p.R = r; p.XW = xw; p.XWe = xw;
-        p.tiles_x = p.WO / xw;
-        p.tiles_y = cdiv(p.HO, r);
-        p.ntiles = p.B * p.tiles_x * p.tiles_y;
-        p.NP = 0;
-    };
-    if (p.WO % 64 == 0) { setup(2, 64); return launch_wb16_edges<WG_SPATIAL, 2, 64>(p, st); }
-    if (p.WO == 32) { setup(4, 32); return launch_wb16_edges<WG_SPATIAL, 4, 32>(p, st); }
-    if (p.WO == 16) { setup(8, 16); return launch_wb16_edges<WG_SPATIAL, 8, 16>(p, st); }
+    if (p.WO % 64 == 0) {
+        if (em == 32 && ec == 32) return launch_wb16<WG_SPATIAL, 1, 1, 1, 1, 4, 64>(p, st);     // 32 x 32 tile, 4 x 64 pixels, waves split the pixels
+        if (em == 32) return launch_wb16<WG_SPATIAL, 1, 2, 1, 1, 4, 64>(p, st);
+        if (ec == 32) return launch_wb16<WG_SPATIAL, 2, 1, 1, 1, 4, 64>(p, st);
+        return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 64>(p, st);
+    }
+    if (p.WO == 32) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 32>(p, st);
+    if (p.WO == 16) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 8, 16>(p, st);
     return 1;
 }
 

@@ -813,7 +813,8 @@ def mark_bf16(p: "_P", bwd) -> None:
         for kind, f in prog.ops:
             if kind == "WEIGHT_PACK":
                 f["BF16_BASE"] = base
-            elif kind == "CONV" and f.get("MODE") == D.MODE_CONV and isinstance(f.get("WT"), TRef) and f["WT"].base == D.BASE["WPACK"]:
+            elif kind == "CONV" and f.get("MODE") in (D.MODE_CONV, D.MODE_CONVT_SCATTER) and isinstance(f.get("WT"), TRef) \
+                    and f["WT"].base == D.BASE["WPACK"]:
                 f["_flags"] = f.get("_flags", 0) | D.FLAG_BF16
                 f["WTB"] = TRef(D.BASE["WPACK"], base + f["WT"].off // 2, f["WT"].shape, "i16", "bf16:" + f["WT"].name)
             elif kind == "WGRAD" and f.get("MODE") == D.MODE_CONV:

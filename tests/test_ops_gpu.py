@@ -269,6 +269,12 @@ def test_conv_transpose_scatter(B, Cin, Cout, H, W, pro):
                mode=D.MODE_CONVT_SCATTER, strides=((Cin, Cout, 4), (1, 4 * Cout, 1)))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pro", [(2, 24, 16, 8, 8, 3), (2, 2048, 512, 4, 4, 2), (2, 64, 32, 16, 24, 3)])
+def test_conv_transpose_scatter_bf16(B, Cin, Cout, H, W, pro):
+    _conv_case(B, Cin, 0, H, W, 4 * Cout, 1, 1, 0, 0, H, W, pro, 0, False, bias=True, stats=False,
+               mode=D.MODE_CONVT_SCATTER, strides=((Cin, Cout, 4), (1, 4 * Cout, 1)), bf16=True)
+
+
 @pytest.mark.parametrize("beta", [0, 1])
 def test_conv_dgrad_3x3_flip(beta):
     # dX[c] = sum_{m,tap} W[m][c_off+c][flip tap] dY[m]: rows = a channel slice of a concat conv
@@ -319,7 +325,9 @@ def _wgrad_case(B, M, C, CT, c_off, H, W, k, s, pt, pl, Ho, Wo, prop, proq, gate
     (3, 64, 64, 20, 20, 2, 0, False),        # 64 x 64, SiLU prologue on P (ConvTranspose weight gradient)
     (2, 768, 384, 1, 520, 0, 0, False),      # a Linear over feature-major tokens: H = 1, W = tokens; tiles straddle images (520 = 8 x 65)
     (4, 130, 130, 16, 16, 3, 0, False),      # 64-row tiles x 3, ReLU on P
-    (2, 24, 4, 64, 64, 0, 3, False),         # thin on both sides
+    (2, 24, 4, 64, 64, 0, 3, False),         # thin on both sides: 32 x 32 tile, the waves split 256-pixel tiles
+    (2, 24, 144, 32, 32, 0, 2, True),        # 32 x 128... thin M: 32 x 64 tiles, SiLU + gate on Q
+    (3, 144, 24, 20, 20, 0, 0, False),       # thin C: 64 x 32 tiles; 400 pixels per image (tiles straddle images)
 ])
 def test_wgrad_1x1_bf16(B, M, C, H, W, prop, proq, gate):
     _wgrad_case(B, M, C, C, 0, H, W, 1, 1, 0, 0, H, W, prop, proq, gate, bf16=True)
@@ -332,7 +340,9 @@ def test_wgrad_1x1_bf16(B, M, C, H, W, prop, proq, gate):
     (2, 256, 64, 64, 0, 16, 16, 0),      # (8, 16): 4 m-tiles
     (3, 64, 128, 128, 0, 10, 16, 3),     # (8, 16), H not a multiple of R
     (1, 32, 13, 45, 32, 10, 128, 0),     # 13 of 64 columns used, channel slice of a concat conv
-    (2, 24, 32, 32, 0, 5, 64, 3),        # M below one tile, odd height (last tile has one row)
+    (2, 24, 32, 32, 0, 5, 64, 3),        # 32 x 32 tile (waves split the pixels of 4 x 64 tiles), odd height
+    (2, 64, 24, 24, 0, 9, 128, 0),       # 64 x 32 tiles, two x tiles per row, H not a multiple of 4
+    (2, 32, 64, 64, 0, 8, 64, 3),        # 32 x 64 tiles
 ])
 def test_wgrad_3x3_bf16(B, M, C, CT, c_off, H, W, proq):
     _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False, bf16=True)

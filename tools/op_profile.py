@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--kinds", default="CONV,WGRAD")
     ap.add_argument("--top", type=int, default=400)
+    ap.add_argument("--precision", default="f32")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = EfficientnetUnet(EfficientNetConfig(a.version, a.bands, 4, class_distribution=[.25] * 4)).to(dev).train()
+    model.precision = a.precision
     x = torch.randn(a.batch, a.bands, a.size, a.size, device=dev)
     model(x)  # builds the engine, warms up
     eng = next(iter(model._engines.values()))
@@ -50,22 +52,25 @@ def main():
                 fl = 2.0 * g["M"] * (g["C1"] + g["C2"]) * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
                 gate = int(rec["t"][D.slot("CONV", "GATE1")[1]]) >= 0
                 desc = (f"M={g['M']:5d} C={g['C1']}+{g['C2']} k{g['KH']} s{g['STRIDE']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PRO1']}{g['PRO2']}"
-                        f"{' gate' if gate else ''} {'PC' if var[i] else 'generic'}")
+                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16')[var[i]]}")
+                by = 4.0 * (g["B"] * (g["C1"] + g["C2"]) * g["H"] * g["W"] + g["B"] * g["M"] * g["HO"] * g["WO"])
             elif kind == "WGRAD":
                 g = {k: int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "KH", "HO", "WO", "MODE", "PROP", "PROQ")}
                 fl = 2.0 * g["M"] * g["C"] * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
                 gate = int(rec["t"][D.slot("WGRAD", "GATEP")[1]]) >= 0 or int(rec["t"][D.slot("WGRAD", "GATEQ")[1]]) >= 0
                 desc = (f"M={g['M']:5d} C={g['C']} k{g['KH']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PROP']}{g['PROQ']}"
-                        f"{' gate' if gate else ''} {'PC' if var[i] else 'generic'}")
+                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16')[var[i]]}")
+                by = 4.0 * g["B"] * g["HO"] * g["WO"] * (g["M"] + g["C"])
             else:
-                fl, desc = 0.0, " ".join(str(int(v)) for v in d[:11])
-            rows.append((float(ms[i]), tag, i, kind, desc, fl))
+                fl, desc, by = 0.0, " ".join(str(int(v)) for v in d[:11]), 0.0
+            rows.append((float(ms[i]), tag, i, kind, desc, fl, by))
         rows.sort(reverse=True)
         tot = sum(r[0] for r in rows)
         print(f"== {tag}: {tot:.2f} ms in {len(rows)} stages of kinds {sorted(kinds)}")
-        for t, tg, i, kind, desc, fl in rows[: a.top]:
+        for t, tg, i, kind, desc, fl, by in rows[: a.top]:
             tf = fl / (t * 1e-3) / 1e12 if t > 0 and fl else 0.0
-            print(f"{t:8.3f} ms  {tg} #{i:4d} {kind:14s} {desc:78s} {tf:7.1f} TF/s")
+            gb = by / (t * 1e-3) / 1e9 if t > 0 else 0.0
+            print(f"{t:8.3f} ms  {tg} #{i:4d} {kind:14s} {desc:78s} {tf:7.1f} TF/s {gb:7.0f} GB/s")
 
 
 if __name__ == "__main__":
