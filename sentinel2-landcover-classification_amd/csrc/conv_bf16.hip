@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     const int HWo = p.HO * p.WO;
     const int nchunks = (p.Ctot + KCH - 1) / KCH;
     const int Ctp = nchunks * KCH;
+    // split-K (deep 1x1 convs over few pixels): this workgroup reduces chunks [ch_begin, ch_end) and leaves a partial tile
+    const int ch_begin = blockIdx.y * p.chunks_per_split;
+    const int ch_end = min(nchunks, ch_begin + p.chunks_per_split);
     const int tx = PIX ? 0 : nt % p.tiles_x;
     const int ty = PIX ? 0 : (nt / p.tiles_x) % p.tiles_y;
     const int sb = PIX ? 0 : nt / (p.tiles_x * p.tiles_y);
@@ -230,12 +233,12 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    fetch(0);
+    fetch(ch_begin * KCH);
     __syncthreads();                                             // prologue table complete
-    commit(0);
+    commit(ch_begin * KCH);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) fetch((ch + 1) * KCH);             // in flight during the MFMAs below
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        if (ch + 1 < ch_end) fetch((ch + 1) * KCH);              // in flight during the MFMAs below
         // k-step (tap, s): 16 channels = octets 2 s and 2 s + 1; lane half lh takes octet 2 s + lh
 #pragma unroll
         for (int tap = 0; tap < TT; ++tap) {
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
             }
         }
         __syncthreads();                                         // every wave is done reading the image
-        if (ch + 1 < nchunks) {
+        if (ch + 1 < ch_end) {
             commit((ch + 1) * KCH);
             __syncthreads();
         }
@@ -285,6 +288,19 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
             cval[rn] = (j < R * XW) && (y0 + r < p.HO) && (x0 + xx < p.WO);
             ycol[rn] = (int64_t)sb * p.YC * HWo + (int64_t)(y0 + r) * p.WO + (x0 + xx);
         }
+    }
+    if (p.splits > 1) {   // partial tile -> scratch; bias / residual / accumulate / statistics are applied by the split-K tail kernel
+        float* part = p.scratch + (int64_t)blockIdx.y * p.y_elems;
+#pragma unroll
+        for (int rm = 0; rm < WM; ++rm)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn)
+                    if (gm < p.M && cval[rn]) part[ycol[rn] + (int64_t)gm * HWo] = acc[rm][rn][reg];
+            }
+        return;
     }
     if (SCATTER) {
         // registers 4q .. 4q+3 of a lane are the 2 x 2 output patch (dy, dx) of one output channel co = row / 4
@@ -381,10 +397,24 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }
     p.n_tiles = (int)blocks;
     p.splits = 1;
+    p.chunks_per_split = nchunks;
+    p.y_elems = (int64_t)p.B * p.YC * p.HO * p.WO;
+    if (PIX && !SCATTER && p.scratch && blocks <= 512 && nchunks >= 8) {
+        // Few tiles and a long reduction (the 1x1 convs of the 8 x 8 / 16 x 16 blocks: 160 workgroups each walking 29 - 48
+        // chunks one memory round trip at a time): cut K so that ~1,000 workgroups share the round trips; the partial tiles
+        // are added in a fixed order by the split-K tail (igemm.hip), which also applies bias / statistics.  SCRATCH holds 8.
+        int splits = (int)std::min<int64_t>(8, cdiv64(1024, blocks));
+        splits = std::min(splits, nchunks / 4);
+        if (splits > 1) {
+            p.chunks_per_split = cdiv(nchunks, splits);
+            p.splits = cdiv(nchunks, p.chunks_per_split);
+        }
+    }
     auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE, SCATTER>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splits), dim3(256), lds, st, p);
+    if (p.splits > 1) launch_splitk_reduce(p, st);
     g_s2k_variant = 2;
     return S2K_OK;
 }

@@ -28,6 +28,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// igemm.hip: the split-K tail - Y (+)= sum of the partial tiles in p.scratch (fixed order) + bias + residual, BatchNorm statistics
+void launch_splitk_reduce(const ConvP& p, hipStream_t st);
+
 // igemm_pc.hip: S2K_OK = launched, 1 = not one of its shapes (the caller takes the generic kernels), < 0 = error
 int launch_conv_pc(ConvP& p, hipStream_t st);
 // conv_bf16.hip (bf16-mixed plans only: p.wtb set): same return convention

@@ -574,6 +574,10 @@ __global__ void __launch_bounds__(NTHREADS) splitk_reduce_kernel(const ConvP p) 
     }
 }
 
+void launch_splitk_reduce(const ConvP& p, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64((int64_t)p.B * p.M, 4)), dim3(NTHREADS), 0, st, p);
+}
+
 template <int BMODE, int TT, int WM, int WN, int WVM, int WVN, int KCH, int EPT, int MINW = 2, bool BVEC = false>
 static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk = false) {
     constexpr int BM = WM * WVM * 32, BN = WN * WVN * 32;

@@ -649,8 +649,10 @@ def test_argmax_first_max_wins():
 
 @pytest.mark.parametrize("B,C,M,H,stats,beta,bias", [(32, 1824, 304, 8, True, 0, False), (32, 3072, 512, 8, True, 0, False),
                                                        (8, 1056, 176, 16, False, 1, True), (2, 320, 70, 8, True, 0, True)])
-def test_conv_1x1_split_k(B, C, M, H, stats, beta, bias):
-    """Deep short-N layers: with a SCRATCH region the kernel cuts K into partial tiles summed in a fixed order."""
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv_1x1_split_k(B, C, M, H, stats, beta, bias, bf16):
+    """Deep short-N layers: with a SCRATCH region the kernel cuts K into partial tiles summed in a fixed order (f32 kernels and,
+    with FLAG_BF16, csrc/conv_bf16.hip)."""
     c = Case(21)
     x = c.t("x", (B, C, H, H))
     bnv = c.bnv("bnv", C)
@@ -660,11 +662,16 @@ def test_conv_1x1_split_k(B, C, M, H, stats, beta, bias):
     nrep = D.stats_replicas(M)
     st = c.t("stats", (nrep, 2, M), "zeros", "f64") if stats else None
     scratch = c.t("scratch", (8 * B * M * H * H,), "nan")
-    pre, wp, MP = c.pack(w, M, C, 1, C, 1, 1, 0)
-    c.run("CONV", ["y"] + (["stats"] if stats else []), tol=1e-4, sum0=("stats",), pre=[pre], X1=x, BNV1=bnv, GATE1=None, X2=None,
+    extra = {}
+    if bf16:
+        pre, wp, MP, wp16 = c.pack(w, M, C, 1, C, 1, 1, 0, bf16=True)
+        extra = dict(WTB=wp16, _flags=D.FLAG_BF16, want_variant=2)
+    else:
+        pre, wp, MP = c.pack(w, M, C, 1, C, 1, 1, 0)
+    c.run("CONV", ["y"] + (["stats"] if stats else []), tol=1e-3 if bf16 else 1e-4, sum0=("stats",), pre=[pre], X1=x, BNV1=bnv, GATE1=None, X2=None,
           BNV2=None, WT=wp, BIAS=bs, Y=y, STATS=st, RES=None, SCRATCH=scratch, B=B, C1=C, C2=0, H=H, W=H, M=M, KH=1, KW=1, STRIDE=1,
           PAD_T=0, PAD_L=0, HO=H, WO=H, PRO1=D.PRO_SILU, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=beta, YC=M,
-          NREP=nrep)
+          NREP=nrep, **extra)
 
 
 # ---------------------------------------------------------------------------------------------------
