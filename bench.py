@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the ~5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 # SURVEY §8d, whole-step denominators (fp32): the layer-wise roofline T = sum over layers of max(FLOP / peak, bytes / BW) of
 # efficientnet-unet-b5 13x256x256 is 0.464 ms per tile (pure MFMA 0.418, pure HBM 0.140) = 2,154 tiles/s per GPU; the Prithvi
@@ -392,6 +393,119 @@ def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms:
             "backend": dist.get_backend(), "op": "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
 
 
+def bf16_mixed_leg(model, cfg, x, y, loss_fn, args, dev, f32_tiles_per_s, with_oracle, _lib, D) -> dict:
+    """The bf16-MIXED mode, reported separately (never instead of the f32 headline): the arithmetic class the reference itself
+    trains with (`precision="bf16"`, /root/reference/src/configs/segmentation.py:146,153).  Same network, same weights as the f32
+    model at this point, same batch: dense convs / weight gradients round their MFMA operands to bf16 (csrc/conv_bf16.hip,
+    wgrad_bf16.hip), everything else - accumulation, BatchNorm statistics, loss, master weights, Adam - stays f32.
+    Returns throughput under the headline's timing protocol, the roofline of its dominant kernel and a parity table."""
+    from s2lc_amd.losses import class_mask
+    from s2lc_amd.modules.efficientnet_unet import EfficientnetUnet
+    from s2lc_amd.optim import FlatAdam
+
+    B = x.shape[0]
+    m16 = EfficientnetUnet(cfg)
+    m16.load_state_dict(model.state_dict())
+    m16.to(dev).train()
+    m16.precision = "bf16-mixed"
+    # ---- parity: one training step of both models from identical weights, batch and drop-connect noise -----------------------
+    eng = next(iter(model._engines.values()))
+    noise = torch.rand(eng.n_noise_rows, B, device=dev)
+    res = {}
+    for tag, m in (("f32", model), ("b16", m16)):
+        bufs = m._flat_bufs.clone()
+        nbt = m._flat_nbt.clone()
+        m.drop_connect_noise = noise
+        for p in m.parameters():
+            p.grad = None
+        logits = m(x)
+        loss = loss_fn(logits, y)
+        loss.backward()
+        torch.cuda.synchronize(dev)
+        res[tag] = (logits.detach().clone(), float(loss), m._grad_buffer().detach().clone())
+        m._flat_bufs.copy_(bufs)          # the running statistics of the comparison step are not kept
+        m._flat_nbt.copy_(nbt)
+        m.drop_connect_noise = None
+        for p in m.parameters():
+            p.grad = None
+    (l32, s32, g32), (l16, s16, g16) = res["f32"], res["b16"]
+    d = (l16 - l32).double()
+    parity = {"reference": "this library's f32 path on the same GPU, same weights / batch / drop-connect noise (train-mode BatchNorm)",
+              "logits_max_rel_err": float(d.abs().max() / l32.abs().max()),
+              "logits_rms_rel_err": float(d.pow(2).mean().sqrt() / l32.double().pow(2).mean().sqrt()),
+              "mask_agreement_pct": float((class_mask(l16) == class_mask(l32)).double().mean() * 100.0),
+              "loss_f32": s32, "loss_bf16_mixed": s16, "loss_rel_delta": abs(s16 - s32) / abs(s32),
+              "grad_cosine": float((g16.double() * g32.double()).sum() / (g16.double().norm() * g32.double().norm())),
+              "grad_rel_l2_err": float((g16.double() - g32.double()).norm() / g32.double().norm())}
+    if with_oracle:
+        try:        # against the fp32 CPU oracle (the reference's arithmetic) on two tiles of the batch
+            from oracle import efficientnet_unet_ref as R
+            from oracle import losses_ref
+
+            net = R.build(args.version, x.shape[1], 4)
+            sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            xs, ys, nz = x[:2].cpu(), y[:2].cpu(), noise[:, :2].cpu()
+            with torch.no_grad():
+                ref = R.unet_forward(sd, net, xs, training=True, dc_noise=nz)
+                ref_loss = float(losses_ref.focal(ref, ys, torch.ones(4), 2.0, 0.0, ignore_index=0))
+            bufs = m16._flat_bufs.clone()
+            nbt = m16._flat_nbt.clone()
+            m16.drop_connect_noise = nz.to(dev)
+            with torch.no_grad():
+                got = m16(x[:2])
+                got_loss = float(loss_fn(got, y[:2]))
+            m16._flat_bufs.copy_(bufs)
+            m16._flat_nbt.copy_(nbt)
+            m16.drop_connect_noise = None
+            dd = (got.cpu() - ref).double()
+            parity["vs_fp32_cpu_oracle_bs2"] = {
+                "logits_max_rel_err": float(dd.abs().max() / ref.abs().max()),
+                "logits_rms_rel_err": float(dd.pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()),
+                "mask_agreement_pct": float((got.cpu().argmax(1) == ref.argmax(1)).double().mean() * 100.0),
+                "loss_oracle": ref_loss, "loss_bf16_mixed": got_loss, "loss_rel_delta": abs(got_loss - ref_loss) / abs(ref_loss)}
+        except Exception as e:  # noqa: BLE001
+            parity["vs_fp32_cpu_oracle_bs2"] = {"error": repr(e)[:200]}
+    # ---- throughput: the headline's protocol ------------------------------------------------------------------------------------
+    opt16 = FlatAdam(m16, lr=1.5e-6, weight_decay=0.05)
+
+    def step():
+        opt16.zero_grad()
+        loss = loss_fn(m16(x), y)
+        loss.backward()
+        opt16.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    dt = time_steps(step, args.steps, None, dev)
+    value = B * args.steps / dt
+    e16 = next(iter(m16._engines.values()))
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(e16.plan.logits_shape, device=dev)
+    grads = m16._grad_buffer()
+    dout = torch.randn(e16.plan.logits_shape, device=dev) * 1e-6
+    kinds, mfma = profile_programs(_lib, D, (e16.fwd, e16.bwd), (e16.bases(m16, x, out, noise=noise),
+                                                                 e16.bases(m16, x, None, dout=dout, noise=noise, grads=grads)), st)
+    dom = max(mfma, key=lambda k: mfma[k]["ms"])
+    k = mfma[dom]
+    # the bf16 kernels still read f32 activations: at 32 - 128 flop per byte they sit far left of the bf16 ridge (312 flop per
+    # byte), so their roof is HBM; the MFMA figure is given beside it
+    roof = {"kernel": dom, "bound": "hbm", "achieved": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]), "launches": k["launches"],
+            "avg_launch_ms": round(k["ms"] / k["launches"], 4),
+            "mfma_tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 1), "mfma_peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS,
+            "mfma_frac_of_bf16_peak": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "mfma_kernels": {n: {"ms": round(v["ms"], 3), "launches": v["launches"], "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                 "algorithmic_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                             for n, v in sorted(mfma.items(), key=lambda kv: -kv[1]["ms"])}}
+    return {"workload": "the headline workload with dense convs / weight gradients on bf16 MFMA operands (f32 accumulate, f32 BatchNorm "
+                        "statistics, loss, master weights, Adam); reported separately from the f32 headline",
+            "value": round(value, 2), "unit": "tiles/s", "ms_per_step": round(dt / args.steps * 1e3, 3), "steps": args.steps, "warmup": args.warmup,
+            "dtype": "bf16-mixed", "speedup_vs_f32": round(value / f32_tiles_per_s, 3), "roofline": roof,
+            "kernels": {kk: {"ms": round(v["ms"], 3), "launches": v["launches"]} for kk, v in sorted(kinds.items())}, "parity": parity}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +518,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1 only; the headline is unaffected)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the extra key `bf16_mixed` (N = 1 only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"],
                     help="arithmetic of the HEADLINE run (default f32, the parity path; bf16-mixed is otherwise reported as the extra key `bf16_mixed`)")
     args = ap.parse_args()
@@ -440,7 +555,8 @@ def main() -> None:
 
     ncls = 4
     torch.manual_seed(42)  # identical initial weights on every rank (configs/segmentation.py:103 seed)
-    model = EfficientnetUnet(EfficientNetConfig(args.version, args.bands, ncls, class_distribution=[0.25] * ncls))
+    model_cfg = EfficientNetConfig(args.version, args.bands, ncls, class_distribution=[0.25] * ncls)
+    model = EfficientnetUnet(model_cfg)
     model.to(dev).train()
     model.precision = args.precision
     opt = FlatAdam(model, lr=1.5e-6, weight_decay=0.05)  # BASE_CONFIG lr / weight_decay
@@ -542,6 +658,14 @@ def main() -> None:
             except Exception as e:  # noqa: BLE001   (the measured throughput must still be printed)
                 print(f"bench.py: profile leg failed: {e!r}", file=sys.stderr, flush=True)
                 roofline = {"error": repr(e)[:300]}
+        if world == 1 and args.precision == "f32" and not args.no_bf16 and not args.no_profile:
+            try:        # an extra key must never cost the headline line
+                extra["bf16_mixed"] = bf16_mixed_leg(model, model_cfg, x, y, loss_fn, args, dev, world * B * args.steps / dt,
+                                                     not args.no_cpu_baseline, _lib, D)
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: bf16_mixed failed: {e!r}", file=sys.stderr, flush=True)
+                extra["bf16_mixed"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_prithvi and not args.no_profile:
             del model, opt
             torch.cuda.empty_cache()

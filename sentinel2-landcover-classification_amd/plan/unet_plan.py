@@ -804,8 +804,10 @@ def mark_bf16(p: "_P", bwd) -> None:
     """bf16-MIXED plan (reported separately from the f32 parity path; the reference's own default is precision="bf16",
     configs/segmentation.py:146,153): every dense conv / Linear and every weight gradient MAY round its two MFMA operands to bf16
     (FLAG_BF16; f32 accumulation, f32 BatchNorm statistics, loss, master weights and optimiser).  WEIGHT_PACK writes a bf16 copy
-    of every packed weight into a mirror region behind the f32 packs (BF16_BASE); which stages actually take the bf16 kernels is
-    the native launcher's decision (csrc/conv_bf16.hip, wgrad_bf16.hip: their shape lists), the others stay exact f32."""
+    of every packed weight into a mirror region behind the f32 packs (BF16_BASE).  Flagged are exactly the shapes the bf16 kernels
+    take (plan/bf16.py restates the shape lists of csrc/conv_bf16.hip, wgrad_bf16.hip); every other stage stays exact f32."""
+    from . import bf16 as B16
+
     base = (p.wpack.mark() + 255) // 256 * 256
     for prog in (p.fwd, bwd):
         if prog is None:
@@ -813,11 +815,10 @@ def mark_bf16(p: "_P", bwd) -> None:
         for kind, f in prog.ops:
             if kind == "WEIGHT_PACK":
                 f["BF16_BASE"] = base
-            elif kind == "CONV" and f.get("MODE") in (D.MODE_CONV, D.MODE_CONVT_SCATTER) and isinstance(f.get("WT"), TRef) \
-                    and f["WT"].base == D.BASE["WPACK"]:
+            elif kind == "CONV" and isinstance(f.get("WT"), TRef) and f["WT"].base == D.BASE["WPACK"] and B16.conv_ok(f):
                 f["_flags"] = f.get("_flags", 0) | D.FLAG_BF16
                 f["WTB"] = TRef(D.BASE["WPACK"], base + f["WT"].off // 2, f["WT"].shape, "i16", "bf16:" + f["WT"].name)
-            elif kind == "WGRAD" and f.get("MODE") == D.MODE_CONV:
+            elif kind == "WGRAD" and B16.wgrad_ok(f):
                 f["_flags"] = f.get("_flags", 0) | D.FLAG_BF16
     p.wpack.top = base + (base + 1) // 2 + 256
 
