@@ -33,9 +33,24 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* sink, unsigned lo
     }
 }
 
+// Stream copy: eight independent 16-byte loads in flight per lane before the first store (a loop of one dependent load / store
+// pair per trip measured 4.6 TB/s; the hot path's own adam_kernel sustains 6.1 TB/s, which a "peak" must at least reach),
+// every CU holding 32 waves.
 __global__ void __launch_bounds__(256) copy_peak_kernel(const float4* src, float4* dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    // every workgroup streams 32 KB pieces (8 x 4 KB, contiguous) of the buffer, workgroups interleaved piece by piece
+    const int64_t piece = 8 * 256;
+    for (int64_t base = (int64_t)blockIdx.x * piece; base < n4; base += (int64_t)gridDim.x * piece) {
+        const int64_t i = base + threadIdx.x;
+        if (base + piece <= n4) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + i + k * 256));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f32x4*>(dst + i + k * 256));
+        } else {
+            for (int64_t j = i; j < n4; j += 256) dst[j] = src[j];
+        }
+    }
 }
 
 }  // namespace s2k
@@ -77,7 +92,7 @@ extern "C" int s2k_measure_peaks(void* scratch, size_t scratch_bytes, int waves_
     const int64_t n4 = (int64_t)((scratch_bytes - (1u << 20)) / 2 / 16);
     const float4* src = reinterpret_cast<const float4*>(static_cast<char*>(scratch) + (1u << 20));
     float4* dst = const_cast<float4*>(src) + n4;
-    const int cblocks = (int)std::min<int64_t>(cdiv64(n4, 256), (int64_t)cus * 16);
+    const int cblocks = (int)std::min<int64_t>(cdiv64(n4, 256 * 8), (int64_t)cus * 8);     // 32 waves per CU, >= 8 trips of 8 loads each
     hipLaunchKernelGGL(copy_peak_kernel, dim3(cblocks), dim3(256), 0, st, src, dst, n4);
     hipEventRecord(e0, st);
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(copy_peak_kernel, dim3(cblocks), dim3(256), 0, st, src, dst, n4);

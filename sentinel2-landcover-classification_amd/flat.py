@@ -55,6 +55,16 @@ class FlatParamsMixin:
         self._flat_params, self._flat_bufs, self._flat_nbt = flat, bufs, nbt
         self._flat_grads = None
         self._engines = {}
+        # torch.compile boundary (compile_ops.py): the leaf through which autograd reaches the opaque backward op, and the handle
+        # under which the custom ops find this module
+        from . import compile_ops
+
+        self._compile_anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
+        self._compile_handle = compile_ops.register(self)
+
+    @property
+    def _compile_trainable(self) -> bool:
+        return any(p.requires_grad for p in self.parameters())
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)

@@ -24,6 +24,7 @@ from torch import nn
 
 from ..plan import opdefs as D
 from ..plan.unet_plan import BlockSpec, UnetSpec, build_layout, plan_unet
+from ..compile_ops import compiled_unet_forward
 from ..flat import FlatParamsMixin
 
 _VERSION_TABLE = {  # (width, depth, dropout)   efficientnet_unet.py:35-45
@@ -307,8 +308,11 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
             self._engines.clear()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        from ..engine import run_unet
-
         if x.dim() != 4 or x.shape[1] != self.config.in_channels:
             raise ValueError(f"expected [B,{self.config.in_channels},H,W], got {tuple(x.shape)}")
+        if torch.compiler.is_compiling():
+            # the reference compiles `self.net` unless --type debug (train_segmentation.py:70-75): Dynamo sees ONE opaque node
+            return compiled_unet_forward(self, x)
+        from ..engine import run_unet
+
         return run_unet(self, x)

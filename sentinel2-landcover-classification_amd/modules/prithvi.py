@@ -185,9 +185,13 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
             raise RuntimeError("this MaskedAutoencoderViT was loaded without its decoder (load_prithvi(no_decoder=True))")
 
     def forward(self, imgs: torch.Tensor, mask_ratio: float = 0.75):
+        self._check(imgs)
+        if torch.compiler.is_compiling():      # the reference compiles `self.net` (train_mae_prithvi.py:59-64): one opaque node
+            from ..compile_ops import compiled_mae_forward
+
+            return compiled_mae_forward(self, imgs, mask_ratio)
         from ..vit_engine import run_vit
 
-        self._check(imgs)
         out = run_vit(self, imgs, dict(noise=self.masking_noise), mask_ratio=mask_ratio)
         return out["loss"].reshape(()), out["pred"], out["mask"]
 

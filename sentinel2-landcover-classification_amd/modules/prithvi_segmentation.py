@@ -122,4 +122,8 @@ class PrithviSegmentationNet(FlatParamsMixin, nn.Module):
         want = (m.in_chans, m.num_frames, m.img_size, m.img_size)
         if x.dim() != 5 or tuple(x.shape[1:]) != want:
             raise ValueError(f"expected [B,{want[0]},{want[1]},{want[2]},{want[3]}] (B,C,T,H,W), got {tuple(x.shape)}")
+        if torch.compiler.is_compiling():
+            from ..compile_ops import compiled_seg_forward
+
+            return compiled_seg_forward(self, x)
         return run_vit(self, x, dict(noise=self.masking_noise, drop_u=self.dropout_noise))["logits"]

@@ -26,11 +26,23 @@ class FlatAdam(torch.optim.Optimizer):
         self.m = None
         self.v = None
         self._plist = None
+        self._resumed_without_first = False      # a state dict written before per-parameter steps existed: every active parameter began at step 1
+        self._first = {}            # parameter index -> global step at which it first held a gradient (torch keeps state['step'] per parameter)
         super().__init__([p for p in module.parameters()], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    def add_param_group(self, param_group) -> None:
+        """One group: the fused step runs over contiguous ranges of ONE flat buffer with one set of hyper-parameters (the reference
+        configures `torch.optim.Adam(net.parameters(), lr, weight_decay)`, a single group: train_segmentation.py:109-115)."""
+        if len(self.param_groups) >= 1:
+            raise ValueError("FlatAdam holds one parameter group (one lr / betas / eps / weight_decay for the module's flat buffer); "
+                             "per-group hyper-parameters are not supported - use torch.optim.Adam on module.parameters() for that")
+        super().add_param_group(param_group)
 
     # -- which floats take part --------------------------------------------------------------------------
     def _ranges(self):
-        """Contiguous float ranges of the flat buffer whose parameters currently hold a gradient."""
+        """[(first float, end float, local step)]: contiguous ranges of the flat buffer whose parameters currently hold a gradient
+        and share a step count.  Like torch.optim.Adam (state['step'] per parameter), a parameter's bias correction counts the
+        steps IT has taken: a backbone unfrozen after N steps starts at step 1, not N + 1."""
         mod = self.module
         if self._plist is None:
             named = dict(mod.named_parameters())
@@ -39,18 +51,23 @@ class FlatAdam(torch.optim.Optimizer):
             # to the tensor in front of them, so neighbouring tensors form one contiguous range
             self._plist = [(named[name], off, (named[name].numel() + 63) // 64 * 64, name in skip)
                            for name, (off, shape) in mod._layout.params.items()]
-        ranges, start, end = [], None, None
-        for p, off, n, skipped in self._plist:
+        ranges, start, end, cur = [], None, None, None
+        for i, (p, off, n, skipped) in enumerate(self._plist):
             if skipped or not p.requires_grad or p.grad is None:
                 if start is not None:
-                    ranges.append((start, end))
+                    ranges.append((start, end, cur))
                     start = None
                 continue
+            local = self.step_count - self._first.setdefault(i, 1 if self._resumed_without_first else self.step_count) + 1
+            if start is not None and local != cur:
+                ranges.append((start, end, cur))
+                start = None
             if start is None:
-                start = off
+                start, cur = off, local
             end = off + n
         if start is not None:
-            ranges.append((start, end))
+            ranges.append((start, end, cur))
+        self._resumed_without_first = False
         return ranges
 
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -77,16 +94,17 @@ class FlatAdam(torch.optim.Optimizer):
         st = torch.cuda.current_stream(p.device).cuda_stream
         L = _lib.lib()
         with torch.cuda.device(p.device):
-            for a, b in self._ranges():
+            for a, b, local_step in self._ranges():
                 _lib.check(L.s2k_adam_step(p.data_ptr() + 4 * a, g.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
                                            self.v.data_ptr() + 4 * a, b - a, float(grp["lr"]), float(b1), float(b2),
-                                           float(grp["eps"]), float(grp["weight_decay"]), self.step_count, st))
+                                           float(grp["eps"]), float(grp["weight_decay"]), local_step, st))
         return loss
 
     # -- checkpointing -------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
-        return {"state": {"step": self.step_count, "exp_avg": None if self.m is None else self.m.detach().clone(),
+        return {"state": {"step": self.step_count, "first_step": dict(self._first),
+                          "exp_avg": None if self.m is None else self.m.detach().clone(),
                           "exp_avg_sq": None if self.v is None else self.v.detach().clone()},
                 "param_groups": groups, "layout_floats": int(self.module._flat_params.numel())}
 
@@ -95,6 +113,8 @@ class FlatAdam(torch.optim.Optimizer):
             raise ValueError("optimizer state belongs to a module with a different flat parameter layout")
         st = state["state"]
         self.step_count = int(st["step"])
+        self._first = {int(k): int(v) for k, v in st.get("first_step", {}).items()}
+        self._resumed_without_first = "first_step" not in st
         dev = self.module._flat_params.device
         self.m = None if st["exp_avg"] is None else st["exp_avg"].to(device=dev, dtype=torch.float32).clone()
         self.v = None if st["exp_avg_sq"] is None else st["exp_avg_sq"].to(device=dev, dtype=torch.float32).clone()

@@ -211,6 +211,26 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   DW2[c][j] += sum_b DGP[b][c]*HS[b][j];  DB2 += sum_b DGP;  DW1[j][c] += sum_b DHP[b][j]*POOL[b][c];  DB1 += sum_b DHP
     "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),
 }
+# Tensor slots a stage WRITES (everything else it only reads).  Used by the planner's side-stream hazard pass (unet_plan.finish_plan:
+# a main-stream stage that writes what an outstanding side-stream stage still reads must wait for the side stream first); a kind
+# missing here is treated as writing every tensor it names.
+WRITES: dict[str, tuple[str, ...]] = {
+    "MEMSET": ("DST",), "AXPY": ("Y",), "WEIGHT_PACK": ("DST",), "CONV": ("Y", "STATS", "SCRATCH"), "WGRAD": ("WGS",),
+    "WGRAD_FINALIZE": ("GRADS",), "DWCONV_FWD": ("Y", "STATS", "BNV", "FRM", "FRV"), "DWCONV_DGRAD": ("G", "STATS2"), "DWCONV_WGRAD": ("DW",),
+    "BN_FINALIZE": ("RM", "RV", "BNV"), "SE_POOL": ("POOL", "BNV", "FRM", "FRV"), "SE_FC": ("HPRE", "GATE"),
+    "SE_FC_BWD": ("DGATE", "HPRE", "DW1", "DB1", "DW2", "DB2", "DPOOL", "HS"), "SE_BWD_REDUCE": ("DGATE",),
+    "BN_BWD_REDUCE": ("GOUT", "STATS2"), "BN_BWD_FINALIZE": ("DGAMMA", "DBETA", "COEF"), "BN_BWD_APPLY": ("DY", "DGAMMA", "DBETA"),
+    "BN_RESIDUAL": ("XOUT", "BNV", "FRM", "FRV"), "CHANNEL_SUM": ("OUT",), "LOSS_FWD": ("LOSS", "ACC"), "LOSS_BWD": ("DLOGITS",),
+    "ARGMAX": ("MASK",), "CHAN_LN_FWD": ("Y", "MR"), "CHAN_LN_BWD": ("DX", "DGAMMA", "DBETA"), "ACT_BWD": ("G",), "ACT_FWD": ("Y",),
+    "ATTN_FWD": ("O", "LSE"), "ATTN_BWD": ("DQKV", "DELTA"), "MAE_MASK_INDEX": ("IDS_RESTORE", "MASK", "ENC_IDX", "DEC_IDX"),
+    "IDS_TO_DEC_IDX": ("DEC_IDX",), "TOKEN_GATHER": ("OUT",), "TOKEN_SCATTER": ("DIN", "DFILL"), "PATCHIFY": ("X", "OUT"),
+    "MAE_LOSS_FWD": ("LOSS", "ACC"), "MAE_LOSS_BWD": ("DPRED",), "TRANSPOSE_CL": ("Y",), "CONFUSION": ("HIST",), "DROP_GATE": ("GATE",),
+    "TILE_PREP": ("X", "Y"), "SE_BN_SUMS": ("DGATE", "PS"), "SE_BN_COMBINE": ("STATS2",), "SPACE_TO_DEPTH": ("Y",), "UPSAMPLE_ZERO": ("Y",),
+    "SE_FC_WGRAD": ("DW1", "DB1", "DW2", "DB2"),
+}
+for _k, _w in WRITES.items():
+    assert _k in OPS and all(x in OPS[_k][0] for x in _w), _k
+
 KIND = {name: i + 1 for i, name in enumerate(OPS)}
 NAME_OF = {i: name for name, i in KIND.items()}
 

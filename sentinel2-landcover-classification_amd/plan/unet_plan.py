@@ -788,6 +788,7 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
                 f["_flags"] = D.FLAG_SIDE
             elif kind == "WGRAD_FINALIZE":
                 f["_flags"] = D.FLAG_JOIN
+        side_stream_hazards(p.bwd)
         n_before = len(p.bwd.ops)
         pack_op(p.bwd, p.pack_rows["bwd"])
         if len(p.bwd.ops) > n_before:   # WEIGHT_PACK went in front
@@ -798,6 +799,45 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
     if getattr(p, "bf16", False):
         mark_bf16(p, bwd)
     return segments, bwd
+
+
+def side_stream_hazards(prog: Program) -> int:
+    """Write-after-read hazards between the two streams of the executor: a side-stream stage (weight / bias gradients) is only
+    ordered AFTER the main-stream work issued before it (the fork event); nothing makes later main-stream work wait for it until
+    the next FLAG_JOIN.  That is fine as long as nobody overwrites what it reads - true for the U-Net, whose gradients each have
+    a buffer of their own, NOT for the transformer blocks, whose residual-stream gradient is accumulated IN PLACE (the LayerNorm
+    backward adds into the buffer that the fc2 / proj weight and bias gradients are still reading on the side stream: a race
+    that showed up as a run-order-dependent 1e-4 error of the MAE gradients).  Every main-stream stage that writes a byte range an
+    outstanding side-stream stage reads gets FLAG_JOIN (the executor then waits for the side stream first).  Returns the number
+    of joins added."""
+    def ranges(f, names):
+        out = []
+        for k in names:
+            v = f.get(k)
+            if isinstance(v, TRef):
+                out.append((v.base, v.off, v.off + v.nbytes))
+        return out
+
+    pending: list = []          # byte ranges read by side-stream stages since the last join
+    added = 0
+    for kind, f in prog.ops:
+        flags = f.get("_flags", 0)
+        t_names = D.OPS[kind][0]
+        writes = D.WRITES.get(kind, tuple(t_names))
+        if flags & D.FLAG_SIDE:
+            pending.extend(ranges(f, [k for k in t_names if k not in writes]))
+            continue
+        if flags & D.FLAG_JOIN:
+            pending.clear()
+            continue
+        if pending:
+            for (b, lo, hi) in ranges(f, writes):
+                if any(b == pb and lo < phi and plo < hi for (pb, plo, phi) in pending):
+                    f["_flags"] = flags | D.FLAG_JOIN
+                    pending.clear()
+                    added += 1
+                    break
+    return added
 
 
 def mark_bf16(p: "_P", bwd) -> None:

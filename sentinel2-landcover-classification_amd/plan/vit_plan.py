@@ -98,6 +98,10 @@ class VitPlan:
     douts: dict | None = None   # several differentiable outputs: name -> TRef in a packed DOUT buffer (None: `dout_shape` only)
     dout_bytes: int = 0
     want_dx: bool = False       # the backward program also writes the gradient w.r.t. the images into the DX base
+    # name of a differentiable output -> [i0, i1): the backward stages that only move ITS upstream gradient into place; when the
+    # caller has no gradient for that output (the trainer differentiates the loss only) the executor skips them and passes a
+    # DOUT buffer without that region
+    optional_dout_ops: dict | None = None
 
 
 # ---- layouts (reference registration order) ---------------------------------------------
@@ -416,9 +420,16 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
 
     p.tape.append(backward)
     segments, bwd = finish_plan(p, layout, training, bucket_floats)
+    optional = None
+    if bwd is not None:
+        # the two stages that bring a caller's gradient of `pred` into the feature-major layout and add it to d loss / d pred:
+        # 5 HBM passes over a pred-sized tensor of zeros per step when the trainer differentiates only the loss
+        i0 = next(i for i, (k, f_) in enumerate(bwd.ops) if k == "TRANSPOSE_CL" and isinstance(f_.get("X"), TRef) and f_["X"].ref == d_pred.ref)
+        assert bwd.ops[i0 + 1][0] == "AXPY"
+        optional = {"pred": (i0, i0 + 2)}
     return VitPlan(s, B, training, p.fwd, bwd, p.ws.mark(), p.aux.mark(), p.blob, layout, segments, outs, cur[0],
                    {"noise": noise}, B * Lp * 4, (1,), p.tensors, p.wpack.mark(), 0, x_shape,
-                   douts={"loss": d_loss, "pred": d_pred}, dout_bytes=256 + B * Lp * PD * 4, want_dx=want_dx)
+                   douts={"loss": d_loss, "pred": d_pred}, dout_bytes=256 + B * Lp * PD * 4, want_dx=want_dx, optional_dout_ops=optional)
 
 
 def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20,

@@ -48,7 +48,7 @@ def load_prithvi(num_frames: int, no_decoder: bool = True, weights: str | None =
         raise FileNotFoundError(f"{path}: the Prithvi-100M checkpoint is not part of this repository "
                                 "(use load_untrained_prithvi for random initialisation)")
     model = MaskedAutoencoderViT(**_prithvi_model_args(num_frames), _decoder=not no_decoder, _flat=False)
-    state = torch.load(path, map_location="cpu")
+    state = torch.load(path, map_location="cpu", weights_only=True)      # a plain state dict of tensors: no pickle execution
     drop = ["pos_embed", "decoder_pos_embed"]
     if no_decoder:
         drop += ["decoder_embed", "mask_token", "decoder_blocks", "decoder_norm", "decoder_pred"]
@@ -76,10 +76,20 @@ def strip_trainer_prefix(state: dict) -> dict:
     return dict(state)
 
 
-def load_reference_checkpoint(model: nn.Module, path, strict: bool = True):
+def load_reference_checkpoint(model: nn.Module, path, strict: bool = True, trust_pickle: bool = False):
     """Load a checkpoint saved by the reference (`ModelCheckpoint`, train_segmentation.py:247-255 — a dict with
     `state_dict`) or a bare state dict into one of this package's modules; accepts the `net._orig_mod.` / `net.` prefixes.
-    The flat parameter buffer is kept (values are copied into the existing views)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False) if not isinstance(path, dict) else path
+    The flat parameter buffer is kept (values are copied into the existing views).  Files are read with `weights_only=True`;
+    `trust_pickle=True` allows full unpickling (arbitrary code execution: only for files you trust)."""
+    if isinstance(path, dict):
+        ck = path
+    else:
+        try:        # tensors / containers only: no arbitrary pickle execution
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:  # noqa: BLE001
+            if not trust_pickle:
+                raise RuntimeError(f"{path}: the checkpoint holds objects beyond tensors and plain containers (a Lightning checkpoint "
+                                   "pickles its hyper-parameters); pass trust_pickle=True to unpickle a file you trust") from e
+            ck = torch.load(path, map_location="cpu", weights_only=False)
     state = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
     return model.load_state_dict(strip_trainer_prefix(state), strict=strict)

@@ -37,7 +37,7 @@ class VitEngine:
     def aux(self) -> torch.Tensor:
         return self.resident.aux
 
-    def bases(self, module, x, out, noise, dout=None, grads=None, space: Workspace | None = None, dx=None) -> _lib.Bases:
+    def bases(self, module, x, out, noise, dout=None, grads=None, space: Workspace | None = None, dx=None, dout_need: int | None = None) -> _lib.Bases:
         space = space or self.resident
         b = _lib.Bases()
         b.set("WS", space.ws).set("AUX", space.aux).set("CONST", self.const).set("WPACK", self.wpack)
@@ -48,6 +48,8 @@ class VitEngine:
         if dout is not None:
             plan = self.plan
             need = plan.dout_bytes if plan.dout_bytes else 4 * int(torch.Size(plan.dout_shape).numel())
+            if dout_need is not None:
+                need = dout_need       # the stages reading the rest of the packed buffer are skipped by the caller
             if dout.numel() * dout.element_size() < need:      # the backward program reads DOUT unchecked on the device
                 raise ValueError(f"DOUT holds {dout.numel() * dout.element_size()} bytes, the backward program reads {need}")
             b.set("DOUT", dout)
@@ -88,58 +90,84 @@ class _VitFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dprimary, *unused):
-        module, eng, lease = ctx.module, ctx.eng, ctx.lease
-        if lease.space is None:
-            raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
         (x,) = ctx.saved_tensors
-        plan = eng.plan
-        scale = getattr(module, "_grad_scale", 1.0)
-        if plan.douts:        # several differentiable outputs: one packed buffer, absent gradients as zeros
-            buf = torch.zeros(plan.dout_bytes + 256, dtype=torch.uint8, device=x.device)
-            for name, g in zip(ctx.names, (dprimary,) + tuple(unused)):
-                if g is not None and name in plan.douts:
-                    t = plan.douts[name]
-                    dst = buf[t.off:t.off + t.nbytes].view(torch.float32).view(t.shape)
-                    dst.copy_(g.reshape(t.shape))
-                    if scale != 1.0:
-                        dst.mul_(scale)
-            dout = buf
-        else:
-            dout = dprimary.contiguous().reshape(plan.dout_shape).to(torch.float32)
-            if scale != 1.0:
-                dout = dout * scale
-        live = module._grads_live()
-        accumulate = live and not getattr(module, "_overwrite_next", False)
-        module._overwrite_next = False
-        grads = module._grad_buffer() if not accumulate else module._grad_scratch()
-        grads.zero_()
-        dx = torch.empty_like(x) if plan.want_dx else None
-        bases = eng.bases(module, x, ctx.out, ctx.noise, dout=dout, grads=grads, space=lease.space, dx=dx)
-        hook = getattr(module, "_bwd_segment_hook", None)
-        st = _stream(x.device)
-        with torch.cuda.device(x.device):
-            if hook is None:
-                _lib.run(eng.bwd, bases, st)
-            else:
-                if accumulate:
-                    raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
-                _note_bucket_reduction(module)
-                lo_min = eng.plan.trainable_lo
-                for (a, b, lo, hi) in eng.bwd_marks:
-                    _lib.run(eng.bwd, bases, st, a, b)
-                    hook(max(lo, lo_min), hi, grads)
-        lease.release()
-        if accumulate:
-            module._grad_buffer().add_(grads)
-        if not live:
-            module._publish_grads(module._no_grad_params)
-        if dx is not None and scale != 1.0:
-            dx.mul_(1.0 / scale)       # the data-parallel 1/world applies to parameter gradients only (engine.py)
+        dx = vit_backward_raw(ctx.module, ctx.eng, ctx.lease, ctx.noise, ctx.out, x, dict(zip(ctx.names, (dprimary,) + tuple(unused))))
         return dx, None, None, None, None, None
 
 
-def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = None) -> dict:
-    """Runs the module's forward program; returns {output name: tensor}.  `injected`: noise name -> tensor or None."""
+def vit_backward_raw(module, eng, lease, noise, out, x, gouts: dict):
+    """The backward program of a VitEngine forward: `gouts` = upstream gradients by output name (None = absent).  Parameter
+    gradients go into the module's flat gradient buffer; returns dX or None.  Shared by the autograd node above and the
+    torch.compile custom ops (compile_ops.py)."""
+    if lease.space is None:
+        raise RuntimeError("backward through the same forward a second time: the saved activations have been released")
+    plan = eng.plan
+    primary = next(iter(gouts))
+    scale = getattr(module, "_grad_scale", 1.0)
+    skip, dout_need = [], None
+    if plan.douts:        # several differentiable outputs: one packed buffer, absent gradients as zeros
+        absent = [n for n in (plan.optional_dout_ops or {}) if gouts.get(n) is None]
+        if absent and len(absent) == len(plan.optional_dout_ops) and all(t.off >= 256 for n, t in plan.douts.items() if n in absent):
+            # nobody differentiates through these outputs (the reference's trainer uses the loss only): no zero-filled buffer of
+            # their size, and the stages that would move it are skipped
+            skip = sorted(plan.optional_dout_ops[n] for n in absent)
+            dout_need = 256
+        buf = torch.zeros((dout_need or plan.dout_bytes) + 256, dtype=torch.uint8, device=x.device)
+        for name, g in gouts.items():
+            if g is not None and name in plan.douts:
+                t = plan.douts[name]
+                dst = buf[t.off:t.off + t.nbytes].view(torch.float32).view(t.shape)
+                dst.copy_(g.reshape(t.shape))
+                if scale != 1.0:
+                    dst.mul_(scale)
+        dout = buf
+    else:
+        dout = gouts[primary].contiguous().reshape(plan.dout_shape).to(torch.float32)
+        if scale != 1.0:
+            dout = dout * scale
+    live = module._grads_live()
+    accumulate = live and not getattr(module, "_overwrite_next", False)
+    module._overwrite_next = False
+    grads = module._grad_buffer() if not accumulate else module._grad_scratch()
+    grads.zero_()
+    dx = torch.empty_like(x) if plan.want_dx else None
+    bases = eng.bases(module, x, out, noise, dout=dout, grads=grads, space=lease.space, dx=dx, dout_need=dout_need)
+    hook = getattr(module, "_bwd_segment_hook", None)
+    st = _stream(x.device)
+
+    def run_range(a, b):        # stages [a, b) of the backward program minus the skipped ranges
+        for (s0, s1) in skip:
+            if a < s1 and s0 < b:
+                if a < s0:
+                    _lib.run(eng.bwd, bases, st, a, s0)
+                a = max(a, s1)
+        if a < b:
+            _lib.run(eng.bwd, bases, st, a, b)
+
+    with torch.cuda.device(x.device):
+        if hook is None:
+            run_range(0, len(eng.bwd))
+        else:
+            if accumulate:
+                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
+            _note_bucket_reduction(module)
+            lo_min = eng.plan.trainable_lo
+            for (a, b, lo, hi) in eng.bwd_marks:
+                run_range(a, b)
+                hook(max(lo, lo_min), hi, grads)
+    lease.release()
+    if accumulate:
+        module._grad_buffer().add_(grads)
+    if not live:
+        module._publish_grads(module._no_grad_params)
+    if dx is not None and scale != 1.0:
+        dx.mul_(1.0 / scale)       # the data-parallel 1/world applies to parameter gradients only (engine.py)
+    return dx
+
+
+def vit_prepare(module, x: torch.Tensor, injected: dict, mask_ratio: float | None, trainable: bool, want_dx: bool, grad_enabled: bool):
+    """(engine, noise buffer, primary output name, want_grad) for one forward: plan selection exactly as the reference's modules
+    behave under torch autograd (shared by run_vit and the torch.compile custom ops)."""
     if not x.is_cuda:
         raise RuntimeError(f"{type(module).__name__} runs on the HIP engine only: move the module and the input to the GPU "
                            "(there is no CPU fallback; the CPU restatement lives under oracle/ for tests)")
@@ -148,15 +176,12 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
         raise TypeError("the parity path computes in fp32; got " + str(x.dtype))
     if module._flat_params.device != x.device:
         raise RuntimeError("module and input are on different devices")
-    x = x.contiguous()
     B = x.shape[0]
-    trainable = any(p.requires_grad for p in module.parameters())
     is_seg = mask_ratio is None
     # the segmentation head has BatchNorm / Dropout2d: its plan follows module.training (train() plans always carry the
     # backward program, eval() plans only when autograd wants one); the MAE has neither, so its plan carries a backward
     # program iff a gradient is wanted
-    want_dx = torch.is_grad_enabled() and x.requires_grad
-    want_grad = torch.is_grad_enabled() and (trainable or want_dx)
+    want_grad = grad_enabled and (trainable or want_dx)
     training = module.training if is_seg else want_grad
     want_bwd = (training or want_grad) if is_seg else want_grad
     mr = 0.0 if is_seg else float(mask_ratio)
@@ -179,7 +204,16 @@ def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = 
             dst.copy_(src.to(device=x.device, dtype=torch.float32).reshape(-1))
     if is_seg and training:
         module._flat_nbt += 1
-    primary = "logits" if is_seg else "loss"
+    return eng, noise, ("logits" if is_seg else "loss"), want_grad
+
+
+def run_vit(module, x: torch.Tensor, injected: dict, mask_ratio: float | None = None) -> dict:
+    """Runs the module's forward program; returns {output name: tensor}.  `injected`: noise name -> tensor or None."""
+    x = x.contiguous()
+    trainable = any(p.requires_grad for p in module.parameters())
+    want_dx = torch.is_grad_enabled() and x.requires_grad
+    eng, noise, primary, want_grad = vit_prepare(module, x, injected, mask_ratio, trainable, want_dx, torch.is_grad_enabled())
+    plan = eng.plan
     if want_grad:
         anchor = module._anchor(x.device)
         outs = _VitFunction.apply(x, anchor, module, eng, noise, primary)

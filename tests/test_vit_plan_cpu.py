@@ -248,3 +248,45 @@ def test_mae_input_gradient_program_float64():
     dx = m.view((D.BASE["DX"] << 56), tuple(x.shape))
     assert (dx - x64.grad).abs().max().item() <= 1e-6 * x64.grad.abs().max().item()
     _check_grads(plan, fview(bases, "GRADS", True), sd64, 1e-5)
+
+
+def test_no_main_stream_stage_overwrites_what_a_side_stream_stage_still_reads():
+    """The executor orders a side-stream stage (weight / bias gradients) after earlier main-stream work only; a later main-stream
+    stage that writes what it reads must carry FLAG_JOIN.  The transformer blocks accumulate the residual-stream gradient in place
+    (CHAN_LN_BWD adds into the buffer the fc2 / proj weight gradients read): check the invariant on the final programs of every
+    planner (U-Net: no such write exists, so no join is added either)."""
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+    from s2lc_amd.plan import opdefs as D
+    from s2lc_amd.plan.program import TRef
+    from tests.helpers import PRITHVI_SEG_SMALL, PRITHVI_SMALL
+
+    def check(prog):
+        pending, joins = [], 0
+        for i, (kind, f) in enumerate(prog.ops):
+            flags = f.get("_flags", 0)
+            names = D.OPS[kind][0]
+            writes = D.WRITES.get(kind, tuple(names))
+            rng = lambda ks: [(v.base, v.off, v.off + v.nbytes) for k in ks if isinstance(v := f.get(k), TRef)]  # noqa: E731
+            if flags & D.FLAG_SIDE:
+                pending += rng([k for k in names if k not in writes])
+                continue
+            if flags & D.FLAG_JOIN:
+                joins += 1
+                pending = []
+                continue
+            for (b, lo, hi) in rng(writes):
+                assert not any(b == pb and lo < phi and plo < hi for (pb, plo, phi) in pending), (i, kind, f.get("DX") or f.get("Y"))
+        return joins
+
+    mae = MaskedAutoencoderViT(**PRITHVI_SMALL)
+    j = check(mae._make_plan(2, True, 0.75, True).bwd)
+    assert j >= 2 * (PRITHVI_SMALL["depth"] + PRITHVI_SMALL["decoder_depth"])       # both LayerNorm backwards of every block wait
+    bb = MaskedAutoencoderViT(**PRITHVI_SEG_SMALL, _decoder=False, _flat=False)
+    cfg = PrithviSegmentationNetConfig(num_frames=1, num_classes=4, fcn_out_channels=8, fcn_num_convs=1, fcn_dropout=0.1,
+                                       frozen_backbone=False, embed_dim=32, patch_height=4, patch_width=4)
+    check(PrithviSegmentationNet(cfg, backbone=bb)._make_plan(2, True, 0.0, True).bwd)
+    unet = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.25] * 4))
+    plan = unet._make_plan(2, 64, 64, True)
+    assert check(plan.bwd) == sum(1 for k, _ in plan.bwd.ops if k == "WGRAD_FINALIZE")      # nothing added for the U-Net
