@@ -484,9 +484,14 @@ def op_chan_ln_bwd(m: Mem, o):
     dx = rstd * (g - g.mean(1, keepdim=True) - xhat * (g * xhat).mean(1, keepdim=True))
     dst = m.view(o["DX"], (B, C, HW))
     if o["ACCUM"]:
-        dst.add_(dx)
+        if o.get("DXIN", -1) >= 0:
+            dst.copy_(m.view(o["DXIN"], (B, C, HW)) + dx)
+        else:
+            dst.add_(dx)
     else:
         dst.copy_(dx)
+    if o.get("DSUM", -1) >= 0:
+        m.view(o["DSUM"], (C,)).add_(dst.double().sum((0, 2)).to(m.fdtype))
     if o["DGAMMA"] >= 0:
         m.view(o["DGAMMA"], (C,)).add_((dy * xhat).double().sum((0, 2)).to(m.fdtype))
         m.view(o["DBETA"], (C,)).add_(dy.double().sum((0, 2)).to(m.fdtype))

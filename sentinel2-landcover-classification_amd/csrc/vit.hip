@@ -33,6 +33,8 @@ constexpr int LN_NW = 16;   // waves per workgroup: the channel loop of a tile i
 struct LnP {
     const float *x, *gamma, *beta, *dy, *mr_in;
     float *y, *mr, *dx, *dgamma, *dbeta;
+    const float* dxin;      // backward, ACCUM: DX = DXIN + ... (out of place) when given
+    float* dsum;            // backward: DSUM[c] += sum of the new DX values (a bias gradient), or null
     int B, C, HW, tiles_per_b, accum;
     float eps;
 };
@@ -115,10 +117,12 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     float* pg = lsm;              // [C] dgamma partial
     float* pb = lsm + p.C;        // [C] dbeta partial
-    float(*red)[64][2] = reinterpret_cast<float(*)[64][2]>(lsm + 2 * p.C);   // [LN_NW][64][2]
+    float* pd = lsm + 2 * p.C;    // [C] sum of the new DX values (DSUM)
+    float(*red)[64][2] = reinterpret_cast<float(*)[64][2]>(lsm + 3 * p.C);   // [LN_NW][64][2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool want_p = p.dgamma != nullptr;
-    for (int c = threadIdx.x; c < 2 * p.C; c += 64 * LN_NW) lsm[c] = 0.0f;
+    const bool want_p = p.dgamma != nullptr, want_d = p.dsum != nullptr;
+    const float* acc_src = p.dxin ? p.dxin : p.dx;
+    for (int c = threadIdx.x; c < 3 * p.C; c += 64 * LN_NW) lsm[c] = 0.0f;
     __syncthreads();
     const int64_t ntiles = (int64_t)p.B * p.tiles_per_b;
     const float invC = 1.0f / p.C;
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
                 const int64_t off = base + (int64_t)min(c0 + LN_NW * u, p.C - 1) * p.HW;
                 dv[u] = p.dy[off];
                 xv[u] = p.x[off];
-                ov[u] = p.accum ? p.dx[off] : 0.0f;      // kernel-uniform condition
+                ov[u] = p.accum ? acc_src[off] : 0.0f;   // kernel-uniform condition
             }
 #pragma unroll
             for (int u = 0; u < LN_U; ++u) {
@@ -185,7 +189,12 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
                 if (c < p.C) {      // wave-uniform
                     const float xh = (xv[u] - mean) * rstd;
                     const float g = dv[u] * p.gamma[c];
-                    if (ok) p.dx[base + (int64_t)c * p.HW] = rstd * (g - m1 - xh * m2) + ov[u];
+                    const float nv = rstd * (g - m1 - xh * m2) + ov[u];
+                    if (ok) p.dx[base + (int64_t)c * p.HW] = nv;
+                    if (want_d) {
+                        const float sd = wave_sum_hi(ok ? nv : 0.0f);
+                        if (lane == 63) pd[c] += sd;
+                    }
                     if (want_p) {
                         const float a = wave_sum_hi(dv[u] * xh), bb = wave_sum_hi(dv[u]);
                         if (lane == 63) { pg[c] += a; pb[c] += bb; }
@@ -195,11 +204,14 @@ __global__ void __launch_bounds__(64 * LN_NW) chan_ln_bwd_kernel(const LnP p) {
         }
         __syncthreads();
     }
-    if (want_p) {
+    if (want_p || want_d) {
         __syncthreads();
         for (int c = threadIdx.x; c < p.C; c += 64 * LN_NW) {
-            atomicAdd(p.dgamma + c, pg[c]);
-            atomicAdd(p.dbeta + c, pb[c]);
+            if (want_p) {
+                atomicAdd(p.dgamma + c, pg[c]);
+                atomicAdd(p.dbeta + c, pb[c]);
+            }
+            if (want_d) atomicAdd(p.dsum + c, pd[c]);
         }
     }
 }
@@ -213,7 +225,9 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     p.dx = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DX]);
     p.dgamma = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DGAMMA]);
     p.dbeta = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DBETA]);
-    CHECK_PTRS("chan_ln_bwd", p.dy, p.x, p.mr_in, p.gamma, p.dx, p.dgamma, p.dbeta);
+    p.dxin = ref_ptr<const float>(c, op.t[S2K_CHAN_LN_BWD_T_DXIN]);
+    p.dsum = ref_ptr<float>(c, op.t[S2K_CHAN_LN_BWD_T_DSUM]);
+    CHECK_PTRS("chan_ln_bwd", p.dy, p.x, p.mr_in, p.gamma, p.dx, p.dgamma, p.dbeta, p.dxin, p.dsum);
     p.B = op.d[S2K_CHAN_LN_BWD_D_B]; p.C = op.d[S2K_CHAN_LN_BWD_D_C]; p.HW = op.d[S2K_CHAN_LN_BWD_D_HW];
     p.accum = op.d[S2K_CHAN_LN_BWD_D_ACCUM];
     if (!p.dy || !p.x || !p.mr_in || !p.gamma || !p.dx || p.B <= 0 || p.C <= 0 || p.HW <= 0 || (!p.dgamma != !p.dbeta)) {
@@ -221,7 +235,7 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
-    const size_t lds = (2 * (size_t)p.C + LN_NW * 64 * 2) * sizeof(float);
+    const size_t lds = (3 * (size_t)p.C + LN_NW * 64 * 2) * sizeof(float);
     if (lds > 64 * 1024) { set_error("chan_ln_bwd: C too large"); return S2K_EINVAL; }
     hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 1024)), dim3(64 * LN_NW), lds, c.stream, p);
     return S2K_OK;

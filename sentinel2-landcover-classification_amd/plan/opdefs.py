@@ -140,7 +140,11 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     #   MR[b][hw] = {mean, rstd};  Y = (X - mean) * rstd * GAMMA[c] + BETA[c]
     "CHAN_LN_FWD": (["X", "GAMMA", "BETA", "Y", "MR"], [], ["B", "C", "HW"], ["EPS"]),
     # DX (+)= rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)), g = DY * GAMMA;  DGAMMA[c] += sum DY * xhat;  DBETA[c] += sum DY
-    "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA"], [], ["B", "C", "HW", "ACCUM"], []),
+    # DXIN (with ACCUM): the accumulation is OUT OF PLACE, DX = DXIN + ... - the residual-stream gradient of a transformer block gets
+    # a fresh buffer at every update, so the weight-gradient stages still reading the old one on the side stream are never
+    # overwritten (no stream join needed).  DSUM[c] += sum_{b,hw} DX (the new values): the bias gradient of the Linear whose
+    # output gradient DX is (attn.proj / mlp.fc2 of the transformer blocks) - saves a CHANNEL_SUM pass over DX per Linear.
+    "CHAN_LN_BWD": (["DY", "X", "MR", "GAMMA", "DX", "DGAMMA", "DBETA", "DXIN", "DSUM"], [], ["B", "C", "HW", "ACCUM"], []),
     # G[i] *= act'(X[i])
     # ACT = ACT_MUL: G[i] *= X[i]  (the dropout gate of EfficientNet's classifier head in the backward)
     "ACT_BWD": (["G", "X"], ["COUNT"], ["ACT"], []),
@@ -221,7 +225,7 @@ WRITES: dict[str, tuple[str, ...]] = {
     "SE_FC_BWD": ("DGATE", "HPRE", "DW1", "DB1", "DW2", "DB2", "DPOOL", "HS"), "SE_BWD_REDUCE": ("DGATE",),
     "BN_BWD_REDUCE": ("GOUT", "STATS2"), "BN_BWD_FINALIZE": ("DGAMMA", "DBETA", "COEF"), "BN_BWD_APPLY": ("DY", "DGAMMA", "DBETA"),
     "BN_RESIDUAL": ("XOUT", "BNV", "FRM", "FRV"), "CHANNEL_SUM": ("OUT",), "LOSS_FWD": ("LOSS", "ACC"), "LOSS_BWD": ("DLOGITS",),
-    "ARGMAX": ("MASK",), "CHAN_LN_FWD": ("Y", "MR"), "CHAN_LN_BWD": ("DX", "DGAMMA", "DBETA"), "ACT_BWD": ("G",), "ACT_FWD": ("Y",),
+    "ARGMAX": ("MASK",), "CHAN_LN_FWD": ("Y", "MR"), "CHAN_LN_BWD": ("DX", "DGAMMA", "DBETA", "DSUM"), "ACT_BWD": ("G",), "ACT_FWD": ("Y",),
     "ATTN_FWD": ("O", "LSE"), "ATTN_BWD": ("DQKV", "DELTA"), "MAE_MASK_INDEX": ("IDS_RESTORE", "MASK", "ENC_IDX", "DEC_IDX"),
     "IDS_TO_DEC_IDX": ("DEC_IDX",), "TOKEN_GATHER": ("OUT",), "TOKEN_SCATTER": ("DIN", "DFILL"), "PATCHIFY": ("X", "OUT"),
     "MAE_LOSS_FWD": ("LOSS", "ACC"), "MAE_LOSS_BWD": ("DPRED",), "TRANSPOSE_CL": ("Y",), "CONFUSION": ("HIST",), "DROP_GATE": ("GATE",),

@@ -213,15 +213,16 @@ class _V:
         return y
 
     def linear_bwd(self, wname: str, bname: str | None, x: TRef, dy: TRef, K: int, M: int, N: int, pro: int = D.PRO_NONE,
-                   dx: TRef | None = None, dx_beta: int = 0) -> None:
-        """weight / bias gradients (when trainable) and, if `dx` is given, the input gradient w.r.t. pro(x)."""
+                   dx: TRef | None = None, dx_beta: int = 0, bias_sum: bool = True) -> None:
+        """weight / bias gradients (when trainable) and, if `dx` is given, the input gradient w.r.t. pro(x).
+        bias_sum=False: the bias gradient (the row sums of dy) is produced by the stage that wrote dy (CHAN_LN_BWD's DSUM)."""
         p, B = self.p, self.p.B
         if self.trainable(wname):
             # [M][K] scratch layout = the Linear weight's layout: accumulate straight into the gradient buffer (no finalize pass)
             p.bwd.add("WGRAD", P=dy, BNVP=None, GATEP=None, Q=x, BNVQ=self.ident_bnv(K) if pro != D.PRO_NONE else None, GATEQ=None,
                       WGS=p.pgrad(wname), B=B, M=M, C=K, CTOT=K, H=1, W=N, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N,
                       PROP=D.PRO_NONE, PROQ=pro, MODE=D.MODE_CONV)
-            if bname:
+            if bname and bias_sum:
                 p.bwd.add("CHANNEL_SUM", G=dy, OUT=p.pgrad(bname), B=B, C=M, HW=N)
         if dx is not None:
             wp, MP = p.pack_weight("bwd", wname, K, M, 1, 1, K, 1, 0)
@@ -237,12 +238,17 @@ class _V:
                   B=B, C=C, HW=N, EPS=eps)
         return y, mr
 
-    def ln_bwd(self, prefix: str, dy: TRef, x: TRef, mr: TRef, dx: TRef, C: int, N: int, accum: int):
+    def ln_bwd(self, prefix: str, dy: TRef, x: TRef, mr: TRef, dx: TRef, C: int, N: int, accum: int, dxin: TRef | None = None,
+               dsum: TRef | None = None):
+        """dxin (with accum): DX = DXIN + ... (out of place); dsum: += the row sums of the new DX (a Linear's bias gradient)."""
         p, B = self.p, self.p.B
         tr = self.trainable(prefix + ".weight")
         p.bwd.add("CHAN_LN_BWD", DY=dy, X=x, MR=mr, GAMMA=p.param(prefix + ".weight"), DX=dx,
                   DGAMMA=p.pgrad(prefix + ".weight") if tr else None, DBETA=p.pgrad(prefix + ".bias") if tr else None,
-                  B=B, C=C, HW=N, ACCUM=accum)
+                  DXIN=dxin, DSUM=dsum, B=B, C=C, HW=N, ACCUM=accum)
+
+    def bias_grad(self, bname: str) -> TRef | None:
+        return self.p.pgrad(bname) if self.trainable(bname) else None
 
     # timm Block on [B][Dm][N] ------------------------------------------------------------------------
     def block_fwd(self, prefix: str, x: TRef, Dm: int, heads: int, hidden: int, L: int) -> tuple[TRef, dict]:
@@ -266,24 +272,41 @@ class _V:
         return xo, dict(prefix=prefix, x=x, h1=h1, mr1=mr1, qkv=qkv, o=o, lse=lse, xm=xm, h2=h2, mr2=mr2, f1=f1, a1=a1, Dm=Dm, heads=heads,
                         hidden=hidden, N=N, L=L)
 
-    def block_bwd(self, r: dict, g: TRef) -> None:
-        """g = gradient of the block output, [B][Dm][N]; on return it holds the gradient of the block INPUT (the
-        residual stream's gradient is accumulated in place)."""
+    def block_bwd(self, r: dict, g: TRef, below_fc2_bias: TRef | None = None) -> TRef:
+        """g = gradient of the block output, [B][Dm][N]; returns the gradient of the block INPUT.  The residual stream's gradient
+        gets a FRESH buffer at each of its two updates (CHAN_LN_BWD with DXIN): the fc2 / proj weight-gradient stages, which read
+        it on the side stream, are never overwritten - an in-place accumulation raced with them.  The bias gradients of proj and
+        of the fc2 of the block BELOW (`below_fc2_bias`) are the row sums of those new buffers and come out of the same
+        CHAN_LN_BWD stages (DSUM); this block's own fc2 bias gradient was produced by whoever wrote `g`."""
         p, B = self.p, self.p.B
         pre, Dm, heads, hidden, N = r["prefix"], r["Dm"], r["heads"], r["hidden"], r["N"]
         g_f1 = p.alloc("g:f1:" + pre, (B, hidden, N))
-        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1)
+        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1, bias_sum=False)
         p.bwd.add("ACT_BWD", G=g_f1, X=r["f1"], COUNT=B * hidden * N, ACT=D.ACT_GELU)
         g_h = p.alloc("g:h:" + pre, (B, Dm, N))       # shared scratch for both LayerNorm output gradients
         self.linear_bwd(pre + ".mlp.fc1.weight", pre + ".mlp.fc1.bias", r["h2"], g_f1, Dm, hidden, N, dx=g_h)
-        self.ln_bwd(pre + ".norm2", g_h, r["xm"], r["mr2"], g, Dm, N, accum=1)
+        g_mid = p.alloc("g:mid:" + pre, (B, Dm, N))   # d loss / d (x + attention branch)
+        self.ln_bwd(pre + ".norm2", g_h, r["xm"], r["mr2"], g_mid, Dm, N, accum=1, dxin=g, dsum=self.bias_grad(pre + ".attn.proj.bias"))
         g_o = p.alloc("g:o:" + pre, (B, Dm, N))
-        self.linear_bwd(pre + ".attn.proj.weight", pre + ".attn.proj.bias", r["o"], g, Dm, Dm, N, dx=g_o)
+        self.linear_bwd(pre + ".attn.proj.weight", pre + ".attn.proj.bias", r["o"], g_mid, Dm, Dm, N, dx=g_o, bias_sum=False)
         g_qkv = p.alloc("g:qkv:" + pre, (B, 3 * Dm, N))
         p.bwd.add("ATTN_BWD", QKV=r["qkv"], DO=g_o, DQKV=g_qkv, O=r["o"], LSE=r["lse"], DELTA=p.alloc("delta:" + pre, (B, heads, N)),
                   B=B, HEADS=heads, HD=Dm // heads, L=r["L"], LS=N, SCALE=float(Dm // heads) ** -0.5)
         self.linear_bwd(pre + ".attn.qkv.weight", pre + ".attn.qkv.bias", r["h1"], g_qkv, Dm, 3 * Dm, N, dx=g_h)
-        self.ln_bwd(pre + ".norm1", g_h, r["x"], r["mr1"], g, Dm, N, accum=1)
+        g_in = p.alloc("g:in:" + pre, (B, Dm, N))
+        self.ln_bwd(pre + ".norm1", g_h, r["x"], r["mr1"], g_in, Dm, N, accum=1, dxin=g_mid, dsum=below_fc2_bias)
+        return g_in
+
+    def blocks_bwd(self, recs: list, g: TRef) -> TRef:
+        """Backward through a stack of blocks (last first).  `g` must have been written by a CHAN_LN_BWD whose DSUM was
+        `top_fc2_bias(recs)` (the final norm's backward)."""
+        for i in range(len(recs) - 1, -1, -1):
+            below = self.bias_grad(recs[i - 1]["prefix"] + ".mlp.fc2.bias") if i > 0 else None
+            g = self.block_bwd(recs[i], g, below)
+        return g
+
+    def top_fc2_bias(self, recs: list) -> TRef | None:
+        return self.bias_grad(recs[-1]["prefix"] + ".mlp.fc2.bias") if recs else None
 
 
 def _encoder(v: _V, s: MaeSpec, prefix: str, x_img: TRef, noise: TRef, keep: int, outs: dict, need_input_grads: bool):
@@ -321,9 +344,8 @@ def _encoder_bwd(v: _V, s: MaeSpec, rec: dict, g_latent: TRef, dx: TRef | None =
     p, B = v.p, v.p.B
     prefix, N, NS, Dm, Lp, Kp = rec["prefix"], rec["N"], rec["NS"], rec["Dm"], rec["Lp"], rec["Kp"]
     g = p.alloc("g:enc:" + prefix, (B, Dm, NS))
-    v.ln_bwd(prefix + "norm", g_latent, rec["x_last"], rec["mr"], g, Dm, NS, accum=0)
-    for r in reversed(rec["blocks"]):
-        v.block_bwd(r, g)
+    v.ln_bwd(prefix + "norm", g_latent, rec["x_last"], rec["mr"], g, Dm, NS, accum=0, dsum=v.top_fc2_bias(rec["blocks"]))
+    g = v.blocks_bwd(rec["blocks"], g)
     g_pe = p.alloc("g:pe:" + prefix, (B, Dm, Lp))
     p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=rec["enc_idx"], DIN=g_pe, DFILL=p.pgrad(prefix + "cls_token") if v.trainable(prefix + "cls_token") else None,
               B=B, C=Dm, LIN=Lp, LOUT=N,
@@ -408,9 +430,8 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
         g_yn = p.alloc("g:yn", (B, Dd, NDS))
         v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, NDS, dx=g_yn)
         g = p.alloc("g:dec", (B, Dd, NDS))
-        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0)
-        for r in reversed(drecs):
-            v.block_bwd(r, g)
+        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0, dsum=v.top_fc2_bias(drecs))
+        g = v.blocks_bwd(drecs, g)
         g_dx = p.alloc("g:dx", (B, Dd, NS))
         p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=erec["dec_idx"], DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND,
                   LIN_S=NS, LOUT_S=NDS)
@@ -661,9 +682,8 @@ def plan_mae_decoder(s: MaeSpec, B: int, N: int, want_bwd: bool, layout: ParamLa
         g_yn = p.alloc("g:yn", (B, Dd, NDS))
         v.linear_bwd("decoder_pred.weight", "decoder_pred.bias", yn, g_pred, Dd, PD, NDS, dx=g_yn)
         g = p.alloc("g:dec", (B, Dd, NDS))
-        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0)
-        for r in reversed(drecs):
-            v.block_bwd(r, g)
+        v.ln_bwd("decoder_norm", g_yn, y, mrd, g, Dd, NDS, accum=0, dsum=v.top_fc2_bias(drecs))
+        g = v.blocks_bwd(drecs, g)
         g_dx = p.alloc("g:dx", (B, Dd, NS))
         p.bwd.add("TOKEN_SCATTER", DOUT=g, IDX=dec_idx, DIN=g_dx, DFILL=p.pgrad("mask_token"), B=B, C=Dd, LIN=N, LOUT=ND,
                   LIN_S=NS, LOUT_S=NDS)

@@ -281,8 +281,16 @@ def test_no_main_stream_stage_overwrites_what_a_side_stream_stage_still_reads():
         return joins
 
     mae = MaskedAutoencoderViT(**PRITHVI_SMALL)
-    j = check(mae._make_plan(2, True, 0.75, True).bwd)
-    assert j >= 2 * (PRITHVI_SMALL["depth"] + PRITHVI_SMALL["decoder_depth"])       # both LayerNorm backwards of every block wait
+    plan = mae._make_plan(2, True, 0.75, True)
+    j = check(plan.bwd)
+    # the residual-stream gradient gets a fresh buffer at every update (CHAN_LN_BWD with DXIN), so no LayerNorm backward has to
+    # wait for the side stream: the only joins are the buckets' WGRAD_FINALIZE stages
+    assert j == sum(1 for k, _ in plan.bwd.ops if k == "WGRAD_FINALIZE")
+    lnb = [f for k, f in plan.bwd.ops if k == "CHAN_LN_BWD"]
+    assert sum(1 for f in lnb if f.get("DXIN") is not None) == 2 * (PRITHVI_SMALL["depth"] + PRITHVI_SMALL["decoder_depth"])
+    # the proj / fc2 bias gradients come out of those stages: one CHANNEL_SUM per block less two
+    n_blocks = PRITHVI_SMALL["depth"] + PRITHVI_SMALL["decoder_depth"]
+    assert sum(1 for f in lnb if f.get("DSUM") is not None) == 2 * n_blocks
     bb = MaskedAutoencoderViT(**PRITHVI_SEG_SMALL, _decoder=False, _flat=False)
     cfg = PrithviSegmentationNetConfig(num_frames=1, num_classes=4, fcn_out_channels=8, fcn_num_convs=1, fcn_dropout=0.1,
                                        frozen_backbone=False, embed_dim=32, patch_height=4, patch_width=4)
