@@ -383,6 +383,7 @@ int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
         if (ec == 32) return launch_wb16<WG_SPATIAL, 2, 1, 1, 1, 4, 64>(p, st);
         return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 64>(p, st);
     }
+    if (p.WO % 56 == 0) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 56>(p, st);      // 224-pixel inputs: 56 / 112 / 224 wide maps
     if (p.WO == 32) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 32>(p, st);
     if (p.WO == 16) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 8, 16>(p, st);
     return 1;

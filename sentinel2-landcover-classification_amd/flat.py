@@ -62,6 +62,23 @@ class FlatParamsMixin:
         self._compile_anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self._compile_handle = compile_ops.register(self)
 
+    # -- arithmetic ---------------------------------------------------------------------------
+    @property
+    def precision(self) -> str:
+        """"f32" (default: exact-f32 MFMA everywhere, the parity path) or "bf16-mixed": dense convs / Linears and their weight
+        gradients may round their MFMA operands to bf16 (f32 accumulation, f32 BatchNorm / LayerNorm / attention / loss / master
+        weights / Adam) - the arithmetic class of the reference's own default `precision="bf16"` (configs/segmentation.py:146,153,
+        prithvi_mae_finetune.py), reported separately from the f32 results and never the default."""
+        return getattr(self, "_precision", "f32")
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("f32", "bf16-mixed"):
+            raise ValueError(f"precision must be 'f32' or 'bf16-mixed', got {value!r}")
+        if value != self.precision:
+            self._precision = value
+            self._engines.clear()
+
     @property
     def _compile_trainable(self) -> bool:
         return any(p.requires_grad for p in self.parameters())

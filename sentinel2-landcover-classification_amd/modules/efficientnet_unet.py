@@ -291,22 +291,6 @@ class EfficientnetUnet(FlatParamsMixin, nn.Module):
                          want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx,
                          bf16=self.precision == "bf16-mixed")
 
-    @property
-    def precision(self) -> str:
-        """"f32" (default: exact-f32 MFMA everywhere, the parity path) or "bf16-mixed": dense convs and weight gradients may
-        round their MFMA operands to bf16 (f32 accumulation, f32 BatchNorm statistics / loss / master weights / Adam) - the
-        arithmetic class of the reference's own default `precision="bf16"` (configs/segmentation.py:146,153), reported
-        separately from the f32 results and never the default."""
-        return getattr(self, "_precision", "f32")
-
-    @precision.setter
-    def precision(self, value: str) -> None:
-        if value not in ("f32", "bf16-mixed"):
-            raise ValueError(f"precision must be 'f32' or 'bf16-mixed', got {value!r}")
-        if value != self.precision:
-            self._precision = value
-            self._engines.clear()
-
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 4 or x.shape[1] != self.config.in_channels:
             raise ValueError(f"expected [B,{self.config.in_channels},H,W], got {tuple(x.shape)}")

@@ -171,7 +171,7 @@ class MaskedAutoencoderViT(FlatParamsMixin, nn.Module):
     # -- engine -------------------------------------------------------------------------------------------
     def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.75, want_bwd: bool | None = None, want_dx: bool = False):
         return plan_mae(self.spec, B, mask_ratio, training, self._layout,    # (no BatchNorm / dropout: training == want_bwd)
-                        bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx)
+                        bucket_floats=getattr(self, "_bucket_floats", 8 << 20), want_dx=want_dx, bf16=self.precision == "bf16-mixed")
 
     def _check_imgs(self, imgs):
         s = self.spec

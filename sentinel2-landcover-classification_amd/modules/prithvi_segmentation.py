@@ -113,7 +113,7 @@ class PrithviSegmentationNet(FlatParamsMixin, nn.Module):
 
     def _make_plan(self, B: int, training: bool, mask_ratio: float = 0.0, want_bwd: bool | None = None, want_dx: bool = False):
         return plan_seg(self.spec, B, training, self._layout, want_bwd=want_bwd, bucket_floats=getattr(self, "_bucket_floats", 8 << 20),
-                        want_dx=want_dx)
+                        want_dx=want_dx, bf16=self.precision == "bf16-mixed")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from ..vit_engine import run_vit

@@ -45,4 +45,4 @@ def wgrad_ok(f: dict) -> bool:
         return hw % 8 == 0 and f["B"] * hw >= 512
     if T != 9 or f["KH"] != 3 or f["PAD_T"] != 1 or f["PAD_L"] != 1 or f.get("GATEQ") is not None or f["PROP"] != D.PRO_NONE:
         return False
-    return f["WO"] % 64 == 0 or f["WO"] in (32, 16)
+    return f["WO"] % 64 == 0 or f["WO"] % 56 == 0 or f["WO"] in (32, 16)

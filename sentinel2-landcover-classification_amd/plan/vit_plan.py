@@ -181,8 +181,24 @@ def seg_layout(s: SegSpec) -> ParamLayout:
     return L
 
 
+_ROW_ALIGN = 4      # floats; 8 while a bf16-mixed plan is being built (the bf16 weight-gradient kernel contracts pixel OCTETS)
+
+
 def row_stride(n: int) -> int:
-    return (n + 3) // 4 * 4
+    return (n + _ROW_ALIGN - 1) // _ROW_ALIGN * _ROW_ALIGN
+
+
+class _row_align:
+    def __init__(self, floats: int):
+        self.floats = floats
+
+    def __enter__(self):
+        global _ROW_ALIGN
+        self.prev, _ROW_ALIGN = _ROW_ALIGN, self.floats
+
+    def __exit__(self, *exc):
+        global _ROW_ALIGN
+        _ROW_ALIGN = self.prev
 
 
 # ---- building blocks ----------------------------------------------------------------------------------
@@ -366,11 +382,19 @@ def _out(outs: dict, cursor: list, name: str, shape: tuple, dtype: str = "f32") 
 
 
 def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: ParamLayout | None = None,
-             bucket_floats: int = 8 << 20, want_dx: bool = False) -> VitPlan:
-    """MaskedAutoencoderViT.forward(imgs, mask_ratio) -> (loss, pred, mask) (+ latent, ids_restore for forward_encoder)."""
+             bucket_floats: int = 8 << 20, want_dx: bool = False, bf16: bool = False) -> VitPlan:
+    """MaskedAutoencoderViT.forward(imgs, mask_ratio) -> (loss, pred, mask) (+ latent, ids_restore for forward_encoder).
+    bf16: the bf16-mixed plan (unet_plan.mark_bf16: Linears and their weight gradients on bf16 MFMA operands; attention,
+    LayerNorm, GELU, loss and the optimiser stay f32); token rows are padded to 8 floats instead of 4."""
+    with _row_align(8 if bf16 else 4):
+        return _plan_mae(s, B, mask_ratio, training, layout, bucket_floats, want_dx, bf16)
+
+
+def _plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout, bucket_floats: int, want_dx: bool, bf16: bool) -> VitPlan:
     assert s.decoder
     layout = layout or mae_layout(s)
     p = _P(s, layout, B, s.img_size, s.img_size, training)
+    p.bf16 = bool(bf16)
     v = _V(p, lambda name: True)
     Lp, Dm, Dd, PD = s.num_patches, s.embed_dim, s.decoder_embed_dim, s.patch_dim
     keep = int(Lp * (1 - mask_ratio))
@@ -454,14 +478,20 @@ def plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout: Para
 
 
 def plan_seg(s: SegSpec, B: int, training: bool, layout: ParamLayout | None = None, bucket_floats: int = 8 << 20,
-             want_bwd: bool | None = None, want_dx: bool = False) -> VitPlan:
-    """PrithviSegmentationNet.forward (prithvi_segmentation.py:156-162)."""
+             want_bwd: bool | None = None, want_dx: bool = False, bf16: bool = False) -> VitPlan:
+    """PrithviSegmentationNet.forward (prithvi_segmentation.py:156-162).  bf16: the bf16-mixed plan (see plan_mae)."""
+    with _row_align(8 if bf16 else 4):
+        return _plan_seg(s, B, training, layout, bucket_floats, want_bwd, want_dx, bf16)
+
+
+def _plan_seg(s: SegSpec, B: int, training: bool, layout, bucket_floats: int, want_bwd, want_dx: bool, bf16: bool) -> VitPlan:
     m = s.mae
     assert not m.decoder
     if m.img_size // m.patch_size * 16 != m.img_size:
         raise ValueError("the neck upsamples the patch grid x16: img_size must be 16 * (img_size // patch_size)")
     layout = layout or seg_layout(s)
     p = _P(s, layout, B, m.img_size, m.img_size, training, want_bwd)
+    p.bf16 = bool(bf16)
     frozen = s.frozen_backbone
     v = _V(p, lambda name: not (frozen and name.startswith("backbone.")))
     Lp, Dm, E = m.num_patches, m.embed_dim, s.embed

@@ -167,3 +167,57 @@ def test_bf16_mixed_against_the_f32_path_and_the_fp32_oracle(version, C, H, B, s
     m16.load_state_dict(sd)
     l_back, _, _ = _step(m16, x.to(DEV), y.to(DEV), noise)
     assert rel_err(l_back.cpu().numpy(), l32.cpu().numpy()) < 1e-6
+
+
+def test_prithvi_bf16_mixed_against_f32():
+    """MaskedAutoencoderViT / PrithviSegmentationNet in bf16-mixed (Linears, neck / head convs and their weight gradients on bf16
+    MFMA operands; attention, LayerNorm, GELU, loss in f32; token rows padded to 8 floats) against the f32 path."""
+    from s2lc_amd.losses import CrossEntropyLoss, class_mask
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+    from tests.helpers import PRITHVI_SEG_SMALL, PRITHVI_SMALL
+
+    x = detgen.normal("b16.mae.x", (4, 3, 1, 32, 32), seed=81).to(DEV)
+    noise = detgen.uniform("b16.mae.n", (4, 16), 0.0, 1.0, seed=81)
+    res = {}
+    for prec in ("f32", "bf16-mixed"):
+        torch.manual_seed(7)
+        m = MaskedAutoencoderViT(**PRITHVI_SMALL).to(DEV)
+        m.precision = prec
+        m.masking_noise = noise
+        loss, pred, mask = m(x, mask_ratio=0.75)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[prec] = (float(loss), pred.detach().clone(), mask.clone(), m._grad_buffer().detach().clone())
+        if prec == "bf16-mixed":
+            eng = next(e for e in m._engines.values() if e.bwd is not None)
+            flagged = sum(1 for prog in (eng.plan.fwd, eng.plan.bwd) for k, f in prog.ops if k in ("CONV", "WGRAD") and f.get("_flags", 0) & D.FLAG_BF16)
+            assert flagged >= 20, flagged
+    (l0, p0, k0, g0), (l1, p1, k1, g1) = res["f32"], res["bf16-mixed"]
+    assert torch.equal(k0, k1)
+    cos = float((g0.double() * g1.double()).sum() / (g0.double().norm() * g1.double().norm()))
+    e = rel_err(p1.cpu().numpy(), p0.cpu().numpy())
+    print(f"MAE bf16-mixed vs f32: loss {l1:.6f} vs {l0:.6f}, pred max rel err {e:.2e}, gradient cosine {cos:.6f}")
+    assert abs(l1 - l0) < 5e-3 * abs(l0) and e < 3e-2 and cos > 0.999
+
+    xs = detgen.normal("b16.seg.x", (2, 3, 1, 64, 64), seed=82).to(DEV)
+    ys = detgen.labels("b16.seg.y", (2, 64, 64), 4, seed=82).to(DEV)
+    res = {}
+    for prec in ("f32", "bf16-mixed"):
+        torch.manual_seed(8)
+        bb = MaskedAutoencoderViT(**PRITHVI_SEG_SMALL, _decoder=False, _flat=False)
+        cfg = PrithviSegmentationNetConfig(num_frames=1, num_classes=4, fcn_out_channels=8, fcn_num_convs=1, fcn_dropout=0.1,
+                                           frozen_backbone=False, embed_dim=32, patch_height=4, patch_width=4)
+        net = PrithviSegmentationNet(cfg, backbone=bb).to(DEV).eval()      # eval: BatchNorm on running statistics (well conditioned)
+        net.precision = prec
+        net.masking_noise = detgen.uniform("b16.seg.n", (2, 16), 0, 1, seed=82)
+        logits = net(xs)
+        CrossEntropyLoss(ignore_index=0)(logits, ys).backward()
+        torch.cuda.synchronize()
+        res[prec] = (logits.detach().clone(), net._grad_buffer().detach().clone())
+    (lg0, g0), (lg1, g1) = res["f32"], res["bf16-mixed"]
+    e = rel_err(lg1.cpu().numpy(), lg0.cpu().numpy())
+    agree = float((class_mask(lg1) == class_mask(lg0)).double().mean())
+    cos = float((g0.double() * g1.double()).sum() / (g0.double().norm() * g1.double().norm()))
+    print(f"seg net bf16-mixed vs f32 (eval): logits max rel err {e:.2e}, masks agree {100 * agree:.2f} %, gradient cosine {cos:.6f}")
+    assert e < 3e-2 and agree > 0.98 and cos > 0.999

@@ -343,6 +343,7 @@ def test_wgrad_1x1_bf16(B, M, C, H, W, prop, proq, gate):
     (2, 24, 32, 32, 0, 5, 64, 3),        # 32 x 32 tile (waves split the pixels of 4 x 64 tiles), odd height
     (2, 64, 24, 24, 0, 9, 128, 0),       # 64 x 32 tiles, two x tiles per row, H not a multiple of 4
     (2, 32, 64, 64, 0, 8, 64, 3),        # 32 x 64 tiles
+    (2, 96, 80, 80, 0, 9, 112, 3),       # (2, 56) tiles (224-pixel inputs), two x tiles per row, odd height, ragged m / c tiles
 ])
 def test_wgrad_3x3_bf16(B, M, C, CT, c_off, H, W, proq):
     _wgrad_case(B, M, C, CT, c_off, H, W, 3, 1, 1, 1, H, W, 0, proq, False, bf16=True)

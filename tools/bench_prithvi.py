@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--unfrozen", action="store_true")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--ops", action="store_true", help="with --profile: per-shape table of the MFMA stages")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(42)
@@ -63,6 +64,7 @@ def main():
         flops = (875e9 if a.unfrozen else 804e9) * B
     opt = FlatAdam(model, lr=1e-4)
     model.train()
+    model.precision = a.precision
     for _ in range(a.warmup):
         loss = step()
     torch.cuda.synchronize()
@@ -71,7 +73,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    res = {"workload": f"prithvi-{a.what}" + ("-unfrozen" if a.unfrozen else ""), "batch": B, "ms_per_step": dt * 1e3, "samples_per_s": B / dt,
+    res = {"workload": f"prithvi-{a.what}" + ("-unfrozen" if a.unfrozen else ""), "batch": B, "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "precision": a.precision,
            "algorithmic_tflops": flops / dt / 1e12, "loss": float(loss)}
     if a.profile:
         eng = next(iter(model._engines.values()))
