@@ -54,8 +54,9 @@ __device__ __forceinline__ wu32x4 pro_unit(const f32x4& a, const f32x4& b, int p
 // k-steps s = wk, wk + WVK, ... of a pixel tile.  WVK > 1 (thin layers: a 32-channel side leaves one 32 x 32 tile per tap) splits the
 // pixels of a tile over waves; every wave adds its partial sums in the combine.
 // Pixel tile: 1x1: XW consecutive pixels (R = 1); 3x3: R rows x XW pixels.
+// 1x1: two workgroups per CU; 3x3 (144 accumulator registers per lane + the next tile's staging registers): one.
 template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW>
-__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
+__global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel(const WgradP p) {
     constexpr bool PIX = MODE == WG_PIX;
     constexpr int NT = 256;
     constexpr int T = PIX ? 1 : 9;
@@ -119,8 +120,13 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
     const int wk = wave % WVK, wmn = wave / WVK;
     const int wm0 = (wmn / WVC) * (WM * 32), wc0 = (wmn % WVC) * (WN * 32);
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        // ================================================ stage ================================================================
+    // ---- staging registers: the WHOLE next tile is fetched while the current one is multiplied ---------------------------------
+    f32x4 pxa[POB][PRG], pxb[POB][PRG], qxa[QOB][QRG], qxb[QOB][QRG];
+    float qgate[QOB][QRG];
+    bool pok[POB], qok[QOB];
+    float hval[NHI > 0 ? NHI : 1];
+
+    auto fetch = [&](int tile) {
         int tb = 0, y0 = 0, x0 = 0;
         if (PIX) {
             if (img_local) tb = (int)(((int64_t)tile * NPJ) / p.HWp);
@@ -131,114 +137,60 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
         }
         const rsrc_t rp = make_rsrc(p.p + (int64_t)tb * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - tb) * p.M * p.HWp * 4);
         const rsrc_t rq = make_rsrc(p.q + (int64_t)tb * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - tb) * p.C * p.HWq * 4);
-        // byte offset of pixel octet `oct` of the P / Q tile inside a row (image-relative), or "no such pixels"
-        auto p_off = [&](int oct, uint32_t& off, int& b) -> bool {
-            b = tb;
-            if (oct >= NPO) return false;
+#pragma unroll
+        for (int ob = 0; ob < POB; ++ob) {
+            // byte offset of this lane's pixel octet of the P tile inside a row (image-relative), or "no such pixels"
+            const int oct = ob * 8 + o8;
+            uint32_t off = 0;
+            bool ok = oct < NPO;
             if (PIX) {
                 const int64_t n = (int64_t)tile * NPJ + 8 * oct;
-                if (n >= ntot) return false;
-                b = (int)(n / p.HWp);
-                off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (n - (int64_t)b * p.HWp)) * 4u;
-                return true;
+                ok = ok && n < ntot;
+                const int64_t nn = ok ? n : 0;
+                const int b = (int)(nn / p.HWp);
+                off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (nn - (int64_t)b * p.HWp)) * 4u;
+            } else {
+                const int r = oct / XO, k = oct % XO;
+                off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * 4u;
+                ok = ok && y0 + r < p.HO;
             }
-            const int r = oct / XO, k = oct % XO;
-            off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * 4u;
-            return y0 + r < p.HO;
-        };
-        auto q_off = [&](int oct, uint32_t& off, int& b) -> bool {
-            b = tb;
-            if (oct >= NQO) return false;
-            if (PIX) {
-                const int64_t n = (int64_t)tile * NPJ + 8 * oct;
-                if (n >= ntot) return false;
-                b = (int)(n / p.HWq);
-                off = (uint32_t)((int64_t)(b - tb) * p.C * p.HWq + (n - (int64_t)b * p.HWq)) * 4u;
-                return true;
+            pok[ob] = ok;
+#pragma unroll
+            for (int j = 0; j < PRG; ++j) {
+                const uint32_t a = ok ? off + (uint32_t)prow[j] * p_rstep : BUF_OOB;
+                pxa[ob][j] = bload4(rp, a);
+                pxb[ob][j] = bload4(rp, ok ? a + 16u : BUF_OOB);
             }
-            const int hr = oct / XO, k = oct % XO;
-            const int iy = y0 - 1 + hr;
-            off = (uint32_t)(iy * p.W + x0 + 8 * k) * 4u;
-            return iy >= 0 && iy < p.H;
-        };
-        // one batch = octet blocks [OB0, OB1) of every row group of this wave: all loads first, then prologue + bf16 + LDS
-        auto stage_p = [&](auto ob0c, auto ob1c) {
-            constexpr int OB0 = decltype(ob0c)::value, OB1 = decltype(ob1c)::value, NB = OB1 - OB0;
-            f32x4 xa[NB][PRG], xb[NB][PRG];
-            bool ok[NB];
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                uint32_t off = 0;
-                int b;
-                ok[ob] = p_off((OB0 + ob) * 8 + o8, off, b);
-#pragma unroll
-                for (int j = 0; j < PRG; ++j) {
-                    const uint32_t a = ok[ob] ? off + (uint32_t)prow[j] * p_rstep : BUF_OOB;
-                    xa[ob][j] = bload4(rp, a);
-                    xb[ob][j] = bload4(rp, ok[ob] ? a + 16u : BUF_OOB);
-                }
-            }
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                const int oct = (OB0 + ob) * 8 + o8;
-                if (oct < NPO)
-#pragma unroll
-                    for (int j = 0; j < PRG; ++j)
-                        Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pro_unit(xa[ob][j], xb[ob][j], p.prop, psc[j], psh[j], 1.0f, ok[ob]);
-            }
-        };
-        auto stage_q = [&](auto ob0c, auto ob1c) {
-            constexpr int OB0 = decltype(ob0c)::value, OB1 = decltype(ob1c)::value, NB = OB1 - OB0;
-            f32x4 xa[NB][QRG], xb[NB][QRG];
-            float g[NB][QRG];
-            bool ok[NB];
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                uint32_t off = 0;
-                int b;
-                ok[ob] = q_off((OB0 + ob) * 8 + o8, off, b);
-#pragma unroll
-                for (int j = 0; j < QRG; ++j) {
-                    const uint32_t a = ok[ob] ? off + (uint32_t)qrow[j] * q_rstep : BUF_OOB;
-                    xa[ob][j] = bload4(rq, a);
-                    xb[ob][j] = bload4(rq, ok[ob] ? a + 16u : BUF_OOB);
-                    g[ob][j] = (PIX && p.gateq && ok[ob]) ? p.gateq[(int64_t)b * p.C + qrow[j]] : 1.0f;
-                }
-            }
-#pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                const int oct = (OB0 + ob) * 8 + o8;
-                if (oct < NQO) {
-                    const int slot = PIX ? oct : (oct / XO) * QXO + 1 + (oct % XO);
-#pragma unroll
-                    for (int j = 0; j < QRG; ++j)
-                        Qs[slot * BC + (wave + 4 * j) * 8 + r8] = pro_unit(xa[ob][j], xb[ob][j], p.proq, qsc[j], qsh[j], g[ob][j], ok[ob]);
-                }
-            }
-        };
-        using std::integral_constant;
-        // batches sized so that a batch's loads (+ the accumulators) fit the register file: <= 8 (octet block, row group) items
-        if constexpr (POB * PRG <= 8) {
-            stage_p(integral_constant<int, 0>{}, integral_constant<int, POB>{});
-        } else {
-            constexpr int H1 = POB / 2;
-            stage_p(integral_constant<int, 0>{}, integral_constant<int, H1>{});
-            stage_p(integral_constant<int, H1>{}, integral_constant<int, POB>{});
         }
-        if constexpr (QOB * QRG <= 8) {
-            stage_q(integral_constant<int, 0>{}, integral_constant<int, QOB>{});
-        } else if constexpr (QOB * QRG <= 16) {
-            constexpr int H1 = QOB / 2;
-            stage_q(integral_constant<int, 0>{}, integral_constant<int, H1>{});
-            stage_q(integral_constant<int, H1>{}, integral_constant<int, QOB>{});
-        } else {
-            constexpr int H1 = QOB / 3, H2 = 2 * QOB / 3;
-            stage_q(integral_constant<int, 0>{}, integral_constant<int, H1>{});
-            stage_q(integral_constant<int, H1>{}, integral_constant<int, H2>{});
-            stage_q(integral_constant<int, H2>{}, integral_constant<int, QOB>{});
+#pragma unroll
+        for (int ob = 0; ob < QOB; ++ob) {
+            const int oct = ob * 8 + o8;
+            uint32_t off = 0;
+            bool ok = oct < NQO;
+            int b = tb;
+            if (PIX) {
+                const int64_t n = (int64_t)tile * NPJ + 8 * oct;
+                ok = ok && n < ntot;
+                const int64_t nn = ok ? n : 0;
+                b = (int)(nn / p.HWq);
+                off = (uint32_t)((int64_t)(b - tb) * p.C * p.HWq + (nn - (int64_t)b * p.HWq)) * 4u;
+            } else {
+                const int hr = oct / XO, k = oct % XO;
+                const int iy = y0 - 1 + hr;
+                off = (uint32_t)(iy * p.W + x0 + 8 * k) * 4u;
+                ok = ok && iy >= 0 && iy < p.H;
+            }
+            qok[ob] = ok;
+#pragma unroll
+            for (int j = 0; j < QRG; ++j) {
+                const uint32_t a = ok ? off + (uint32_t)qrow[j] * q_rstep : BUF_OOB;
+                qxa[ob][j] = bload4(rq, a);
+                qxb[ob][j] = bload4(rq, ok ? a + 16u : BUF_OOB);
+                qgate[ob][j] = (PIX && p.gateq && ok) ? p.gateq[(int64_t)b * p.C + qrow[j]] : 1.0f;
+            }
         }
         if constexpr (!PIX) {
-            // the tile's halo columns: one pixel left of octet 0 (element 7 of the unit left of it) and one right of the last octet
+            // the tile's halo columns: one pixel left of octet 0 and one right of the last octet, per (channel, halo row)
 #pragma unroll
             for (int i = 0; i < NHI; ++i) {
                 const int idx = tid + NT * i;
@@ -249,12 +201,50 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const WgradP p) {
                 const int gc = min(c0 + c, p.C - 1);
                 float x = bload(rq, ok ? (uint32_t)(iy * p.W + ix) * 4u + (uint32_t)gc * q_rstep : BUF_OOB);
                 if (p.proq != S2K_PRO_NONE) x = apply_pro(x, p.proq, p.bnvq[gc], p.bnvq[p.C + gc]);
-                if (!ok) x = 0.0f;
-                if (idx < BC * QR * 2)
-                    Qs[(hr * QXO + (side ? XO + 1 : 0)) * BC + c] = side ? wu32x4{wpk(x, 0.0f), 0u, 0u, 0u} : wu32x4{0u, 0u, 0u, wpk(0.0f, x)};
+                hval[NHI > 0 ? i : 0] = ok ? x : 0.0f;
             }
         }
+    };
+    // prologue + bf16 rounding + LDS: nothing here depends on the tile (validity travels in pok / qok)
+    auto commit = [&]() {
+#pragma unroll
+        for (int ob = 0; ob < POB; ++ob) {
+            const int oct = ob * 8 + o8;
+            if (oct < NPO)
+#pragma unroll
+                for (int j = 0; j < PRG; ++j)
+                    Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pro_unit(pxa[ob][j], pxb[ob][j], p.prop, psc[j], psh[j], 1.0f, pok[ob]);
+        }
+#pragma unroll
+        for (int ob = 0; ob < QOB; ++ob) {
+            const int oct = ob * 8 + o8;
+            if (oct < NQO) {
+                const int slot = PIX ? oct : (oct / XO) * QXO + 1 + (oct % XO);
+#pragma unroll
+                for (int j = 0; j < QRG; ++j)
+                    Qs[slot * BC + (wave + 4 * j) * 8 + r8] = pro_unit(qxa[ob][j], qxb[ob][j], p.proq, qsc[j], qsh[j], qgate[ob][j], qok[ob]);
+            }
+        }
+        if constexpr (!PIX) {
+#pragma unroll
+            for (int i = 0; i < NHI; ++i) {
+                const int idx = tid + NT * i;
+                if (idx < BC * QR * 2) {
+                    const int c = idx % BC, rest = idx / BC;
+                    const int side = rest & 1, hr = rest >> 1;
+                    const float x = hval[NHI > 0 ? i : 0];
+                    // left halo pixel = element 7 of the unit left of octet 0; right halo pixel = element 0 of the unit after the last
+                    Qs[(hr * QXO + (side ? XO + 1 : 0)) * BC + c] = side ? wu32x4{wpk(x, 0.0f), 0u, 0u, 0u} : wu32x4{0u, 0u, 0u, wpk(0.0f, x)};
+                }
+            }
+        }
+    };
+
+    if (tile_begin < tile_end) fetch(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        commit();
         __syncthreads();
+        if (tile + 1 < tile_end) fetch(tile + 1);                   // in flight while this tile is multiplied
 
         // ================================================ multiply =============================================================
 #pragma unroll
@@ -344,11 +334,14 @@ static int launch_wb16(WgradP& p, hipStream_t st) {
     auto kern = wgrad_bf16_kernel<MODE, WVM, WVC, WM, WN, R, XW>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    // pixel splits: enough workgroups for ~3 per CU; each split ends in an atomic combine of its accumulator tiles, so at least
-    // 8 pixel tiles per split
+    // Pixel splits.  Every split ends in an atomic combine of its accumulator tiles, and float atomics run at ~1.3 TB/s chip-wide
+    // (MI355X_MICROARCH.md): with bf16 MFMAs the combine of a 512 x 512 x 9 gradient split 12 ways (113 MB of adds, 87 us) cost
+    // more than the whole contraction.  So: just enough splits to give every CU its workgroups (one per CU for the 3x3 kernels,
+    // two for 1x1), whole rounds of them, and at least 4 pixel tiles per split.
     const int mc = p.n_mtiles * p.n_ctiles;
-    int splits = std::max(1, (3 * 256) / mc);
-    splits = std::min(splits, std::max(1, p.ntiles / 8));
+    const int slots = PIX ? 512 : 256;
+    int splits = std::max(1, slots / mc);
+    splits = std::min(splits, std::max(1, p.ntiles / 4));
     if (splits > 65535) splits = 65535;
     p.tiles_per_split = cdiv(p.ntiles, splits);
     splits = cdiv(p.ntiles, p.tiles_per_split);
@@ -381,7 +374,7 @@ int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
         if (em == 32 && ec == 32) return launch_wb16<WG_SPATIAL, 1, 1, 1, 1, 4, 64>(p, st);     // 32 x 32 tile, 4 x 64 pixels, waves split the pixels
         if (em == 32) return launch_wb16<WG_SPATIAL, 1, 2, 1, 1, 4, 64>(p, st);
         if (ec == 32) return launch_wb16<WG_SPATIAL, 2, 1, 1, 1, 4, 64>(p, st);
-        return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 64>(p, st);
+        return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 64>(p, st);      // 4 x 64 pixel tiles: halo 6 rows per 4
     }
     if (p.WO % 56 == 0) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 56>(p, st);      // 224-pixel inputs: 56 / 112 / 224 wide maps
     if (p.WO == 32) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 32>(p, st);

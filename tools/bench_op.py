@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--scratch", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS check: the chip holds a higher clock on trivial data)")
     ap.add_argument("--N", type=int, default=0, help="conv1: tokens per image (H=1, W=N) instead of an HxH map")
+    ap.add_argument("--bf16", action="store_true", help="FLAG_BF16: the bf16 MFMA kernels (conv: WTB points at arbitrary bf16 bits - timing only)")
     a = ap.parse_args()
     B, M, C, H = a.B, a.M, a.C, a.H
     ar = Arena(D.BASE["WS"])
@@ -64,7 +65,8 @@ def main():
         P = ar.alloc("p", (B, M, Hh, Wd)); Q = ar.alloc("q", (B, C, Hh, Wd)); bq = ar.alloc("bnv", (4, C))
         wgs = ar.alloc("wgs", (T, M, C))
         prog.add("WGRAD", P=P, BNVP=None, GATEP=None, Q=Q, BNVQ=bq if a.pro else None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C,
-                 H=Hh, W=Wd, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=Hh, WO=Wd, PROP=0, PROQ=a.pro, MODE=0)
+                 H=Hh, W=Wd, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=Hh, WO=Wd, PROP=0, PROQ=a.pro, MODE=0,
+                 **({"_flags": D.FLAG_BF16} if a.bf16 else {}))
         flops = 2.0 * M * C * T * B * Hh * Wd
     else:
         Wd = H
@@ -77,7 +79,8 @@ def main():
         prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st,
                  SCRATCH=scr, B=B, C1=C,
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
-                 W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M))
+                 W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M),
+                 **({"_flags": D.FLAG_BF16, "WTB": ar.alloc("w16", (KP * T * MP // 2,))} if a.bf16 else {}))
         flops = 2.0 * M * C * T * B * H * Wd
     buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * (0.0 if a.zeros else 0.5)).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)

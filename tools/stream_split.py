@@ -1,0 +1,59 @@
+"""Per-stream view of a rocprofv3 --kernel-trace CSV over the last `--steps` training steps (marker = the fused Adam step):
+sum of kernel durations per stream / queue, union busy time per stream, and the time only ONE stream is busy."""
+import argparse
+import collections
+import csv
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cs, ce = 0, None, None
+    for s, e in iv:
+        if ce is None or s > ce:
+            if ce is not None:
+                tot += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    return tot + (ce - cs if ce is not None else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("csv")
+    ap.add_argument("--marker", default="adam")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--skip-last", type=int, default=0)
+    ap.add_argument("--per-step", type=int, default=1)
+    a = ap.parse_args()
+    rows = []
+    for r in csv.DictReader(open(a.csv)):
+        q = r.get("Queue_Id") or r.get("Stream_Id") or "?"
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], q))
+    rows.sort()
+    marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+    if a.skip_last:
+        marks = marks[:-a.skip_last * a.per_step]
+    marks = marks[a.per_step - 1::a.per_step]
+    lo, hi = marks[-a.steps - 1], marks[-1]
+    t0, t1 = rows[lo][1], rows[hi][1]
+    sel = rows[lo + 1:hi + 1]
+    n = a.steps
+    by = collections.defaultdict(list)
+    for s, e, k, q in sel:
+        by[q].append((s, e))
+    print(f"wall {(t1 - t0) / n / 1e6:.3f} ms/step; union of all kernels {union([(s, e) for s, e, _, _ in sel]) / n / 1e6:.3f} ms/step")
+    for q, iv in sorted(by.items(), key=lambda kv: -len(kv[1])):
+        print(f"  queue {q}: {len(iv) / n:.0f} launches/step, sum {sum(e - s for s, e in iv) / n / 1e6:.3f} ms/step, union {union(iv) / n / 1e6:.3f} ms/step")
+    # top kernels of the busiest queue by time
+    main_q = max(by, key=lambda q: len(by[q]))
+    agg = collections.defaultdict(float)
+    for s, e, k, q in sel:
+        if q == main_q:
+            agg[k.split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")] += e - s
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:14]:
+        print(f"     main queue {k:32s} {v / n / 1e6:7.3f} ms/step")
+
+
+if __name__ == "__main__":
+    main()
