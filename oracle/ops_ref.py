@@ -410,7 +410,14 @@ def op_bn_bwd_apply(m: Mem, o):
         coef = m.view(o["COEF"], (3, C))
     else:   # fused form: BN_BWD_FINALIZE's arithmetic
         n = float("inf") if o.get("EVAL", 0) else float(o["COUNT"])   # eval-mode BatchNorm: statistics are constants
-        st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
+        if o.get("PS", -1) >= 0:   # SE_BN_COMBINE folded in
+            ps = m.view(o["PS"], (4, B, C)).double()
+            mul, add = m.view(o["MULBC"], (B, C)), m.view(o["ADDBC"], (B, C))
+            mul = mul.double() if mul is not None else torch.ones(B, C, dtype=torch.float64)
+            add = add.double() * o["ADDSCALE"] if add is not None else torch.zeros(B, C, dtype=torch.float64)
+            st = torch.stack([(mul * ps[0] + add * ps[1]).sum(0), (mul * ps[2] + add * ps[3]).sum(0)])
+        else:
+            st = m.view(o["STATS2"], (max(o["NREP"], 1), 2, C), "f64").sum(0)
         m.view(o["DGAMMA"], (C,)).add_(st[1].to(m.fdtype))
         m.view(o["DBETA"], (C,)).add_(st[0].to(m.fdtype))
         a = (m.view(o["GAMMA"], (C,)) * bnv[3]).double()

@@ -1111,7 +1111,32 @@ struct BnFuse {
     int nrep;
     const float *mulbc, *addbc;   // MODE 3: g' = (GP * mul + add * addscale) * silu'(u) is recomputed here
     float addscale;
+    const float* ps;              // MODE 3: SE_BN_SUMS's plane sums [4][B][C]; the sums over the batch are formed here (SE_BN_COMBINE)
+    int B;
 };
+
+// the channel's two BN-backward sums: from the STATS2 replicas, or (fz.ps) combined from the SE backward's plane sums - the same
+// lane order in every wave, so all waves of a channel agree bit for bit
+__device__ __forceinline__ void bn_fuse_sums(const BnFuse& fz, int C, int c, int lane, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    if (fz.ps) {
+        const int64_t np = (int64_t)fz.B * C;
+        for (int b = lane; b < fz.B; b += 64) {
+            const int64_t pl = (int64_t)b * C + c;
+            const double mul = fz.mulbc ? (double)fz.mulbc[pl] : 1.0, add = fz.addbc ? (double)fz.addbc[pl] * (double)fz.addscale : 0.0;
+            s1 += mul * (double)fz.ps[pl] + add * (double)fz.ps[np + pl];
+            s2 += mul * (double)fz.ps[2 * np + pl] + add * (double)fz.ps[3 * np + pl];
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+    } else if (fz.nrep <= 8) {   // wave-uniform addresses: scalar loads
+        for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+    } else {
+        for (int r = lane; r < fz.nrep; r += 64) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+    }
+}
 
 // MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY; MODE 2 = the same with the coefficients computed here from STATS2;
 // MODE 3 = MODE 2 with gp = (a*mul + add) * silu'(scale*y + shift) recomputed per element, see SE_BN_SUMS);
@@ -1124,6 +1149,14 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
     if (!get_task(HW, nplanes, t)) return;
     const int lane = threadIdx.x & 63;
     const int c = (int)((uint32_t)t.plane % (uint32_t)C);
+    const int64_t base = t.plane * HW + t.start;
+    // the first element group is requested BEFORE the per-channel coefficients are formed (replica / plane sums in f64: a few
+    // dependent L2 round trips), so the stream is already in flight when the arithmetic needs it
+    float4 av0 = make_float4(0, 0, 0, 0), yv0 = make_float4(0, 0, 0, 0);
+    if (VEC && lane < (t.count >> 2)) {
+        if (a) av0 = reinterpret_cast<const float4*>(a + base)[lane];
+        yv0 = reinterpret_cast<const float4*>(y + base)[lane];
+    }
     float k0, k1, k2;  // out = k0*a + k1*y + k2
     float gmul = 1.0f, gadd = 0.0f, bscale = 1.0f, bshift = 0.0f;
     if (MODE == 3) {
@@ -1133,14 +1166,8 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
         bshift = bnv[C + c];
     }
     if (MODE >= 2) {
-        double s1 = 0.0, s2 = 0.0;
-        if (fz.nrep <= 8) {   // wave-uniform addresses: scalar loads
-            for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
-        } else {
-            for (int r = lane; r < fz.nrep; r += 64) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
-            s1 = wave_sum_d(s1);
-            s2 = wave_sum_d(s2);
-        }
+        double s1, s2;
+        bn_fuse_sums(fz, C, c, lane, s1, s2);
         const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
         const double aa = (double)fz.gamma[c] * (double)invstd;
         const float A = (float)aa, Bq = (float)(-aa * s2 * fz.inv_count), Cq = (float)(-aa * s1 * fz.inv_count);   // no f64 divide per wave
@@ -1161,13 +1188,14 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
         else { sc = bnv[c]; sh = bnv[C + c]; }
         k0 = a ? 1.0f : 0.0f; k1 = sc * dcs; k2 = sh * dcs;
     }
-    const int64_t base = t.plane * HW + t.start;
     if (VEC) {
         const int n4 = t.count >> 2;
         for (int i = lane; i < n4; i += 64) {
-            float4 av = make_float4(0, 0, 0, 0);
-            if (a) av = reinterpret_cast<const float4*>(a + base)[i];
-            const float4 yv = reinterpret_cast<const float4*>(y + base)[i];
+            float4 av = av0, yv = yv0;
+            if (i + 64 < n4) {                      // next group in flight while this one is computed and stored
+                if (a) av0 = reinterpret_cast<const float4*>(a + base)[i + 64];
+                yv0 = reinterpret_cast<const float4*>(y + base)[i + 64];
+            }
             if (MODE == 3) {
                 av.x = fmaf(av.x, gmul, gadd) * act_grad(fmaf(yv.x, bscale, bshift), S2K_PRO_SILU);
                 av.y = fmaf(av.y, gmul, gadd) * act_grad(fmaf(yv.y, bscale, bshift), S2K_PRO_SILU);
@@ -1198,14 +1226,8 @@ __global__ void __launch_bounds__(NTHREADS) bn_bwd_apply_small_kernel(const floa
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    if (fz.nrep <= 8) {
-        for (int r = 0; r < fz.nrep; ++r) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
-    } else {
-        for (int r = lane; r < fz.nrep; r += 64) { s1 += fz.st2[(int64_t)r * 2 * C + c]; s2 += fz.st2[(int64_t)r * 2 * C + C + c]; }
-        s1 = wave_sum_d(s1);
-        s2 = wave_sum_d(s2);
-    }
+    double s1, s2;
+    bn_fuse_sums(fz, C, c, lane, s1, s2);
     const float mean = bnv[2 * C + c], invstd = bnv[3 * C + c];
     const double aa = (double)fz.gamma[c] * (double)invstd;
     const float A = (float)aa, Bq = (float)(-aa * s2 * fz.inv_count), Cq = (float)(-aa * s1 * fz.inv_count);
@@ -1328,11 +1350,14 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
         return S2K_OK;
     }
     // no COEF table: the BN_BWD_FINALIZE arithmetic is done here (one launch less per BatchNorm)
-    if (!fz.st2 || !fz.gamma || !fz.dgamma || !fz.dbeta || count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2, GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
+    fz.ps = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_PS]);
+    fz.B = B;
+    if ((!fz.st2 && !fz.ps) || !fz.gamma || !fz.dgamma || !fz.dbeta || count <= 0) { set_error("bn_bwd_apply: fused form needs STATS2 (or PS), GAMMA, DGAMMA, DBETA, COUNT"); return S2K_EINVAL; }
     fz.mulbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_MULBC]);
     fz.addbc = ref_ptr<const float>(c, op.t[S2K_BN_BWD_APPLY_T_ADDBC]);
     fz.addscale = op.f[S2K_BN_BWD_APPLY_F_ADDSCALE];
-    CHECK_PTRS("bn_bwd_apply", fz.mulbc, fz.addbc);
+    CHECK_PTRS("bn_bwd_apply", fz.mulbc, fz.addbc, fz.ps);
+    if (fz.ps && op.d[S2K_BN_BWD_APPLY_D_ACT] != S2K_PRO_SILU) { set_error("bn_bwd_apply: PS belongs to the recomputing (SiLU) form"); return S2K_EINVAL; }
     if (op.d[S2K_BN_BWD_APPLY_D_ACT] == S2K_PRO_NONE && !fz.mulbc && !fz.addbc) {
         if (launch_bn_bwd_apply_small<2>(gp, y, bnv, dy, B, C, HW, c.stream, fz)) return S2K_OK;
         launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);

@@ -128,7 +128,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # recomputed per element (the sums in STATS2 then come from SE_BN_SUMS / SE_BN_COMBINE instead of BN_BWD_REDUCE)
     # EVAL: BatchNorm ran on its running statistics (module.eval()): mean / invstd are constants, so dY = A*g' only (the
     # batch-statistics terms Bq, Cq vanish); DGAMMA / DBETA are the same sums
-    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC"], ["COUNT"],
+    # PS given (recomputing form): the sums are combined here from SE_BN_SUMS's plane sums (SE_BN_COMBINE's arithmetic, done by
+    # every wave for its channel: 6*B values from L2) and STATS2 is not read - one launch less per depthwise BatchNorm
+    "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC", "PS"], ["COUNT"],
                      ["B", "C", "HW", "NREP", "ACT", "EVAL"], ["ADDSCALE"]),
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"] + FOLD_T, FOLD_N, ["B", "C", "HW"] + FOLD_D, ["KEEP"] + FOLD_F),

@@ -417,11 +417,15 @@ def dwconv_bn(p: _P, wname: str, bnprefix: str, src: Act, k: int, stride: int, e
             # two-pass form (csrc/ew.hip, SE_BN_SUMS): the plane sums were collected by the SE backward's pass; combine them
             # with the SE result and let APPLY recompute g' = (d * gate + dpool / HW) * silu'(u) while it streams d and y
             HWo = Ho * Wo
-            st2 = p.aux.alloc("stats2c:" + bnprefix, (1, 2, C), "f64")
-            p.bwd.add("SE_BN_COMBINE", PS=out.se_sums, MULBC=out.mulbc, ADDBC=out.addbc, STATS2=st2, B=B, C=C, ADDSCALE=out.addscale)
             dY = out.grad
+            fold_combine = tune("S2K_SE_COMBINE_IN_APPLY", "1") != "0"     # SE_BN_COMBINE's arithmetic inside APPLY: one launch less
+            st2 = None
+            if not fold_combine:
+                st2 = p.aux.alloc("stats2c:" + bnprefix, (1, 2, C), "f64")
+                p.bwd.add("SE_BN_COMBINE", PS=out.se_sums, MULBC=out.mulbc, ADDBC=out.addbc, STATS2=st2, B=B, C=C, ADDSCALE=out.addscale)
             p.bwd.add("BN_BWD_APPLY", GP=dY, Y=y, BNV=bnv, COEF=None, DY=dY, STATS2=st2, GAMMA=p.param(bnprefix + ".weight"),
                       DGAMMA=p.pgrad(bnprefix + ".weight"), DBETA=p.pgrad(bnprefix + ".bias"), MULBC=out.mulbc, ADDBC=out.addbc,
+                      PS=out.se_sums if fold_combine else None,
                       COUNT=B * HWo, B=B, C=C, HW=HWo, NREP=1, ACT=D.ACT_SILU, ADDSCALE=out.addscale, EVAL=int(not p.training))
         else:
             dY = _bn_backward(p, bnprefix, out.grad, y, bnv, C, Ho * Wo, D.ACT_SILU, out.mulbc, out.addbc, out.addscale)

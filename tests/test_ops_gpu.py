@@ -754,6 +754,15 @@ def test_se_bn_two_pass_stages(B, C, HW):          # (<= 64 elements: channel-pe
     dg, db = c3.t("dgamma", (C,)), c3.t("dbeta", (C,))
     c3.run("BN_BWD_APPLY", ["gp", "dgamma", "dbeta"], 2e-5, GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=gam, DGAMMA=dg, DBETA=db,
            MULBC=mul, ADDBC=add, COUNT=B * HW, B=B, C=C, HW=HW, NREP=1, ACT=D.ACT_SILU, ADDSCALE=1.0 / HW)
+    # the same with SE_BN_COMBINE folded in: APPLY forms the sums from the plane sums itself
+    c4 = Case(27)
+    gp, y = c4.t("gp", (B, C, HW)), c4.t("y", (B, C, HW))
+    bnv, gam = c4.bnv("bnv", C), c4.t("gamma", (C,), "pos")
+    mul, add = c4.t("mul", (B, C), "rand"), c4.t("add", (B, C))
+    ps = c4.t("ps", (4, B, C), scale=3.0)
+    dg, db = c4.t("dgamma", (C,)), c4.t("dbeta", (C,))
+    c4.run("BN_BWD_APPLY", ["gp", "dgamma", "dbeta"], 2e-5, GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=None, GAMMA=gam, DGAMMA=dg, DBETA=db,
+           MULBC=mul, ADDBC=add, PS=ps, COUNT=B * HW, B=B, C=C, HW=HW, NREP=1, ACT=D.ACT_SILU, ADDSCALE=1.0 / HW)
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 5, 6, 8), (1, 3, 7, 5), (2, 16, 28, 28)])

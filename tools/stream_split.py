@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--skip-last", type=int, default=0)
     ap.add_argument("--per-step", type=int, default=1)
+    ap.add_argument("--gap-us", type=float, default=20.0)
     a = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(a.csv)):
@@ -53,6 +54,37 @@ def main():
             agg[k.split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")] += e - s
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:14]:
         print(f"     main queue {k:32s} {v / n / 1e6:7.3f} ms/step")
+    overlap_report(sel, main_q, n, a.gap_us)
+
+
+def overlap_report(sel, main_q, n, gap_us):
+    """time with only the main queue busy / only other queues / both / neither, and the main queue's long gaps (waits at joins)."""
+    ev = []
+    for s, e, _, q in sel:
+        m = 0 if q == main_q else 1
+        ev.append((s, 1, m))
+        ev.append((e, -1, m))
+    ev.sort()
+    cnt = [0, 0]
+    acc = collections.defaultdict(int)
+    last = ev[0][0]
+    for t, d, m in ev:
+        acc[(cnt[0] > 0, cnt[1] > 0)] += t - last
+        last = t
+        cnt[m] += d
+    print("  main only %.3f  side only %.3f  both %.3f  idle %.3f ms/step" % tuple(acc[k] / n / 1e6 for k in ((True, False), (False, True), (True, True), (False, False))))
+    mq = [(s, e, k) for s, e, k, q in sel if q == main_q]
+    side = sorted((s, e) for s, e, _, q in sel if q != main_q)
+    gaps = []
+    for (s0, e0, k0), (s1, e1, k1) in zip(mq, mq[1:]):
+        if s1 - e0 > gap_us * 1000:
+            busy = sum(max(0, min(e, s1) - max(s, e0)) for s, e in side if e > e0 and s < s1)
+            gaps.append((s1 - e0, busy, k0, k1))
+    tot = sum(g[0] for g in gaps)
+    print(f"  main-queue gaps > {gap_us} us: {len(gaps) / n:.1f} per step, {tot / n / 1e6:.3f} ms/step (side busy during {sum(g[1] for g in gaps) / n / 1e6:.3f})")
+    short = lambda k: k.split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")[:28]
+    for g in sorted(gaps, reverse=True)[:12]:
+        print(f"     gap {g[0] / 1e3:8.1f} us (side busy {g[1] / 1e3:7.1f})  after {short(g[2]):28s} before {short(g[3])}")
 
 
 if __name__ == "__main__":
