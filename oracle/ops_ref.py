@@ -659,6 +659,15 @@ def op_patchify(m: Mem, o):
     if inv == 0:
         out.copy_(_patch_cols(x, P, TUB, order))
         return
+    if inv == 4:             # gradient through the standardised target (opdefs.PATCHIFY)
+        tgt = _patch_cols(m.view(o["IMGS"], (B, C, T, H, W)), P, TUB, "mae")      # [B, PD, L]
+        n = tgt.shape[1]
+        mu = tgt.mean(1, keepdim=True)
+        sdev = (tgt.var(1, keepdim=True) + 1.0e-6) ** 0.5
+        g = -out
+        xc = tgt - mu
+        out = (g - g.mean(1, keepdim=True)) / sdev - xc * (g * xc).sum(1, keepdim=True) / (sdev ** 3 * (n - 1))
+        inv = 1
     if order == "conv":      # rows (c, tt, py, px)
         v = out.reshape(B, C, TUB, P, P, T // TUB, H // P, W // P).permute(0, 1, 5, 2, 6, 3, 7, 4)      # b c t tt h py w px
     else:                    # rows (tt, py, px, c)

@@ -90,8 +90,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     int gate_b[PIX ? NBI : 1];  // 1x1: image of the pixel quad (SE gate row)
     int img_b = 0;
     if (PIX) {
-        const bool img_local = (p.HW % BN) == 0;
-        if (img_local) img_b = (nt * BN) / p.HW;
+        img_b = (nt * BN) / p.HW;             // descriptors based at the tile's first image (see igemm.hip)
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
             const int it = tid + NT * i;
@@ -388,10 +387,11 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     const size_t lds = img + (PRO != S2K_PRO_NONE ? (size_t)2 * nchunks * KCH * sizeof(float) : 0);
     if (lds > 160 * 1024) return 1;
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
-        const bool local = !PIX || (p.HW % BN) == 0;
+        // (descriptors are based at the first image a tile touches)
+        const int64_t span = (!PIX || (p.HW % BN) == 0) ? 1 : std::min<int64_t>(p.B, (BN - 2) / p.HW + 2);
         const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
-        const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
-        if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
+        const int64_t need = std::max(img1, img2) * span;
+        if (need >= 0x7ffffff0ll) { set_error("conv: the %lld image(s) one tile touches exceed 2 GiB (%lld B)", (long long)span, (long long)need); return S2K_EINVAL; }
     }
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }

@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
     int st_gate = 0;
     bool st_valid = false;
     int img_b = 0;                                                  // image the activation descriptors are based at
-    const bool img_local = (BMODE == BM_PIX) && (p.HW % BN) == 0;
 
     if (BMODE == BM_PIX) {
         const int n0 = nt * BN;
@@ -104,9 +103,10 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
         const int nn = st_valid ? n : 0;
         const int b = nn / p.HW, pp = nn - b * p.HW;
         st_gate = b * p.C1;
-        // tile inside one image (H*W % BN == 0): the descriptors below are based at that image, offsets stay image-local
-        // (tensors of more than 2 GiB — a 16 x 768 x 224 x 224 gradient — are then addressable with 32-bit offsets)
-        if (img_local) img_b = n0 / p.HW;
+        // the descriptors below are based at the image of the tile's first pixel, so offsets only span the images one tile
+        // touches (one when H*W % BN == 0, else (BN - 2) / HW + 2): tensors of more than 2 GiB — a 16 x 768 x 224 x 224
+        // gradient — are addressable with 32-bit offsets
+        img_b = n0 / p.HW;
         const int brel = b - img_b;
         if (gather) {  // X1 is [B][C1/4][2H][2W]; pseudo-channel k=(co,dy,dx)
             const int yy = pp / p.W, xx = pp - yy * p.W;
@@ -592,10 +592,11 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (lds > 160 * 1024) { set_error("conv: LDS %zu too large", lds); return S2K_EINVAL; }
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
-        const bool local = BMODE == BM_SPATIAL || (p.HW % BN) == 0;
+        // (descriptors are based at the first image a tile touches)
+        const int64_t span = (BMODE == BM_SPATIAL || (p.HW % BN) == 0) ? 1 : std::min<int64_t>(p.B, (BN - 2) / p.HW + 2);
         const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
-        const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
-        if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
+        const int64_t need = std::max(img1, img2) * span;
+        if (need >= 0x7ffffff0ll) { set_error("conv: the %lld image(s) one tile touches exceed 2 GiB (%lld B)", (long long)span, (long long)need); return S2K_EINVAL; }
     }
     if (BMODE == BM_SPATIAL && p.IR * p.WS > NTHREADS * EPT) { set_error("conv: halo tile exceeds EPT"); return S2K_EINVAL; }
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;

@@ -82,8 +82,7 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
         if (BMODE == BM_PIX) {
             const int n = nt * BN + 4 * j4;
             const bool ok = n < p.Ntot;
-            const bool img_local = (p.HW % BN) == 0;
-            if (img_local) img_b = (nt * BN) / p.HW;
+            img_b = (nt * BN) / p.HW;         // descriptors based at the tile's first image (see igemm.hip)
             const int nn = ok ? n : 0;
             const int b = nn / p.HW, pp = nn - b * p.HW;
             bvoff = ok ? (uint32_t)((int64_t)(b - img_b) * p.C1 * p.HW + pp) * 4u : BUF_OOB;
@@ -329,10 +328,11 @@ static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     static_assert((THIN ? 8 : 4) * BM * sizeof(float) <= lds, "statistics rows fit in the image");
     p.n_mtiles = cdiv(p.M, BM);
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
-        const bool local = BMODE == BM_SPATIAL || (p.HW % BNP) == 0;
+        // (descriptors are based at the first image a tile touches)
+        const int64_t span = (BMODE == BM_SPATIAL || (p.HW % BNP) == 0) ? 1 : std::min<int64_t>(p.B, (BNP - 2) / p.HW + 2);
         const int64_t img1 = (int64_t)p.C1 * p.H * p.W * 4, img2 = (int64_t)p.C2 * p.H * p.W * 4;
-        const int64_t need = std::max(img1, img2) * (local ? 1 : p.B);
-        if (need >= 0x7ffffff0ll) { set_error("conv: activation %s larger than 2 GiB (%lld B)", local ? "image" : "tensor", (long long)need); return S2K_EINVAL; }
+        const int64_t need = std::max(img1, img2) * span;
+        if (need >= 0x7ffffff0ll) { set_error("conv: the %lld image(s) one tile touches exceed 2 GiB (%lld B)", (long long)span, (long long)need); return S2K_EINVAL; }
     }
     const int64_t blocks = (int64_t)p.n_mtiles * n_ntiles;
     if (blocks <= 0 || blocks > 0x7fffffff) { set_error("conv: bad grid %lld", (long long)blocks); return S2K_EINVAL; }

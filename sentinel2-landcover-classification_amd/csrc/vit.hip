@@ -481,16 +481,63 @@ __global__ void patchify_kernel(const PatchP p, int inverse, int order, int ls, 
     }
 }
 
+// PATCHIFY INVERSE 4: the gradient w.r.t. the images through the standardised loss target.  One wave per patch, lanes along the
+// PD features (order (tt, py, px, c)): mean, centred sum of squares (two passes, as torch.var), then the two sums over g = -OUT,
+// then the PD gradient values.  Every pixel belongs to exactly one patch, so DX is written, not accumulated.
+__global__ void __launch_bounds__(NTHREADS) patch_norm_target_grad_kernel(const PatchP p, const float* imgs, float* dx, const float* gpred,
+                                                                         int ls, int l_off) {
+    const int lane = threadIdx.x & 63;
+    const int64_t patch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (patch >= (int64_t)p.B * p.L) return;
+    const int b = (int)(patch / p.L), l = (int)(patch % p.L);
+    const int w = l % p.gw, h = (l / p.gw) % p.gh, t = l / (p.gw * p.gh);
+    const int64_t base = (((int64_t)b * p.C * p.T + (int64_t)t * p.TUB) * p.H + (int64_t)h * p.P) * p.W + (int64_t)w * p.P;
+    const int64_t cstride = (int64_t)p.T * p.H * p.W;
+    auto pix = [&](int f) -> int64_t {
+        const int cc = f % p.C, px = (f / p.C) % p.P, py = (f / (p.C * p.P)) % p.P, tt = f / (p.C * p.P * p.P);
+        return base + (int64_t)cc * cstride + ((int64_t)tt * p.H + py) * p.W + px;
+    };
+    const float* g = gpred + (int64_t)b * p.PD * ls + l + l_off;
+    double s = 0.0;
+    for (int f = lane; f < p.PD; f += 64) s += (double)imgs[pix(f)];
+    const double mu = wave_sum_d(s) / p.PD;
+    double q = 0.0, sg = 0.0, sgx = 0.0;
+    for (int f = lane; f < p.PD; f += 64) {
+        const double xc = (double)imgs[pix(f)] - mu, gv = -(double)g[(int64_t)f * ls];
+        q += xc * xc;
+        sg += gv;
+        sgx += gv * xc;
+    }
+    q = wave_sum_d(q);
+    sg = wave_sum_d(sg);
+    sgx = wave_sum_d(sgx);
+    const double sd = sqrt(q / (p.PD - 1) + 1.0e-6);
+    const double inv = 1.0 / sd, gm = sg / p.PD, k = sgx / (sd * sd * sd * (p.PD - 1));
+    for (int f = lane; f < p.PD; f += 64) {
+        const int64_t xi = pix(f);
+        const double xc = (double)imgs[xi] - mu, gv = -(double)g[(int64_t)f * ls];
+        dx[xi] = (float)((gv - gm) * inv - xc * k);
+    }
+}
+
 int launch_patchify(const S2kOp& op, const Ctx& c) {
     PatchP p{};
     if (int e = fill_patch(p, op.d)) return e;
     p.x = ref_ptr<const float>(c, op.t[S2K_PATCHIFY_T_X]);
     p.out = ref_ptr<float>(c, op.t[S2K_PATCHIFY_T_OUT]);
-    CHECK_PTRS("patchify", p.x, p.out);
+    const float* imgs = ref_ptr<const float>(c, op.t[S2K_PATCHIFY_T_IMGS]);
+    CHECK_PTRS("patchify", p.x, p.out, imgs);
     if (!p.x || !p.out) { set_error("patchify: missing tensor"); return S2K_EINVAL; }
     const int inverse = op.d[S2K_PATCHIFY_D_INVERSE], order = op.d[S2K_PATCHIFY_D_ORDER], l_off = op.d[S2K_PATCHIFY_D_L_OFF];
     const int ls = op.d[S2K_PATCHIFY_D_LS] > 0 ? op.d[S2K_PATCHIFY_D_LS] : p.L;
-    if (inverse < 0 || inverse > 3 || order < 0 || order > 1 || l_off < 0 || ls < p.L + l_off) { set_error("patchify: bad mode / stride"); return S2K_EINVAL; }
+    if (inverse < 0 || inverse > 4 || order < 0 || order > 1 || l_off < 0 || ls < p.L + l_off) { set_error("patchify: bad mode / stride"); return S2K_EINVAL; }
+    if (inverse == 4) {
+        if (!imgs || order != 1 || p.PD < 2) { set_error("patchify: the standardised-target gradient needs IMGS, ORDER 1 and PD >= 2"); return S2K_EINVAL; }
+        const int64_t npatch = (int64_t)p.B * p.L;
+        hipLaunchKernelGGL(patch_norm_target_grad_kernel, dim3((unsigned)cdiv64(npatch, 4)), dim3(NTHREADS), 0, c.stream, p, imgs,
+                           const_cast<float*>(p.x), p.out, ls, l_off);
+        return S2K_OK;
+    }
     const int64_t n = (int64_t)p.B * p.PD * p.L;
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n, 256), 16384)), dim3(256), 0, c.stream, p, inverse, order, ls, l_off);
     return S2K_OK;

@@ -171,13 +171,11 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
             const int b = (int)(nn / p.HWp);
             const int pp = (int)(nn - (int64_t)b * p.HWp);
             f_b = b;
-            int brel = b;
-            if (img_local) {
-                const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);      // image of this pixel tile (uniform)
-                rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
-                rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
-                brel = b - bt;
-            }
+            // descriptors based at the first image this pixel tile touches (uniform): offsets span the tile's images only
+            const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);
+            rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - bt) * p.M * p.HWp * 4);
+            rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - bt) * p.C * p.HWq * 4);
+            const int brel = b - bt;
             // per-lane part (image, pixel; or out of range) in the vector offset, the row / channel part in the scalar
             // offset (clamped into the tensor: rows and channels past the end only feed discarded outputs)
             const int prow_u = __builtin_amdgcn_readfirstlane(prow);
@@ -393,9 +391,9 @@ static int launch_wg2(WgradP& p, hipStream_t st) {
     p.PSTR = NPJ + 1;                                                               // compile-time strides in the kernel
     p.CSQ = (MODE == WG_SPATIAL) ? NTHREADS * EPT + 1 : (MODE == WG_GATHER ? 4 * NPJ + 1 : NPJ + 1);
     {   // 32-bit buffer offsets: one image must stay below 2 GiB when tiles are image-local, else the whole tensor
-        const bool local = (MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0;
-        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
-        if (need >= 0x7ffffff0ll) { set_error("wgrad: activation %s larger than 2 GiB", local ? "image" : "tensor"); return S2K_EINVAL; }
+        const int64_t span = ((MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0) ? 1 : std::min<int64_t>(p.B, (NPJ - 2) / p.HWp + 2);   // images one pixel tile touches
+        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * span;
+        if (need >= 0x7ffffff0ll) { set_error("wgrad: the %lld image(s) one pixel tile touches exceed 2 GiB", (long long)span); return S2K_EINVAL; }
     }
     const size_t lds = ((size_t)BM * p.PSTR + (size_t)BC * p.CSQ + 2 * (BM + BC)) * sizeof(float);
     if (p.gatep || (p.gateq && MODE != WG_PIX)) { set_error("wgrad: SE gate is only supported on the Q operand of 1x1 convs"); return S2K_EINVAL; }

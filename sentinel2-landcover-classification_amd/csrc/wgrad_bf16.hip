@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
     auto fetch = [&](int tile) {
         int tb = 0, y0 = 0, x0 = 0;
         if (PIX) {
-            if (img_local) tb = (int)(((int64_t)tile * NPJ) / p.HWp);
+            tb = (int)(((int64_t)tile * NPJ) / p.HWp);      // first image the tile touches: offsets span the tile's images only
         } else {
             const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y;
             tb = tile / (p.tiles_x * p.tiles_y);
@@ -327,8 +327,8 @@ static int launch_wb16(WgradP& p, hipStream_t st) {
         p.NP = 0;
     }
     {   // 32-bit buffer offsets: one image below 2 GiB when tiles are image-local, else the whole tensor
-        const bool local = !PIX || (p.HWp % NPJ) == 0;
-        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
+        const int64_t span = (!PIX || (p.HWp % NPJ) == 0) ? 1 : std::min<int64_t>(p.B, (NPJ - 2) / p.HWp + 2);   // images one pixel tile touches
+        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * span;
         if (need >= 0x7ffffff0ll) return 1;
     }
     auto kern = wgrad_bf16_kernel<MODE, WVM, WVC, WM, WN, R, XW>;

@@ -153,13 +153,11 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
                 const int64_t nn = f_pok ? n : 0;
                 const int b = (int)(nn / p.HWp);
                 const int pp = (int)(nn - (int64_t)b * p.HWp);
-                int brel = b;
-                if (img_local) {
-                    const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);      // image of this pixel tile (uniform)
-                    rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
-                    rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
-                    brel = b - bt;
-                }
+                // descriptors based at the first image this pixel tile touches (uniform): offsets span the tile's images only
+                const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);
+                rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - bt) * p.M * p.HWp * 4);
+                rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - bt) * p.C * p.HWq * 4);
+                const int brel = b - bt;
                 pvoff[0] = f_pok ? (uint32_t)((int64_t)brel * p.M * p.HWp + pp) * 4u : BUF_OOB;
                 qvoff[0] = f_pok ? (uint32_t)((int64_t)brel * p.C * p.HWq + pp) * 4u : BUF_OOB;
                 f_qok = f_pok;
@@ -335,9 +333,9 @@ static int launch_pc2(WgradP& p, hipStream_t st) {
     p.n_mtiles = cdiv(p.M, BM);
     p.n_ctiles = cdiv(p.C, BC);
     {   // 32-bit buffer offsets: one image must stay below 2 GiB when tiles are image-local, else the whole tensor
-        const bool local = (MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0;
-        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * (local ? 1 : p.B);
-        if (need >= 0x7ffffff0ll) { set_error("wgrad: activation %s larger than 2 GiB", local ? "image" : "tensor"); return S2K_EINVAL; }
+        const int64_t span = ((MODE == WG_SPATIAL) || (p.HWp % NPJ) == 0) ? 1 : std::min<int64_t>(p.B, (NPJ - 2) / p.HWp + 2);   // images one pixel tile touches
+        const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * span;
+        if (need >= 0x7ffffff0ll) { set_error("wgrad: the %lld image(s) one pixel tile touches exceed 2 GiB", (long long)span); return S2K_EINVAL; }
     }
     if (p.gatep || p.gateq) { set_error("wgrad (pc): SE gates stay on the generic kernels"); return S2K_EINVAL; }
     const size_t lds = (size_t)2 * (NPJ * (BM + 4) + USED * (BC + 4)) * sizeof(float);

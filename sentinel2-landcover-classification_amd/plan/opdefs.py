@@ -185,7 +185,10 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # gradient of the patch columns into the gradient w.r.t. the images
     # INVERSE 2: X = -OUT, 3: X += OUT.  ORDER 1: row index (tt, py, px, c) — the MAE loss target's feature order (prithvi.py:236-245)
     # instead of the Conv3d weight's (c, tt, py, px).  LS / L_OFF: row stride (0 = L) and first column of OUT's patches.
-    "PATCHIFY": (["X", "OUT"], [], ["B", "C", "T", "H", "W", "P", "TUB", "INVERSE", "ORDER", "LS", "L_OFF"], []),
+    # INVERSE 4 (ORDER 1): X = the gradient w.r.t. the images through the per-patch STANDARDISED loss target (norm_pix_loss,
+    # prithvi.py:341-344): with g = -OUT (d loss / d target), x = the patch of IMGS, n = PD, mu / v = its mean / unbiased variance,
+    # s = sqrt(v + 1e-6):   X_j = (g_j - mean(g)) / s - (x_j - mu) * sum_i g_i (x_i - mu) / (s^3 (n - 1))
+    "PATCHIFY": (["X", "OUT", "IMGS"], [], ["B", "C", "T", "H", "W", "P", "TUB", "INVERSE", "ORDER", "LS", "L_OFF"], []),
     # MAE loss (prithvi.py:333-350).  PRED is feature-major [B][PD][LP], token l in column l + L_OFF, feature order
     # (tt, py, px, c).  LOSS[0] = sum_l MASK * mean_f (PRED - target)^2 / sum MASK;  NORM_PIX: per-patch standardised target
     "MAE_LOSS_FWD": (["PRED", "IMGS", "MASK", "LOSS", "ACC"], [],

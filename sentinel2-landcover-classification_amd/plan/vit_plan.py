@@ -444,10 +444,10 @@ def _plan_mae(s: MaeSpec, B: int, mask_ratio: float, training: bool, layout, buc
         if x_dx is not None:
             # the loss also depends on the images through its TARGET (patchify(imgs), prithvi.py:340): d loss / d target = -d loss /
             # d pred; written first (it covers every pixel), the encoder's part is added at the end of the backward
-            if s.norm_pix_loss:
-                raise NotImplementedError("gradient w.r.t. the images through the per-patch normalised target (norm_pix_loss)")
-            p.bwd.add("PATCHIFY", X=x_dx, OUT=g_pred, B=B, C=s.in_chans, T=s.num_frames, H=s.img_size, W=s.img_size, P=s.patch_size,
-                      TUB=s.tubelet_size, INVERSE=2, ORDER=1, LS=NDS, L_OFF=1)
+            # (norm_pix_loss: through the per-patch standardisation as well, PATCHIFY INVERSE 4)
+            p.bwd.add("PATCHIFY", X=x_dx, OUT=g_pred, IMGS=x_img if s.norm_pix_loss else None, B=B, C=s.in_chans, T=s.num_frames,
+                      H=s.img_size, W=s.img_size, P=s.patch_size, TUB=s.tubelet_size, INVERSE=4 if s.norm_pix_loss else 2, ORDER=1,
+                      LS=NDS, L_OFF=1)
         g_user = p.alloc("g:pred_user", (B, PD, NDS))
         p.bwd.add("TRANSPOSE_CL", X=d_pred, Y=g_user, B=B, C=Lp, L=PD, L_OFF=0, LOUT=PD, YS=NDS, Y_OFF=1)
         p.bwd.add("AXPY", X=g_user, Y=g_pred, COUNT=B * PD * NDS)

@@ -55,10 +55,13 @@ def test_unet_input_gradient(train):
     assert model.out_conv1x1.weight.grad is None
 
 
-def test_mae_input_gradient_and_gradient_through_pred():
+@pytest.mark.parametrize("norm_pix", [False, True])
+def test_mae_input_gradient_and_gradient_through_pred(norm_pix):
+    """norm_pix_loss: the target's per-patch standardisation depends on the images too (prithvi.py:341-344)"""
     tag = "small_t3_bs2"
     cfg, sd, x, noise, ratio = mae_inputs(tag)
-    model = MaskedAutoencoderViT(**MAE_CASES[tag][0])
+    cfg.norm_pix_loss = norm_pix
+    model = MaskedAutoencoderViT(**{**MAE_CASES[tag][0], "norm_pix_loss": norm_pix})
     model.load_state_dict(sd)
     model.to(DEV)
     model.masking_noise = noise

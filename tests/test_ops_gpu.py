@@ -721,6 +721,17 @@ def test_wgrad3x3_reads_past_2gib():
           KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=H, PROP=0, PROQ=0, MODE=D.MODE_CONV)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv1x1_and_wgrad1x1_straddling_tiles_past_2gib(bf16):
+    """H*W = 220 * 222 is no multiple of any pixel-tile width (48840 = 8 * 6105), so tiles straddle two images; the tensor
+    (15 x 768 x 220 x 222 x 4 B = 2.1 GiB) does not fit 32-bit offsets from its start: the descriptors are based at the first
+    image each tile touches."""
+    B, C, H, W, M = 15, 768, 220, 222, 8
+    assert B * C * H * W * 4 > 2 ** 31 and (H * W) % 64 != 0 and (H * W) % 8 == 0
+    _conv_case(B, C, 0, H, W, M, 1, 1, 0, 0, H, W, D.PRO_NONE, 0, False, bias=False, stats=False, seed=35, bf16=bf16)
+    _wgrad_case(B, M, C, C, 0, H, W, 1, 1, 0, 0, H, W, 0, 0, False, seed=36, bf16=bf16)
+
+
 def test_convt_wgrad_gather_reads_past_2gib():
     B, Cout, H2 = _big()
     H, Cin = H2 // 2, 8

@@ -49,31 +49,35 @@ def _compare_tensors(plan, ws_gpu_bytes, bases_cpu, names, what):
     assert not bad, f"{what}: first diverging tensors: {bad[:6]}"
 
 
-@pytest.mark.parametrize("version,C,H,B", [("b0", 6, 64, 2), ("b0", 4, 96, 1), ("b3", 13, 64, 2)])
-def test_programs_stage_by_stage_vs_emulator(version, C, H, B):
+@pytest.mark.parametrize("version,C,H,W,B", [
+    ("b0", 6, 64, 64, 2), ("b0", 4, 96, 96, 1), ("b3", 13, 64, 64, 2),
+    ("b0", 6, 64, 160, 2),         # non-square tiles (H != W at every level: 2 x 5 deepest maps)
+    ("b7", 13, 64, 96, 2),         # the widest variant: 3,840-channel expands, 160-wide SE squeezes, 55 blocks (reference _test() loops b0-b7,
+])                                 # efficientnet_unet.py:415-439)
+def test_programs_stage_by_stage_vs_emulator(version, C, H, W, B):
     from s2lc_amd import _lib, engine
 
     ncls = 4
     model, net, sd = _model(version, C, ncls, seed=31)
-    x = detgen.normal("gpu.x", (B, C, H, H), seed=31)
-    y = detgen.labels("gpu.y", (B, H, H), ncls, seed=31)
+    x = detgen.normal("gpu.x", (B, C, H, W), seed=31)
+    y = detgen.labels("gpu.y", (B, H, W), ncls, seed=31)
     noise = detgen.uniform("gpu.dc", (len(net.blocks), B), 0.0, 1.0, seed=31)
-    plan = model._make_plan(B, H, H, True)
-    bases_cpu = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * H)
+    plan = model._make_plan(B, H, W, True)
+    bases_cpu = make_bases(plan, model._flat_params, model._flat_bufs, x, noise, B * ncls * H * W)
     emulate(plan.fwd.pack(), bases_cpu)
 
     dev = torch.device("cuda:0")
     model.to(dev).train()
-    eng = engine.UnetEngine(model, B, H, H, True, dev)
+    eng = engine.UnetEngine(model, B, H, W, True, dev)
     eng.ws.view(torch.float32)[: eng.ws.numel() // 4].fill_(float("nan"))
-    out = torch.empty(B, ncls, H, H, device=dev)
+    out = torch.empty(B, ncls, H, W, device=dev)
     xg, ng = x.to(dev), noise.to(dev)
     st = torch.cuda.current_stream().cuda_stream
     _lib.run(eng.fwd, eng.bases(model, xg, out, noise=ng), st)
     torch.cuda.synchronize()
     fwd_names = [n for n in plan.tensors if not n.startswith(("g:", "gp:", "coef:", "dgate:", "dpool:", "hs:"))]
     _compare_tensors(plan, eng.ws.cpu(), bases_cpu, fwd_names, "forward")
-    ref_logits = bases_cpu[D.BASE["OUT"]].view(torch.float32).view(B, ncls, H, H)
+    ref_logits = bases_cpu[D.BASE["OUT"]].view(torch.float32).view(B, ncls, H, W)
     assert rel_err(out.cpu().numpy(), ref_logits.numpy()) < 1e-3
     bufs_ref = bases_cpu[D.BASE["BUFS"]].view(torch.float32)
     assert rel_err(model._flat_bufs.cpu().numpy(), bufs_ref.numpy()) < 1e-4

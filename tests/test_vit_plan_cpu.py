@@ -223,10 +223,12 @@ def test_method_plans_match_oracle_float64():
     assert torch.equal(m.view(gx.ref, gx.shape), xt.grad)
 
 
-def test_mae_input_gradient_program_float64():
+@pytest.mark.parametrize("norm_pix", [False, True])
+def test_mae_input_gradient_program_float64(norm_pix):
     """want_dx: d loss / d imgs = the encoder path (inverse patchify of the patch-embed data gradient) + the loss TARGET path
     (the reference's forward_loss differentiates patchify(imgs) too); plus an upstream gradient on pred."""
     cfg, sd, x, noise, ratio = mae_inputs("small_t3_bs2")
+    cfg.norm_pix_loss = norm_pix       # (the target's per-patch standardisation is differentiated too, prithvi.py:341-344)
     B = x.shape[0]
     spec = _mae_spec(cfg)
     plan = V.plan_mae(spec, B, ratio, True, want_dx=True)
