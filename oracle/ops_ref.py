@@ -781,6 +781,15 @@ def op_space_to_depth(m: Mem, o):
     m.view(o["Y"], (B, 4 * C, H, W)).copy_(_unshuffle2(m.view(o["X"], (B, C, 2 * H, 2 * W))))
 
 
+def op_im2col(m: Mem, o):
+    B, C, H, W, KH, KW, S, PT, PL, HO, WO = (o[k] for k in ("B", "C", "H", "W", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO"))
+    x = m.view(o["X"], (B, C, H, W))
+    pb, pr = (HO - 1) * S + KH - H - PT, (WO - 1) * S + KW - W - PL
+    xp = F.pad(x, (PL, max(pr, 0), PT, max(pb, 0)))[:, :, :(HO - 1) * S + KH, :(WO - 1) * S + KW]
+    cols = F.unfold(xp, (KH, KW), stride=S)                      # [B, C*KH*KW, HO*WO], rows ordered (c, ky, kx)
+    m.view(o["Y"], (B, C * KH * KW, HO * WO)).copy_(cols)
+
+
 def op_tile_prep(m: Mem, o):
     """crop -> flips -> normalise (two separately rounded fp32 steps, as numpy's `img -= mean; img *= denominator`) + label LUT"""
     B, C, H, W, S, N = o["B"], o["C"], o["H"], o["W"], o["S"], o["NSRC"]
@@ -824,7 +833,7 @@ DISPATCH = {
     "CHAN_LN_FWD": op_chan_ln_fwd, "CHAN_LN_BWD": op_chan_ln_bwd, "ACT_BWD": op_act_bwd, "ACT_FWD": op_act_fwd, "ATTN_FWD": op_attn_fwd,
     "ATTN_BWD": op_attn_bwd, "TILE_PREP": op_tile_prep, "SPACE_TO_DEPTH": op_space_to_depth, "SE_FC_WGRAD": op_se_fc_wgrad, "SE_BN_SUMS": op_se_bn_sums, "SE_BN_COMBINE": op_se_bn_combine, "MAE_MASK_INDEX": op_mae_mask_index, "TOKEN_GATHER": op_token_gather,
     "TOKEN_SCATTER": op_token_scatter, "PATCHIFY": op_patchify, "MAE_LOSS_FWD": op_mae_loss_fwd,
-    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "IDS_TO_DEC_IDX": op_ids_to_dec_idx, "UPSAMPLE_ZERO": op_upsample_zero, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion,
+    "MAE_LOSS_BWD": op_mae_loss_bwd, "TRANSPOSE_CL": op_transpose_cl, "IDS_TO_DEC_IDX": op_ids_to_dec_idx, "UPSAMPLE_ZERO": op_upsample_zero, "DROP_GATE": op_drop_gate, "CONFUSION": op_confusion, "IM2COL": op_im2col,
 }
 
 

@@ -1442,6 +1442,54 @@ int launch_space_to_depth(const S2kOp& op, const Ctx& c) {
     return S2K_OK;
 }
 
+// ---------------- patch columns of a strided dense conv (IM2COL) ----------------------------------------------------------------
+// one thread: 4 consecutive output columns of one (b, k, yo) row -> one float4 store; the strided reads of neighbouring lanes fall
+// into the same cache lines.  Bounds-checked buffer loads give the zero padding.
+__global__ void __launch_bounds__(NTHREADS) im2col_kernel(const float* x, float* y, int C, int H, int W, int KH, int KW, int S, int PT, int PL,
+                                                          int HO, int WO, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x;     // over (b, k, yo, xq)
+    if (i >= total) return;
+    const int wq = (WO + 3) >> 2;
+    const int xq = (int)(i % wq);
+    int64_t r = i / wq;
+    const int yo = (int)(r % HO); r /= HO;
+    const int K = C * KH * KW;
+    const int k = (int)(r % K);
+    const int64_t b = r / K;
+    const int kx = k % KW, ky = (k / KW) % KH, c = k / (KW * KH);
+    const int iy = yo * S + ky - PT;
+    const float* src = x + ((b * C + c) * H) * (int64_t)W;             // the (b, c) plane: offsets below stay inside 32 bits (H * W * 4 < 2 GiB)
+    const rsrc_t rs = make_rsrc(src, (int64_t)H * W * 4);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ix = (4 * xq + j) * S + kx - PL;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[j] = bload(rs, ok ? (uint32_t)(iy * W + ix) * 4u : BUF_OOB);
+    }
+    float* dst = y + ((b * K + k) * HO + yo) * (int64_t)WO + 4 * xq;
+    if ((WO & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * xq + j < WO) dst[j] = v[j];
+}
+
+int launch_im2col(const S2kOp& op, const Ctx& c) {
+    const float* x = ref_ptr<const float>(c, op.t[S2K_IM2COL_T_X]);
+    float* y = ref_ptr<float>(c, op.t[S2K_IM2COL_T_Y]);
+    CHECK_PTRS("im2col", x, y);
+    const int32_t* d = op.d;
+    const int B = d[S2K_IM2COL_D_B], C = d[S2K_IM2COL_D_C], H = d[S2K_IM2COL_D_H], W = d[S2K_IM2COL_D_W], KH = d[S2K_IM2COL_D_KH], KW = d[S2K_IM2COL_D_KW];
+    const int S = d[S2K_IM2COL_D_STRIDE], PT = d[S2K_IM2COL_D_PAD_T], PL = d[S2K_IM2COL_D_PAD_L], HO = d[S2K_IM2COL_D_HO], WO = d[S2K_IM2COL_D_WO];
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || S <= 0 || HO <= 0 || WO <= 0 || PT < 0 || PL < 0 ||
+        (int64_t)H * W * 4 >= 0x7ffffff0ll) { set_error("im2col: bad args"); return S2K_EINVAL; }
+    const int64_t total = (int64_t)B * C * KH * KW * HO * ((WO + 3) >> 2);
+    if (cdiv64(total, NTHREADS) > 0x7fffffffll) { set_error("im2col: grid too large"); return S2K_EINVAL; }
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)cdiv64(total, NTHREADS)), dim3(NTHREADS), 0, c.stream, x, y, C, H, W, KH, KW, S, PT, PL, HO, WO, total);
+    return S2K_OK;
+}
+
 // ---------------- zero-insertion upsampling (data gradient of a strided dense conv; only planned for input gradients) ------
 __global__ void upsample_zero_kernel(const float* x, float* y, int H, int W, int S, int HO, int WO, int64_t total) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -70,6 +70,7 @@ int launch_space_to_depth(const S2kOp&, const Ctx&);
 int launch_se_fc_wgrad(const S2kOp&, const Ctx&);
 int launch_ids_to_dec_idx(const S2kOp&, const Ctx&);
 int launch_upsample_zero(const S2kOp&, const Ctx&);
+int launch_im2col(const S2kOp&, const Ctx&);
 int launch_adam(float*, const float*, float*, float*, int64_t, double, double, double, double, double, int, hipStream_t);
 int launch_mfma_selftest(const float*, const float*, float*, hipStream_t);
 
@@ -91,7 +92,7 @@ static const char* const kNames[S2K_N_KINDS + 1] = {
     "BN_RESIDUAL", "CHANNEL_SUM", "LOSS_FWD", "LOSS_BWD", "ARGMAX", "CHAN_LN_FWD", "CHAN_LN_BWD", "ACT_BWD", "ACT_FWD",
     "ATTN_FWD", "ATTN_BWD", "MAE_MASK_INDEX", "IDS_TO_DEC_IDX", "TOKEN_GATHER", "TOKEN_SCATTER", "PATCHIFY", "MAE_LOSS_FWD",
     "MAE_LOSS_BWD", "TRANSPOSE_CL", "CONFUSION", "DROP_GATE", "TILE_PREP", "SE_BN_SUMS", "SE_BN_COMBINE", "SPACE_TO_DEPTH",
-    "UPSAMPLE_ZERO", "SE_FC_WGRAD"};
+    "UPSAMPLE_ZERO", "SE_FC_WGRAD", "IM2COL"};
 
 static int dispatch(const S2kOp& op, const Ctx& c) {
     switch (op.kind) {
@@ -145,6 +146,7 @@ static int dispatch(const S2kOp& op, const Ctx& c) {
         case S2K_OP_SE_FC_WGRAD: return launch_se_fc_wgrad(op, c);
         case S2K_OP_IDS_TO_DEC_IDX: return launch_ids_to_dec_idx(op, c);
         case S2K_OP_UPSAMPLE_ZERO: return launch_upsample_zero(op, c);
+        case S2K_OP_IM2COL: return launch_im2col(op, c);
         default: set_error("unknown stage kind %d", op.kind); return S2K_ENOSYS;
     }
 }

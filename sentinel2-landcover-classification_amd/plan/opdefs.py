@@ -226,6 +226,11 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # parameter gradients of the two SE Linears from what SE_FC_BWD left behind (DGP = its DGATE, DHP = its HPRE, HS):
     #   DW2[c][j] += sum_b DGP[b][c]*HS[b][j];  DB2 += sum_b DGP;  DW1[j][c] += sum_b DHP[b][j]*POOL[b][c];  DB1 += sum_b DHP
     "SE_FC_WGRAD": (["DGP", "HS", "DHP", "POOL", "DW1", "DB1", "DW2", "DB2"], [], ["B", "C", "CSQ"], []),
+    # Y[b][(c*KH + ky)*KW + kx][yo][xo] = X[b][c][yo*S + ky - PT][xo*S + kx - PL]   (zero outside X): the patch columns of a
+    # STRIDED dense conv (the stem: 13 -> 48 channels, 3x3, stride 2).  The conv and its weight gradient then are 1x1 contractions
+    # over C*KH*KW pseudo-channels - the parameter's own [M][C][KH][KW] layout is that 1x1 weight - on the fast pixel-tile kernels
+    # instead of the generic strided path (17 - 24 TF/s there; the weight gradient was the last, fully exposed stage of a step)
+    "IM2COL": (["X", "Y"], [], ["B", "C", "H", "W", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO"], []),
 }
 # Tensor slots a stage WRITES (everything else it only reads).  Used by the planner's side-stream hazard pass (unet_plan.finish_plan:
 # a main-stream stage that writes what an outstanding side-stream stage still reads must wait for the side stream first); a kind
@@ -242,7 +247,7 @@ WRITES: dict[str, tuple[str, ...]] = {
     "IDS_TO_DEC_IDX": ("DEC_IDX",), "TOKEN_GATHER": ("OUT",), "TOKEN_SCATTER": ("DIN", "DFILL"), "PATCHIFY": ("X", "OUT"),
     "MAE_LOSS_FWD": ("LOSS", "ACC"), "MAE_LOSS_BWD": ("DPRED",), "TRANSPOSE_CL": ("Y",), "CONFUSION": ("HIST",), "DROP_GATE": ("GATE",),
     "TILE_PREP": ("X", "Y"), "SE_BN_SUMS": ("DGATE", "PS"), "SE_BN_COMBINE": ("STATS2",), "SPACE_TO_DEPTH": ("Y",), "UPSAMPLE_ZERO": ("Y",),
-    "SE_FC_WGRAD": ("DW1", "DB1", "DW2", "DB2"),
+    "SE_FC_WGRAD": ("DW1", "DB1", "DW2", "DB2"), "IM2COL": ("Y",),
 }
 for _k, _w in WRITES.items():
     assert _k in OPS and all(x in OPS[_k][0] for x in _w), _k

@@ -329,6 +329,16 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
     """Dense conv (+bias) -> train/eval BatchNorm -> activation, output left virtual."""
     B = p.B
     Ho, Wo, pt, pl = _conv_geometry(srcs[0], k, stride, same)
+    s0 = srcs[0]
+    if (stride > 1 and k > 1 and len(srcs) == 1 and s0.pro == D.PRO_NONE and s0.gate is None and not s0.needs_grad
+            and tune("S2K_STEM_IM2COL", "1") != "0"):
+        # a STRIDED dense conv (the stem) as patch columns + a 1x1 contraction over C*k*k pseudo-channels (opdefs.IM2COL): the
+        # parameter's [M][C][k][k] layout is the 1x1 weight [M][C*k*k], its gradient accumulates straight into the gradient buffer
+        # and the columns written in the forward pass serve the weight gradient again.  (With a gradient w.r.t. the source wanted,
+        # the strided path below and its zero-insertion data gradient stay.)
+        col = p.alloc("col:" + wname, (B, s0.C * k * k, Ho, Wo))
+        p.fwd.add("IM2COL", X=s0.raw, Y=col, B=B, C=s0.C, H=s0.H, W=s0.W, KH=k, KW=k, STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo)
+        return conv_bn(p, wname, bnprefix, [Act(col, s0.C * k * k, Ho, Wo, needs_grad=False)], M, 1, 1, False, act, eps, mom, bias)
     y = p.alloc("y:" + wname, (B, M, Ho, Wo))
     stats = _stats(p, "stats:" + bnprefix, M) if p.training else None
     s1 = srcs[0]

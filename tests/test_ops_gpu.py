@@ -776,6 +776,19 @@ def test_se_bn_two_pass_stages(B, C, HW):          # (<= 64 elements: channel-pe
            MULBC=mul, ADDBC=add, PS=ps, COUNT=B * HW, B=B, C=C, HW=HW, NREP=1, ACT=D.ACT_SILU, ADDSCALE=1.0 / HW)
 
 
+@pytest.mark.parametrize("B,C,H,W,k,s", [(2, 13, 32, 32, 3, 2), (1, 3, 15, 22, 3, 2), (2, 4, 17, 17, 5, 2), (1, 2, 12, 20, 3, 3)])
+def test_im2col_exact(B, C, H, W, k, s):
+    """patch columns of a strided conv with TF-SAME padding (odd sizes: one pad row / column more at the bottom / right)"""
+    from s2lc_amd.plan.unet_plan import same_pads
+
+    Ho, pt = same_pads(H, k, s)
+    Wo, pl = same_pads(W, k, s)
+    c = Case(28)
+    x = c.t("x", (B, C, H, W))
+    y = c.t("y", (B, C * k * k, Ho, Wo), "nan")
+    c.run("IM2COL", ["y"], 1e-30, X=x, Y=y, B=B, C=C, H=H, W=W, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 5, 6, 8), (1, 3, 7, 5), (2, 16, 28, 28)])
 def test_space_to_depth_exact(B, C, H, W):
     c = Case(24)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--skip-last", type=int, default=0)
     ap.add_argument("--per-step", type=int, default=1)
     ap.add_argument("--gap-us", type=float, default=20.0)
+    ap.add_argument("--tail-us", type=float, default=0.0, help="print the kernel timeline of this many us before the last long main-queue gap ends")
     a = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(a.csv)):
@@ -54,10 +55,10 @@ def main():
             agg[k.split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")] += e - s
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:14]:
         print(f"     main queue {k:32s} {v / n / 1e6:7.3f} ms/step")
-    overlap_report(sel, main_q, n, a.gap_us)
+    overlap_report(sel, main_q, n, a.gap_us, a.tail_us)
 
 
-def overlap_report(sel, main_q, n, gap_us):
+def overlap_report(sel, main_q, n, gap_us, tail_us=0.0):
     """time with only the main queue busy / only other queues / both / neither, and the main queue's long gaps (waits at joins)."""
     ev = []
     for s, e, _, q in sel:
@@ -85,6 +86,14 @@ def overlap_report(sel, main_q, n, gap_us):
     short = lambda k: k.split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")[:28]
     for g in sorted(gaps, reverse=True)[:12]:
         print(f"     gap {g[0] / 1e3:8.1f} us (side busy {g[1] / 1e3:7.1f})  after {short(g[2]):28s} before {short(g[3])}")
+    if gaps and tail_us > 0:
+        # timeline around the LAST long gap: what the side queue was finishing while the main queue waited
+        g_end = max(s1 for (s0, e0, k0), (s1, e1, k1) in zip(mq, mq[1:]) if s1 - e0 > gap_us * 1000)
+        lo = g_end - int(tail_us * 1000)
+        print(f"  timeline of the last {tail_us:.0f} us before the main queue resumes (t relative to that moment, us):")
+        for s_, e_, k, q in sel:
+            if e_ > lo and s_ < g_end + 20000:
+                print(f"     {'main' if q == main_q else 'side'} {(s_ - g_end) / 1e3:9.1f} .. {(e_ - g_end) / 1e3:9.1f}  {(e_ - s_) / 1e3:7.1f} us  {short(k)}")
 
 
 if __name__ == "__main__":
