@@ -355,22 +355,10 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(const WgradP p) {
         }
     }
 
-    // ---------------- combine: wgs[t][m][c] += acc ------------------------------------------------
+    // ---------------- combine: wgs[t][m][c] += acc (k-waves reduced through LDS first: wgrad.h) -------
     if (p.exp & 2) return;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int rm = 0; rm < WM; ++rm)
-#pragma unroll
-            for (int rn = 0; rn < WN; ++rn) {
-                const int gc = c0 + wc0 + rn * 32 + l31;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if (gm < p.M && gc < p.C)
-                        atomicAdd(p.wgs + ((int64_t)t * p.M + gm) * p.CTOT + gc, acc[t][rm][rn][reg]);
-                }
-            }
+    if (tile_begin >= tile_end) return;
+    wg_combine<T, WM, WN, WVK>(p, acc, smem, wk, wmn, lane, m0, c0, wm0, wc0);     // (the loop's last barrier freed the tile images)
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -288,21 +288,10 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
         __syncthreads();
     }
 
-    // ---------------- combine: wgs[t][m][c] += acc ------------------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int rm = 0; rm < WM; ++rm)
-#pragma unroll
-            for (int rn = 0; rn < WN; ++rn) {
-                const int gc = c0 + wc0 + rn * 32 + l31;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if (gm < p.M && gc < p.C)
-                        atomicAdd(p.wgs + ((int64_t)t * p.M + gm) * p.CTOT + gc, acc[t][rm][rn][reg]);
-                }
-            }
+    // ---------------- combine: wgs[t][m][c] += acc (k-waves reduced through LDS first: wgrad.h) -----------------------------------
+    if (p.exp & 2) return;          // tuning builds only (S2K_WG_EXP)
+    if (tile_begin >= tile_end) return;
+    wg_combine<T, WM, WN, WVK>(p, acc, reinterpret_cast<float*>(smem_w), wk, wmn, lane, m0, c0, wm0, wc0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -339,7 +328,8 @@ static int launch_wb16(WgradP& p, hipStream_t st) {
     // more than the whole contraction.  So: just enough splits to give every CU its workgroups (one per CU for the 3x3 kernels,
     // two for 1x1), whole rounds of them, and at least 4 pixel tiles per split.
     const int mc = p.n_mtiles * p.n_ctiles;
-    const int slots = PIX ? 512 : 256;
+    static const int slots_exp = tune_int("S2K_WB16_SLOTS", 0);
+    const int slots = slots_exp > 0 ? slots_exp : (PIX ? 512 : 256);
     int splits = std::max(1, slots / mc);
     splits = std::min(splits, std::max(1, p.ntiles / 4));
     if (splits > 65535) splits = 65535;

@@ -306,23 +306,12 @@ __global__ void __launch_bounds__(512) wgrad_pc_kernel(const WgradP p) {
         WG_DBG_ADD(1, WG_STAMP() - s1);
     }
 
-    // ---------------- combine: wgs[t][m][c] += acc ------------------------------------------------
+    // ---------------- combine: wgs[t][m][c] += acc (k-waves reduced through LDS first: wgrad.h) -------
     WG_DBG_FLUSH();
     if (p.exp & 2) return;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int rm = 0; rm < WM; ++rm)
-#pragma unroll
-            for (int rn = 0; rn < WN; ++rn) {
-                const int gc = c0 + wc0 + rn * 32 + l31;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int gm = m0 + wm0 + rm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    if (gm < p.M && gc < p.C)
-                        atomicAdd(p.wgs + ((int64_t)t * p.M + gm) * p.CTOT + gc, acc[t][rm][rn][reg]);
-                }
-            }
+    if (tile_begin >= tile_end) return;
+    if constexpr (WVK > 1) __syncthreads();     // every consumer wave has left the multiply loop (the producers have exited): the images are free
+    wg_combine<T, WM, WN, WVK>(p, acc, smem, wk, wmn, lane, m0, c0, wm0, wc0);
 }
 
 // -------------------------------------------------------------------------------------------------
