@@ -130,22 +130,6 @@ def _r16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def _bnbwd(m: Mem, gp, y, bnv, st2_ref: int, gamma_ref: int, dgamma_ref: int, dbeta_ref: int, C: int):
-    """PRO_BNBWD: dY = A*gp + Bq*xhat + Cq, BN_BWD_FINALIZE's arithmetic done by the consumer (opdefs.PRO_BNBWD)."""
-    B = gp.shape[0]
-    n = float(B * gp.shape[2] * gp.shape[3])
-    nrep = max(1, min(64, 4096 // max(C, 1)))
-    st = m.view(st2_ref, (nrep, 2, C), "f64").sum(0)
-    gamma = m.view(gamma_ref, (C,))
-    if dgamma_ref >= 0:
-        m.view(dgamma_ref, (C,)).add_(st[1].to(m.fdtype))
-        m.view(dbeta_ref, (C,)).add_(st[0].to(m.fdtype))
-    a = (gamma * bnv[3]).double()
-    coef = torch.stack([a, -a * st[1] / n, -a * st[0] / n]).to(m.fdtype)
-    xhat = (y - bnv[2].view(1, C, 1, 1)) * bnv[3].view(1, C, 1, 1)
-    return coef[0].view(1, C, 1, 1) * gp + coef[1].view(1, C, 1, 1) * xhat + coef[2].view(1, C, 1, 1)
-
-
 def op_conv(m: Mem, o):
     B, C1, C2, H, W, M = o["B"], o["C1"], o["C2"], o["H"], o["W"], o["M"]
     KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
@@ -156,11 +140,7 @@ def op_conv(m: Mem, o):
         x1 = _unshuffle2(m.view(o["X1"], (B, co, 2 * H, 2 * W)))
     else:
         x1 = m.view(o["X1"], (B, C1, H, W))
-    if o["PRO1"] == 6:      # PRO_BNBWD: X2 carries the BatchNorm's raw input y (C2 = 0)
-        x = _bnbwd(m, x1, m.view(o["X2"], (B, C1, H, W)), m.view(o["BNV1"], (4, C1)), o["BNB_STATS2"], o["BNB_GAMMA"], o["BNB_DGAMMA"],
-                   o["BNB_DBETA"], C1)
-    else:
-        x = _pro(x1, m.view(o["BNV1"], (4, C1)), m.view(o["GATE1"], (B, C1)), o["PRO1"], C1)
+    x = _pro(x1, m.view(o["BNV1"], (4, C1)), m.view(o["GATE1"], (B, C1)), o["PRO1"], C1)
     if C2:
         x2 = _pro(m.view(o["X2"], (B, C2, H, W)), m.view(o["BNV2"], (4, C2)), None, o["PRO2"], C2)
         x = torch.cat([x, x2], 1)
@@ -198,11 +178,7 @@ def op_wgrad(m: Mem, o):
     B, M, C, CT, H, W = o["B"], o["M"], o["C"], o["CTOT"], o["H"], o["W"]
     KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
     T = KH * KW
-    if o["PROP"] == 6:      # PRO_BNBWD (never the writer of dgamma / dbeta: the data-gradient CONV is)
-        P = _bnbwd(m, m.view(o["P"], (B, M, Ho, Wo)), m.view(o["PY"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), o["PSTATS2"], o["PGAMMA"],
-                   -1, -1, M)
-    else:
-        P = _pro(m.view(o["P"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
+    P = _pro(m.view(o["P"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
     Q = _pro(m.view(o["Q"], (B, C, H, W)), m.view(o["BNVQ"], (4, C)), m.view(o["GATEQ"], (B, C)), o["PROQ"], C)
     if _bf16_operands(m, o):
         P, Q = _r16(P), _r16(Q)

@@ -32,12 +32,6 @@ def stats_replicas(C: int) -> int:
 
 # ---- prologue / activation codes -----------------------------------------------------------
 PRO_NONE, PRO_AFFINE, PRO_SILU, PRO_RELU, PRO_GELU = 0, 1, 2, 3, 4   # v' = act(scale[c]*v + shift[c]); GELU = exact erf form
-# PRO_BNBWD (bf16-mixed plans, CONV.PRO1 / WGRAD.PROP): the operand is the gradient w.r.t. a train-mode BatchNorm's INPUT, formed on
-# load instead of by a BN_BWD_APPLY pass:  dY = A*gp + Bq*xhat + Cq  with gp = X1 / P (the activation-masked upstream gradient that
-# BN_BWD_REDUCE left), xhat = (y - mean) * invstd from y = X2 / PY and BNV1 / BNVP, and {A, Bq, Cq} = BN_BWD_FINALIZE's coefficients
-# computed by the stage itself from the STATS2 replicas and gamma (CONV: n-slots BNB_*; WGRAD: PSTATS2 / PGAMMA).  The CONV whose
-# BNB_DGAMMA / BNB_DBETA are given also adds the BatchNorm's parameter gradients (one writer per BatchNorm).
-PRO_BNBWD = 6
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU = 0, 2, 3, 4                   # same numbering as PRO_*
 ACT_MUL = 5                                                            # ACT_BWD only: multiply by X instead of act'(X)
 MODE_CONV, MODE_CONVT_SCATTER, MODE_GATHER2X2 = 0, 1, 2
@@ -79,15 +73,14 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # SCRATCH (optional, >= 8 * B*YC*HO*WO floats): lets the kernel cut a long reduction over few output tiles into
     # split-K partials that a tail kernel adds in a fixed order (deep 8x8 / 16x16 layers: 160 tiles cannot fill 256 CUs).
     # WTB (with FLAG_BF16): the bf16 copy of WT written by WEIGHT_PACK (BF16_BASE)
-    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH", "WTB"],
-             ["BNB_STATS2", "BNB_GAMMA", "BNB_DGAMMA", "BNB_DBETA"],
+    "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH", "WTB"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
               "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
     # Weight gradient on f32 MFMA, K = pixels:
     #   WGS[tap][m][c] += sum_{b,yo,xo} Ppro[b][m][yo][xo] * Qpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     # (MODE_GATHER2X2: Q tap (dy,dx) reads Q[b][c][2y+dy][2x+dx]).  Scratch layout [T][M][CTOT]
     # keeps the float atomics 128-B contiguous; WGRAD_FINALIZE folds it into [M][C][T] grads.
-    "WGRAD": (["P", "BNVP", "GATEP", "Q", "BNVQ", "GATEQ", "WGS", "PY", "PSTATS2", "PGAMMA"], [],
+    "WGRAD": (["P", "BNVP", "GATEP", "Q", "BNVQ", "GATEQ", "WGS"], [],
               ["B", "M", "C", "CTOT", "H", "W", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
                "PROP", "PROQ", "MODE"], []),
     # GRADS[off + (m*C + c)*T + t] += WGS[off + (t*M + m)*C + c] for every TABLE entry {off, M, C, T, start}

@@ -98,8 +98,6 @@ class Program:
                 a, j = D.slot(kind, k)
                 if a == "t":
                     arr[i]["t"][j] = NULL if v is None else (v.ref if isinstance(v, TRef) else int(v))
-                elif a == "n" and (v is None or isinstance(v, TRef)):      # a tensor reference carried in an n slot (CONV.BNB_*)
-                    arr[i]["n"][j] = NULL if v is None else v.ref
                 else:
                     arr[i][a][j] = v
         return arr
