@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
         if (ch + 1 < ch_end) fetch((ch + 1) * KCH);              // in flight during the MFMAs below
         // k-step (tap, s): 16 channels = octets 2 s and 2 s + 1; lane half lh takes octet 2 s + lh
 #pragma unroll
-        for (int tap = 0; tap < TT; ++tap) {
+        for (int tap = 0; tap < ((p.exp & 2) ? 0 : TT); ++tap) {
             const int toff = PIX ? 0 : (tap / 3) * WS + (tap % 3);
 #pragma unroll
             for (int s = 0; s < NO / 2; ++s) {
@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     }
 
     // ---- epilogue: f32, as igemm_pc.hip ----------------------------------------------------------------------------------------
+    if (p.exp & 1) return;      // tuning builds only (S2K_CV_EXP)
     bool cval[WN];
     int64_t ycol[WN];
 #pragma unroll
@@ -321,6 +322,77 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
                         }
                 }
             }
+        return;
+    }
+    if constexpr (!SCATTER && (PIX || XW % 4 == 0)) {
+        // ---- transposed store -------------------------------------------------------------------------------------------------------
+        // An accumulator register holds ONE pixel of a row per lane: stored as it is, every instruction writes 2 rows x 128 bytes,
+        // and the write-heavy layers (40 -> 240-channel expand convs: 126 MB out for 21 MB in) streamed their output at 2.9-3.4 TB/s
+        // where a fill reaches 6.8 (tools/exp_cv16.sh: 37 of the stage's 46 us were the stores).  So the tile goes through LDS, 32 rows
+        // per wave row at a time, and comes back pixel-major: a lane stores 4 consecutive pixels (16 bytes), an instruction 2 rows x
+        // 512 bytes.  Bias / residual / accumulate and the BatchNorm statistics move to the reading side (a row's sums: one DPP
+        // reduction over the lanes that hold it, one f64 atomic pair per row and workgroup, fixed order throughout).
+        constexpr int BNP = BN + 8;                              // row stride: lane halves (rows r, r + 4) land in different banks
+        constexpr int PASS_ROWS = WVM * 32;
+        constexpr int G = BN / 4;                                // pixel quads per row
+        constexpr int RPI = NT / G;                              // rows per pass of the 256 threads
+        static_assert(NT % G == 0 && PASS_ROWS % RPI == 0 && (G == 16 || G == 32 || G == 64), "transposed epilogue geometry");
+        float* ct = reinterpret_cast<float*>(smem_b);            // [PASS_ROWS][BNP]  (the image is dead: barrier above)
+        const int g4 = tid % G, r0 = tid / G;
+        bool gok;
+        int64_t gcol;
+        {
+            const int j = 4 * g4;
+            if (PIX) {
+                const int n = nt * BN + j;
+                gok = n < p.Ntot;
+                const int nn = gok ? n : 0;
+                const int b = nn / p.HW, pp = nn - b * p.HW;
+                gcol = (int64_t)b * p.YC * HWo + pp;
+            } else {
+                const int r = j / XW, xx = j % XW;
+                gok = (j < R * XW) && (y0 + r < p.HO) && (x0 + xx < p.WO);
+                gcol = (int64_t)sb * p.YC * HWo + (int64_t)(y0 + r) * p.WO + (x0 + xx);
+            }
+        }
+        double* st = p.stats ? p.stats + (int64_t)(tile % p.nrep) * 2 * p.M : nullptr;
+#pragma unroll
+        for (int rm = 0; rm < WM; ++rm) {
+            if (rm) __syncthreads();                             // the previous pass has been read
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rl = (wave / WVN) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                for (int rn = 0; rn < WN; ++rn) ct[rl * BNP + wn0 + rn * 32 + l31] = acc[rm][rn][reg];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = r0; r < PASS_ROWS; r += RPI) {
+                const int gm = m0 + (r >> 5) * (WM * 32) + rm * 32 + (r & 31);
+                const bool ok = gok && gm < p.M;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ct + r * BNP + 4 * g4);
+                float s = 0.0f, q = 0.0f;
+                if (ok) {
+                    if (p.bias) { const float bsv = p.bias[gm]; v[0] += bsv; v[1] += bsv; v[2] += bsv; v[3] += bsv; }
+                    float* dst = p.y + gcol + (int64_t)gm * HWo;
+                    if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+                    if (p.beta) { const f32x4 ov = *reinterpret_cast<const f32x4*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                    s = (v[0] + v[1]) + (v[2] + v[3]);
+                    q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+                }
+                if (st) {
+                    bool writer;
+                    if (G == 16) { s = row16_sum(s); q = row16_sum(q); writer = (lane & 15) == 15; }
+                    else if (G == 32) { s = half_sum_hi(s); q = half_sum_hi(q); writer = l31 == 31; }
+                    else { s = wave_sum_hi(s); q = wave_sum_hi(q); writer = lane == 63; }
+                    if (writer && gm < p.M) {
+                        atomic_add_d(st + gm, (double)s);
+                        atomic_add_d(st + p.M + gm, (double)q);
+                    }
+                }
+            }
+        }
         return;
     }
     float* srow = reinterpret_cast<float*>(smem_b);              // [WVN wave columns][2][BM]  (the image is dead: barrier above)
@@ -384,7 +456,8 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     static_assert((size_t)WVN * 2 * BM * sizeof(float) <= img, "statistics rows fit in the image");
     p.n_mtiles = cdiv(p.M, BM);
     const int nchunks = cdiv(p.Ctot, KCH);
-    const size_t lds = img + (PRO != S2K_PRO_NONE ? (size_t)2 * nchunks * KCH * sizeof(float) : 0);
+    constexpr size_t ct_bytes = (!SCATTER && (PIX || XW % 4 == 0)) ? (size_t)WVM * 32 * (BN + 8) * sizeof(float) : 0;   // transposed store
+    const size_t lds = std::max(img + (PRO != S2K_PRO_NONE ? (size_t)2 * nchunks * KCH * sizeof(float) : 0), ct_bytes);
     if (lds > 160 * 1024) return 1;
     {   // 32-bit buffer offsets: image-local tiles need one image < 2 GiB, tiles that may straddle images the whole tensor
         // (descriptors are based at the first image a tile touches)

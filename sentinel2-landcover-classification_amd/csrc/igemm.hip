@@ -663,6 +663,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
     p.scratch = ref_ptr<float>(c, op.t[S2K_CONV_T_SCRATCH]);
     p.wtb = (op.flags & S2K_FLAG_BF16) ? ref_ptr<const void>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
+    static const int cv_exp = tune_int("S2K_CV_EXP", 0);
+    p.exp = cv_exp;
     const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb};
     for (const void* q : ptrs)
         if (q == reinterpret_cast<const void*>(1)) { set_error("conv: tensor references a null base"); return S2K_EFAULT; }
