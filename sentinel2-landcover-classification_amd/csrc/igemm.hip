@@ -470,6 +470,74 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
             }
         return;
     }
+    if constexpr (BN >= 64 && BN <= 256) {
+        if (p.tepi) {
+            // ---- transposed store (see conv_bf16.hip): the tile goes through LDS, 32 rows per wave row at a time, and comes back
+            // pixel-major - a lane stores 4 consecutive pixels (16 bytes), an instruction rows x 512 bytes instead of 2 rows x 128 bytes
+            // straight from the MFMA layout (write-heavy layers streamed their output at ~3 TB/s where a fill reaches 6.8).  Bias /
+            // residual / accumulate and the BatchNorm statistics are applied on the reading side (a row's sums: one DPP reduction over
+            // the lanes that hold it, one f64 atomic pair per row and workgroup, fixed order throughout).
+            constexpr int CTP = BN + 8;                          // row stride: lane halves (rows r, r + 4) land in different banks
+            constexpr int PASS_ROWS = WVM * 32;
+            constexpr int G = BN / 4, RPI = NTHREADS / G;
+            static_assert(NTHREADS % G == 0 && PASS_ROWS % RPI == 0 && (G == 16 || G == 32 || G == 64), "transposed epilogue geometry");
+            const int g4 = tid % G, r0 = tid / G;
+            bool gok;
+            int64_t gcol;
+            const int j = 4 * g4;
+            if (BMODE == BM_PIX) {
+                const int n = nt * BN + j;
+                gok = n < p.Ntot;
+                const int nn = gok ? n : 0;
+                const int b = nn / p.HW, pp = nn - b * p.HW;
+                gcol = (int64_t)b * p.YC * HWo + pp;
+            } else {
+                const int tx = nt % p.tiles_x, ty = (nt / p.tiles_x) % p.tiles_y, sb = nt / (p.tiles_x * p.tiles_y);
+                const int r = j / p.XW, xx = j - r * p.XW;
+                gok = (r < p.R) && (ty * p.R + r < p.HO) && (tx * p.XW + xx < p.WO);
+                gcol = (int64_t)sb * p.YC * HWo + (int64_t)(ty * p.R + r) * p.WO + (tx * p.XW + xx);
+            }
+            double* st = p.stats ? p.stats + (int64_t)(tile % p.nrep) * 2 * p.M : nullptr;
+#pragma unroll
+            for (int rm = 0; rm < WM; ++rm) {
+                if (rm) __syncthreads();                         // the previous pass has been read
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rl = (wave / WVN) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                    for (int rn = 0; rn < WN; ++rn) smem[rl * CTP + wn0 + rn * 32 + l31] = acc[rm][rn][reg];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = r0; r < PASS_ROWS; r += RPI) {
+                    const int gm = m0 + (r >> 5) * (WM * 32) + rm * 32 + (r & 31);
+                    const bool ok = gok && gm < p.M;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CTP + 4 * g4);
+                    float s = 0.0f, q = 0.0f;
+                    if (ok) {
+                        if (p.bias) { const float bsv = p.bias[gm]; v[0] += bsv; v[1] += bsv; v[2] += bsv; v[3] += bsv; }
+                        float* dst = p.y + gcol + (int64_t)gm * HWo;
+                        if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+                        if (p.beta) { const f32x4 ov = *reinterpret_cast<const f32x4*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                        s = (v[0] + v[1]) + (v[2] + v[3]);
+                        q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+                    }
+                    if (st) {
+                        bool writer;
+                        if (G == 16) { s = row16_sum(s); q = row16_sum(q); writer = (lane & 15) == 15; }
+                        else if (G == 32) { s = half_sum_hi(s); q = half_sum_hi(q); writer = l31 == 31; }
+                        else { s = wave_sum_hi(s); q = wave_sum_hi(q); writer = lane == 63; }
+                        if (writer && gm < p.M) {
+                            atomic_add_d(st + gm, (double)s);
+                            atomic_add_d(st + p.M + gm, (double)q);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     // row sums for BatchNorm: lanes -> half-wave shuffle, waves -> LDS slots summed in a FIXED order (no
     // float atomics: BatchNorm statistics stay run-to-run reproducible), then ONE f64 atomic pair per row
     // per workgroup into the statistics replica of this tile
@@ -623,7 +691,15 @@ static int launch_cfg(ConvP& p, int n_ntiles, hipStream_t st, bool allow_splitk 
             p.splits = cdiv(nchunks, p.chunks_per_split);
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splits), dim3(NTHREADS), lds, st, p);
+    // transposed store of the output tile (whole tiles only, pixel quads aligned to 16 bytes)
+    size_t lds_run = lds;
+    p.tepi = 0;
+    if (BN >= 64 && BN <= 256 && p.splits == 1 && p.mode != S2K_MODE_CONVT_SCATTER &&
+        ((BMODE == BM_PIX && (p.HW & 3) == 0) || (BMODE == BM_SPATIAL && (p.XW & 3) == 0 && (p.WO & 3) == 0))) {
+        p.tepi = 1;
+        lds_run = std::max(lds, (size_t)WVM * 32 * (BN + 8) * sizeof(float));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splits), dim3(NTHREADS), lds_run, st, p);
     if (p.splits > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64((int64_t)p.B * p.M, 4)), dim3(NTHREADS), 0, st, p);
     return S2K_OK;

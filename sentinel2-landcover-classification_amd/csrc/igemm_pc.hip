@@ -65,6 +65,61 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
     const int sb = (BMODE == BM_PIX) ? 0 : nt / (p.tiles_x * p.tiles_y);
     const int y0 = ty * R, x0 = tx * XW;
 
+    // ---- transposed store (both roles; see conv_bf16.hip): the consumers write their accumulator tiles to LDS 32 rows per wave row
+    // at a time, then all 512 threads read them back pixel-major and store 16-byte pixel quads (an instruction = rows x 512 B instead
+    // of 2 rows x 128 B straight from the MFMA layout: the write-heavy layers streamed their output at ~3 TB/s where a fill reaches
+    // 6.8).  Bias / residual / accumulate and the BatchNorm statistics are applied on the reading side.
+    constexpr bool TEPI = BMODE == BM_PIX || XW % 4 == 0;
+    constexpr int CTP = BN + 8;                                  // LDS row stride: lane halves (rows r, r + 4) land in different banks
+    constexpr int PASS_ROWS = THIN ? 32 : 64;
+    constexpr int G = BN / 4, RPI = 2 * NT / G;
+    static_assert(!TEPI || (PASS_ROWS % RPI == 0 && (G == 16 || G == 32 || G == 64)), "transposed epilogue geometry");   // (launch_pc sizes the LDS for it)
+    auto store_rows = [&](int rm) {
+        const int t = threadIdx.x, g4 = t % G, r0 = t / G;
+        const int ln = t & 63;
+        bool gok;
+        int64_t gcol;
+        const int j = 4 * g4;
+        if (BMODE == BM_PIX) {
+            const int n = nt * BN + j;
+            gok = n < p.Ntot;
+            const int nn = gok ? n : 0;
+            const int b = nn / p.HW, pp = nn - b * p.HW;
+            gcol = (int64_t)b * p.YC * HWo + pp;
+        } else {
+            const int r = j / XW, xx = j % XW;
+            gok = (j < R * XW) && (y0 + r < p.HO) && (x0 + xx < p.WO);
+            gcol = (int64_t)sb * p.YC * HWo + (int64_t)(y0 + r) * p.WO + (x0 + xx);
+        }
+        double* st = p.stats ? p.stats + (int64_t)(tile % p.nrep) * 2 * p.M : nullptr;
+#pragma unroll
+        for (int r = r0; r < PASS_ROWS; r += RPI) {
+            const int gm = m0 + (r >> 5) * (WM * 32) + rm * 32 + (r & 31);
+            const bool ok = gok && gm < p.M;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CTP + 4 * g4);
+            float s = 0.0f, q = 0.0f;
+            if (ok) {
+                if (p.bias) { const float bsv = p.bias[gm]; v[0] += bsv; v[1] += bsv; v[2] += bsv; v[3] += bsv; }
+                float* dst = p.y + gcol + (int64_t)gm * HWo;
+                if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+                if (p.beta) { const f32x4 ov = *reinterpret_cast<const f32x4*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+                *reinterpret_cast<f32x4*>(dst) = v;
+                s = (v[0] + v[1]) + (v[2] + v[3]);
+                q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+            }
+            if (st) {      // a row's sums: one DPP reduction over the lanes that hold it, one f64 atomic pair per row and workgroup
+                bool writer;
+                if (G == 16) { s = row16_sum(s); q = row16_sum(q); writer = (ln & 15) == 15; }
+                else if (G == 32) { s = half_sum_hi(s); q = half_sum_hi(q); writer = (ln & 31) == 31; }
+                else { s = wave_sum_hi(s); q = wave_sum_hi(q); writer = ln == 63; }
+                if (writer && gm < p.M) {
+                    atomic_add_d(st + gm, (double)s);
+                    atomic_add_d(st + p.M + gm, (double)q);
+                }
+            }
+        }
+    };
+
     if (producer) {
         // =================================================================================================================
         // PRODUCER
@@ -171,6 +226,16 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
             if (ch + 1 < nchunks) fetch((ch + 1) * KCH);
             __syncthreads();
         }
+        if constexpr (TEPI) {
+            __syncthreads();                                        // (E1) every wave is done with the LDS image
+#pragma unroll
+            for (int rm = 0; rm < WM; ++rm) {
+                __syncthreads();                                    // the consumers' tiles of pass rm are in LDS
+                store_rows(rm);
+                if (rm + 1 < WM) __syncthreads();                   // pass rm has been read
+            }
+            return;
+        }
     } else {
         // =================================================================================================================
         // CONSUMER
@@ -264,6 +329,21 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
             }
         }
         __syncthreads();                                            // (E1) every wave is done with the LDS image
+        if constexpr (TEPI) {
+#pragma unroll
+            for (int rm = 0; rm < WM; ++rm) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rl = (THIN ? 0 : (wave >> 1) * 32) + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+                    for (int rn = 0; rn < WN; ++rn) smem[rl * CTP + wn0 + rn * 32 + l31] = acc[rm][rn][reg];
+                }
+                __syncthreads();
+                store_rows(rm);
+                if (rm + 1 < WM) __syncthreads();
+            }
+            return;
+        }
         float* srow = smem;                                         // [NWCOL n-columns of waves][2][BM]
         const int wn_idx = THIN ? wave : (wave & 1);
 #pragma unroll
@@ -323,7 +403,8 @@ static int launch_pc(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr int USED = (R + 2) * (XW + 2);
     constexpr int CSB = (BMODE == BM_PIX) ? BNP : USED;
     constexpr int BUF = (KCH * TT * BM + KCH * CSB + 3) & ~3;
-    constexpr size_t lds = (size_t)2 * BUF * sizeof(float);
+    constexpr size_t ct_bytes = (BMODE == BM_PIX || XW % 4 == 0) ? (size_t)(THIN ? 32 : 64) * ((THIN ? 256 : BNP) + 8) * sizeof(float) : 0;   // transposed store
+    constexpr size_t lds = std::max((size_t)2 * BUF * sizeof(float), ct_bytes);
     static_assert(lds <= 160 * 1024, "LDS image");
     static_assert((THIN ? 8 : 4) * BM * sizeof(float) <= lds, "statistics rows fit in the image");
     p.n_mtiles = cdiv(p.M, BM);
