@@ -472,7 +472,8 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     p.splits = 1;
     p.chunks_per_split = nchunks;
     p.y_elems = (int64_t)p.B * p.YC * p.HO * p.WO;
-    if (PIX && !SCATTER && p.scratch && blocks <= 512 && nchunks >= 8) {
+    static const int split_max_blocks = tune_int("S2K_B16_SPLIT_MAX_BLOCKS", 512);
+    if (PIX && !SCATTER && p.scratch && blocks <= split_max_blocks && nchunks >= 8) {
         // Few tiles and a long reduction (the 1x1 convs of the 8 x 8 / 16 x 16 blocks: 160 workgroups each walking 29 - 48
         // chunks one memory round trip at a time): cut K so that ~1,000 workgroups share the round trips; the partial tiles
         // are added in a fixed order by the split-K tail (igemm.hip), which also applies bias / statistics.  SCRATCH holds 8.
