@@ -37,6 +37,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the ~5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+GUIDE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of the 8 TB/s spec)
 # SURVEY §8d, whole-step denominators (fp32): the layer-wise roofline T = sum over layers of max(FLOP / peak, bytes / BW) of
 # efficientnet-unet-b5 13x256x256 is 0.464 ms per tile (pure MFMA 0.418, pure HBM 0.140) = 2,154 tiles/s per GPU; the Prithvi
 # steps are compute-bound: forward + backward FLOP per sample / the f32 MFMA peak.
@@ -725,6 +726,9 @@ def main() -> None:
             "measured_peaks": None if peaks is None else {"mfma_f32_tflops": round(peaks["mfma_f32_tflops"], 1),
                                                           "mfma_clock_mhz": round(peaks["mfma_clock_mhz"]),
                                                           "stream_copy_gbps": round(peaks["copy_gbps"], 1),
+                                                          # a fill (write-only) reaches 6.8 TB/s on this part, our read+write copy 5.6-5.9;
+                                                          # the guide's own float4 copy measured 6.29 TB/s (MI355X_MICROARCH.md)
+                                                          "guide_copy_gbps": GUIDE_COPY_GBS,
                                                           "spec": {"mfma_f32_tflops": PEAK_F32_MFMA_TFLOPS, "hbm_gbps": PEAK_HBM_GBS}},
             "kernels": kernels, "loss": round(loss_val, 6),
             # tiles/s of ONE GPU running the plan the data-parallel ranks run (tape-order weight gradients, segmented backward,
