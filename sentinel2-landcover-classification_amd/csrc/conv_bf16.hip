@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     static_assert(KCH % 16 == 0, "a k-step is 16 channels");
     static_assert(PIX || R * XW <= BN, "3x3 tile");
     static_assert(PIX || (!GATE && !SCATTER && (PRO == S2K_PRO_NONE || PRO == S2K_PRO_RELU)), "3x3: BatchNorm + ReLU prologue at most");
+    static_assert(KCH <= 64 || PIX, "128-channel chunks: 1x1 only");
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_b[];
     u32x4* As = smem_b;
     u32x4* Bs = smem_b + A_UNITS;
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     const int y0 = ty * R, x0 = tx * XW;
     const int MP = p.w_st;                                   // packed row count (M rounded up to 128)
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.wtb);
+    const int kp8 = ((p.Ctot + 63) / 64) * 8;                // octets of the packed K (WEIGHT_PACK pads K to a multiple of 64)
 
     // ---- staging geometry: fixed for the whole K loop ---------------------------------------------------------------------
     uint32_t bvoff[NBI];        // byte offset of the item's pixel quad / halo element in a channel plane (image-relative), or OOB
@@ -146,7 +148,14 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
         for (int i = 0; i < NA; ++i) {
             const int u = tid + NT * i;
             const int row = u % BM, ot = u / BM;             // ot = o * TT + tap
-            if (A_UNITS % NT == 0 || u < A_UNITS) areg[i] = wsrc[((int64_t)ob0 * TT + ot) * MP + m0 + row];
+            if constexpr (KCH > 64) {
+                // the packed K is a multiple of 64: the upper half of the last 128-channel chunk may lie past the entry - re-read its
+                // last octet (the matching B units are zeroed at the commit)
+                const int o = min(ob0 + ot / TT, kp8 - 1), tap = ot % TT;
+                if (A_UNITS % NT == 0 || u < A_UNITS) areg[i] = wsrc[((int64_t)o * TT + tap) * MP + m0 + row];
+            } else {
+                if (A_UNITS % NT == 0 || u < A_UNITS) areg[i] = wsrc[((int64_t)ob0 * TT + ot) * MP + m0 + row];
+            }
         }
         if (PIX) {
 #pragma unroll
@@ -198,6 +207,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
                         v[q] = x;
                     }
                     u32x4 w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+                    if constexpr (KCH > 64) { if (c0 + 8 * b_co[i] >= 8 * kp8) w = u32x4{0u, 0u, 0u, 0u}; }    // octets past the packed K
                     const int s = (b_dst[i] % BN) + e;
                     Bs[(b_dst[i] - (b_dst[i] % BN)) + swz(s)] = w;
                 }
@@ -505,7 +515,9 @@ static int launch_b16_bm(ConvP& p, int n128, hipStream_t st) {
 
 template <int KCH, int PRO, bool GATE>
 static int launch_b16_pix(ConvP& p, hipStream_t st) {
-    if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 256), st);
+    if constexpr (KCH <= 64) {
+        if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 256), st);
+    }
     // few pixels (the 8 x 8 / 16 x 16 maps of the deep blocks): 128-pixel tiles would leave most CUs without a workgroup and each
     // of the few with a long serial K loop; 64 x 64 tiles give 4x the workgroups
     const int n128 = cdiv(p.Ntot, 128);
@@ -528,12 +540,18 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
     if (p.mode != S2K_MODE_CONV) return 1;
     if (T == 1) {
         if (p.C2 != 0 || (p.HW & 3) || p.PT || p.PL) return 1;
+        // deep reductions (the project / data-gradient convs of the 8 x 8 - 32 x 32 blocks, ViT Linears): with bf16 MFMAs a chunk's
+        // multiply is short and a workgroup's K loop is a chain of load round trips - 128-channel chunks halve it
+        static const int deep_min = tune_int("S2K_B16_DEEP_MIN", 512);
+        // (measured: 8 x 8 / 16 x 16 maps 43 -> 22 us, 34 -> 18, 20 -> 10; large pixel counts are matrix-core / bandwidth-bound and lose
+        // 4 - 8 % to the larger LDS image, so only problems of at most 1,024 128 x 128 tiles take it; the 32-row tile would spill)
+        const bool deep = p.Ctot >= deep_min && p.M > 32 && (int64_t)cdiv(p.Ntot, 128) * cdiv(p.M, 128) <= 1024;
         if (p.gate1) {
-            if (p.pro1 == S2K_PRO_SILU) return launch_b16_pix<64, S2K_PRO_SILU, true>(p, st);
+            if (p.pro1 == S2K_PRO_SILU) return deep ? launch_b16_pix<128, S2K_PRO_SILU, true>(p, st) : launch_b16_pix<64, S2K_PRO_SILU, true>(p, st);
             return 1;
         }
         switch (p.pro1) {
-            case S2K_PRO_NONE: return launch_b16_pix<64, S2K_PRO_NONE, false>(p, st);
+            case S2K_PRO_NONE: return deep ? launch_b16_pix<128, S2K_PRO_NONE, false>(p, st) : launch_b16_pix<64, S2K_PRO_NONE, false>(p, st);
             case S2K_PRO_RELU: return launch_b16_pix<64, S2K_PRO_RELU, false>(p, st);
             case S2K_PRO_SILU: return launch_b16_pix<64, S2K_PRO_SILU, false>(p, st);
             case S2K_PRO_AFFINE: return launch_b16_pix<64, S2K_PRO_AFFINE, false>(p, st);

@@ -180,6 +180,9 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     (6, 288, 1, 200, 320, 0, False, True, False, 1),    # a Linear over feature-major tokens (H = 1), accumulate into Y
     (3, 256, 100, 100, 176, 1, False, False, True, 0),  # AFFINE prologue; tiles straddle images, ragged last tile
     (2, 96, 20, 20, 96, 2, False, False, True, 0),      # SiLU prologue without a gate (MBConv expand output read by ... a 1x1)
+    (2, 576, 16, 16, 200, 0, False, True, True, 0),     # deep reduction, no prologue: 128-channel chunks, packed K = 9 x 64 (the last chunk's upper half lies past it)
+    (3, 512, 8, 8, 2048, 0, False, False, True, 0),     # the encoder's head conv: 128-channel chunks, whole chunks only
+    (2, 1056, 16, 16, 176, 2, True, False, False, 1),   # deep project conv, 128-channel chunks with a ragged K (1056 = 16.5 x 64), accumulate
 ])
 def test_conv1x1_bf16(B, C1, H, W, M, pro, gate, bias, stats, beta):
     _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, pro, 0, gate, bias=bias, stats=stats, beta=beta, bf16=True)
