@@ -15,7 +15,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8}
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8,
+       "bf16": torch.bfloat16}
 
 
 class Mem:
@@ -44,6 +45,8 @@ class Mem:
             off *= 2
             if dtype == "f32":
                 dtype = "f64"
+            elif dtype == "bf16":      # (a 2-byte slot doubled holds an f32: the float64 emulation does not round operands)
+                dtype = "f32"
         dt = _DT[dtype]
         isz = torch.empty((), dtype=dt).element_size()
         buf = self.bases[base]
@@ -139,7 +142,7 @@ def op_conv(m: Mem, o):
         co = C1 // 4
         x1 = _unshuffle2(m.view(o["X1"], (B, co, 2 * H, 2 * W)))
     else:
-        x1 = m.view(o["X1"], (B, C1, H, W))
+        x1 = m.view(o["X1"], (B, C1, H, W), "bf16" if o.get("X1_BF16", 0) else "f32").to(m.fdtype)
     x = _pro(x1, m.view(o["BNV1"], (4, C1)), m.view(o["GATE1"], (B, C1)), o["PRO1"], C1)
     if C2:
         x2 = _pro(m.view(o["X2"], (B, C2, H, W)), m.view(o["BNV2"], (4, C2)), None, o["PRO2"], C2)
@@ -178,7 +181,7 @@ def op_wgrad(m: Mem, o):
     B, M, C, CT, H, W = o["B"], o["M"], o["C"], o["CTOT"], o["H"], o["W"]
     KH, KW, S, Ho, Wo, mode = o["KH"], o["KW"], o["STRIDE"], o["HO"], o["WO"], o["MODE"]
     T = KH * KW
-    P = _pro(m.view(o["P"], (B, M, Ho, Wo)), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
+    P = _pro(m.view(o["P"], (B, M, Ho, Wo), "bf16" if o.get("P_BF16", 0) else "f32").to(m.fdtype), m.view(o["BNVP"], (4, M)), m.view(o["GATEP"], (B, M)), o["PROP"], M)
     Q = _pro(m.view(o["Q"], (B, C, H, W)), m.view(o["BNVQ"], (4, C)), m.view(o["GATEQ"], (B, C)), o["PROQ"], C)
     if _bf16_operands(m, o):
         P, Q = _r16(P), _r16(Q)
@@ -406,7 +409,7 @@ def op_bn_bwd_apply(m: Mem, o):
             g = g + add.view(B, C, 1) * o["ADDSCALE"]
         gp = g * _act_grad(y * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1), o["ACT"])
     dy = coef[0].view(1, C, 1) * gp + coef[1].view(1, C, 1) * xhat + coef[2].view(1, C, 1)
-    m.view(o["DY"], (B, C, HW)).copy_(dy)
+    m.view(o["DY"], (B, C, HW), "bf16" if o.get("OUT_BF16", 0) else "f32").copy_(dy)       # (copy_ rounds to nearest even)
 
 
 def op_bn_residual(m: Mem, o):

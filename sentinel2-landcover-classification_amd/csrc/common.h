@@ -89,9 +89,11 @@ __device__ __forceinline__ float bload_s(rsrc_t r, uint32_t voff, uint32_t soff)
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, uint32_t byte_off) {   // 16-byte aligned offsets only
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// (the vector the b64 builtin returns must be bit-cast as a WHOLE: indexing it - v[0], v[1] - makes this compiler emit a single
+// buffer_load_dword and copy the dword into both elements)
 __device__ __forceinline__ float2 bload2(rsrc_t r, uint32_t byte_off) {
-    auto v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
-    return make_float2(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]));
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+    return make_float2(__builtin_bit_cast(float, (uint32_t)(u & 0xffffffffull)), __builtin_bit_cast(float, (uint32_t)(u >> 32)));
 }
 
 // ---- reductions -------------------------------------------------------------------------------

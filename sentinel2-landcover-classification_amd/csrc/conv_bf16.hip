@@ -42,9 +42,12 @@ __device__ __forceinline__ int swz(int s) { return s ^ ((s >> 3) & 3); }
 
 // PRO: S2K_PRO_NONE / RELU / SILU / AFFINE (1x1), NONE / RELU (3x3).  GATE: SE gate [B][C1] multiplies the activated value (1x1).
 // SCATTER (1x1): S2K_MODE_CONVT_SCATTER - rows m = (co, dy, dx) are stored to Y[b][co][2y + dy][2x + dx] (ConvTranspose2d k2 s2).
-template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
+// X16 (1x1, no prologue): X1 is stored as bf16 [B][C1][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): four pixels of a channel are one
+// 8-byte load, the operand units are assembled with v_perm_b32 - no conversion, the values are the ones the f32 path would round to.
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false, bool X16 = false>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     constexpr bool PIX = BMODE == BM_PIX;
+    static_assert(!X16 || (PIX && PRO == S2K_PRO_NONE && !GATE && !SCATTER), "bf16 X1: plain 1x1");
     constexpr int NT = 256;
     constexpr int WVN = 4 / WVM;
     constexpr int BM = WVM * WM * 32, BN = WVN * WN * 32;
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
             const bool ok = it < B_ITEMS && n < p.Ntot;
             const int nn = ok ? n : 0;
             const int b = nn / p.HW, pp = nn - b * p.HW;
-            bvoff[i] = ok ? (uint32_t)((int64_t)(b - img_b) * p.C1 * p.HW + pp) * 4u : BUF_OOB;
+            bvoff[i] = ok ? (uint32_t)((int64_t)(b - img_b) * p.C1 * p.HW + pp) * (X16 ? 2u : 4u) : BUF_OOB;
             b_dst[i] = co * BN + 4 * j4;
             b_co[i] = co;
             gate_b[PIX ? i : 0] = b;
@@ -121,9 +124,10 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
         }
     }
     const int64_t x1_img = (int64_t)p.C1 * p.HW, x2_img = (int64_t)p.C2 * p.HW;
-    const rsrc_t rx1 = make_rsrc(p.x1 + img_b * x1_img, (p.B - img_b) * x1_img * 4);
+    const rsrc_t rx1 = X16 ? make_rsrc(reinterpret_cast<const uint16_t*>(p.x1) + img_b * x1_img, (p.B - img_b) * x1_img * 2)
+                           : make_rsrc(p.x1 + img_b * x1_img, (p.B - img_b) * x1_img * 4);
     const rsrc_t rx2 = make_rsrc(p.x2 ? p.x2 + img_b * x2_img : p.x1, p.x2 ? (p.B - img_b) * x2_img * 4 : 0);
-    const uint32_t cs4 = (uint32_t)p.HW * 4u;
+    const uint32_t cs4 = (uint32_t)p.HW * (X16 ? 2u : 4u);      // bytes between channel planes
 
     // ---- prologue table -----------------------------------------------------------------------------------------------------
     if (PRO != S2K_PRO_NONE) {
@@ -137,7 +141,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     }
 
     u32x4 areg[NA];
-    f32x4 bq[PIX ? NBI : 1][8];          // 1x1: eight channels x four pixels per item
+    f32x4 bq[(PIX && !X16) ? NBI : 1][8];          // 1x1: eight channels x four pixels per item
+    float2 bh[X16 ? NBI : 1][8];                   // X16: the same as four bf16 (two dwords) per channel
     float bs[PIX ? 1 : NBI][8];          // 3x3: eight channels of one halo element per item
     float greg[(PIX && GATE) ? NBI : 1][8];
 
@@ -163,7 +168,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int c = min(c0 + 8 * b_co[i] + q, p.Ctot - 1);   // channels past Ctot meet zero rows of the packed weights
-                    bq[PIX ? i : 0][q] = bload4(rx1, bvoff[i] + (uint32_t)c * cs4);
+                    if constexpr (X16) bh[X16 ? i : 0][q] = bload2(rx1, bvoff[i] + (uint32_t)c * cs4);
+                    else bq[(PIX && !X16) ? i : 0][q] = bload4(rx1, bvoff[i] + (uint32_t)c * cs4);
                     if (GATE) greg[(PIX && GATE) ? i : 0][q] = p.gate1[gate_b[PIX ? i : 0] * p.C1 + c];
                 }
         } else {
@@ -195,13 +201,30 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sc[q] = s0[q]; sc[4 + q] = s1[q]; sh[q] = h0[q]; sh[4 + q] = h1[q]; }
             }
-            if (PIX) {
+            if constexpr (X16) {
+                // dword d of channel q holds pixels 2d (low half) and 2d + 1 (high half): unit e = pixel e of the eight channels
+                uint32_t lo[8], hi[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { lo[q] = __builtin_bit_cast(uint32_t, bh[X16 ? i : 0][q].x); hi[q] = __builtin_bit_cast(uint32_t, bh[X16 ? i : 0][q].y); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {       // even channel in the low half, odd channel in the high half (the compiler picks v_perm_b32 / v_and_or)
+                        const uint32_t a = (e < 2) ? lo[2 * k] : hi[2 * k], b = (e < 2) ? lo[2 * k + 1] : hi[2 * k + 1];
+                        w[k] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                    }
+                    if constexpr (KCH > 64) { if (c0 + 8 * b_co[i] >= 8 * kp8) w = u32x4{0u, 0u, 0u, 0u}; }
+                    const int s = (b_dst[i] % BN) + e;
+                    Bs[(b_dst[i] - (b_dst[i] % BN)) + swz(s)] = w;
+                }
+            } else if (PIX) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        float x = bq[PIX ? i : 0][q][e];
+                        float x = bq[(PIX && !X16) ? i : 0][q][e];
                         if (PRO != S2K_PRO_NONE) x = apply_pro_c<PRO>(x, sc[q], sh[q]);
                         if (GATE) x *= greg[(PIX && GATE) ? i : 0][q];
                         v[q] = x;
@@ -453,7 +476,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
+template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false, bool X16 = false>
 static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
     constexpr bool PIX = BMODE == BM_PIX;
     constexpr int WVN = 4 / WVM;
@@ -494,7 +517,7 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
             p.splits = cdiv(nchunks, p.chunks_per_split);
         }
     }
-    auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE, SCATTER>;
+    auto kern = conv_bf16_kernel<BMODE, WVM, WM, WN, KCH, R, XW, PRO, GATE, SCATTER, X16>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.splits), dim3(256), lds, st, p);
@@ -505,30 +528,31 @@ static int launch_b16(ConvP& p, int n_ntiles, hipStream_t st) {
 
 // tile height by M: 64 rows when 128 would pad M by more than 12 % (32-row tiles, 1 x 4 waves over 256 pixels, are instantiated
 // by the callers: their pixel tile differs)
-template <int BMODE, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false>
+template <int BMODE, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false, bool X16 = false>
 static int launch_b16_bm(ConvP& p, int n128, hipStream_t st) {
     if (p.M <= 32) return 1;
     const bool big = p.M > 64 && (double)cdiv(p.M, 128) * 128 / p.M <= 1.12;
-    if (big) return launch_b16<BMODE, 2, 2, 2, KCH, R, XW, PRO, GATE, SCATTER>(p, n128, st);
-    return launch_b16<BMODE, 2, 1, 2, KCH, R, XW, PRO, GATE, SCATTER>(p, n128, st);
+    if (big) return launch_b16<BMODE, 2, 2, 2, KCH, R, XW, PRO, GATE, SCATTER, X16>(p, n128, st);
+    return launch_b16<BMODE, 2, 1, 2, KCH, R, XW, PRO, GATE, SCATTER, X16>(p, n128, st);
 }
 
-template <int KCH, int PRO, bool GATE>
+template <int KCH, int PRO, bool GATE, bool X16 = false>
 static int launch_b16_pix(ConvP& p, hipStream_t st) {
     if constexpr (KCH <= 64) {
-        if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 256), st);
+        if (p.M <= 32) return launch_b16<BM_PIX, 1, 1, 2, KCH, 1, 64, PRO, GATE, false, X16>(p, cdiv(p.Ntot, 256), st);
     }
     // few pixels (the 8 x 8 / 16 x 16 maps of the deep blocks): 128-pixel tiles would leave most CUs without a workgroup and each
     // of the few with a long serial K loop; 64 x 64 tiles give 4x the workgroups
     const int n128 = cdiv(p.Ntot, 128);
-    if ((int64_t)n128 * cdiv(p.M, 128) < 200) return launch_b16<BM_PIX, 2, 1, 1, KCH, 1, 64, PRO, GATE>(p, cdiv(p.Ntot, 64), st);
-    return launch_b16_bm<BM_PIX, KCH, 1, 64, PRO, GATE>(p, n128, st);
+    if ((int64_t)n128 * cdiv(p.M, 128) < 200) return launch_b16<BM_PIX, 2, 1, 1, KCH, 1, 64, PRO, GATE, false, X16>(p, cdiv(p.Ntot, 64), st);
+    return launch_b16_bm<BM_PIX, KCH, 1, 64, PRO, GATE, false, X16>(p, n128, st);
 }
 
 // S2K_OK = launched, 1 = not one of its shapes (the caller takes the f32 kernels), < 0 = error
 int launch_conv_bf16(ConvP& p, hipStream_t st) {
     if (!p.wtb || p.S != 1 || p.HO != p.H || p.WO != p.W) return 1;
     const int T = p.KH * p.KW;
+    if (p.x1_bf16 && (p.mode != S2K_MODE_CONV || T != 1)) return 1;
     if (p.mode == S2K_MODE_CONVT_SCATTER) {
         // ConvTranspose2d(k2, s2) forward: a 1x1 contraction with rows (co, dy, dx) and a scattering epilogue
         if (T != 1 || p.C2 != 0 || (p.HW & 3) || p.gate1 || p.M <= 32 || (p.M & 3)) return 1;
@@ -550,6 +574,10 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
             if (p.pro1 == S2K_PRO_SILU) return deep ? launch_b16_pix<128, S2K_PRO_SILU, true>(p, st) : launch_b16_pix<64, S2K_PRO_SILU, true>(p, st);
             return 1;
         }
+        if (p.x1_bf16) {      // X1 stored as bf16 (opdefs CONV.X1_BF16): planned only for this shape class; nothing else reads such a tensor
+            if (p.gate1 || p.pro1 != S2K_PRO_NONE || (p.HW & 7)) { set_error("conv: X1_BF16 is for plain 1x1 stages (no prologue, H*W % 8 == 0)"); return S2K_EINVAL; }
+            return deep ? launch_b16_pix<128, S2K_PRO_NONE, false, true>(p, st) : launch_b16_pix<64, S2K_PRO_NONE, false, true>(p, st);
+        }
         switch (p.pro1) {
             case S2K_PRO_NONE: return deep ? launch_b16_pix<128, S2K_PRO_NONE, false>(p, st) : launch_b16_pix<64, S2K_PRO_NONE, false>(p, st);
             case S2K_PRO_RELU: return launch_b16_pix<64, S2K_PRO_RELU, false>(p, st);
@@ -558,6 +586,7 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
             default: return 1;
         }
     }
+    if (p.x1_bf16) return 1;       // (1x1 only: the f32 launcher reports the error)
     if (T != 9 || p.KH != 3 || p.PT != 1 || p.PL != 1 || p.gate1) return 1;
     if (p.pro1 != S2K_PRO_NONE && p.pro1 != S2K_PRO_RELU) return 1;
     if (p.C2 > 0 && (p.pro2 != p.pro1 || (p.C1 % 16) != 0)) return 1;

@@ -1141,7 +1141,16 @@ __device__ __forceinline__ void bn_fuse_sums(const BnFuse& fz, int C, int c, int
 // MODE 0: dy = A*gp + Bq*xhat + Cq (BN_BWD_APPLY; MODE 2 = the same with the coefficients computed here from STATS2;
 // MODE 3 = MODE 2 with gp = (a*mul + add) * silu'(scale*y + shift) recomputed per element, see SE_BN_SUMS);
 // MODE 1: xout = (scale*y+shift)*dcs[b] + ident (BN_RESIDUAL)
-template <int MODE, bool VEC>
+// OUT16 (MODE 2, VEC): the result is stored as bf16 (round to nearest even, `v_cvt_pk_bf16_f32`) - dY of a bf16-mixed plan whose only
+// readers are bf16 MFMA stages that would round exactly these values themselves (opdefs CONV.X1_BF16)
+__device__ __forceinline__ uint32_t pm_pk_bf16(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+}
+
+template <int MODE, bool VEC, bool OUT16 = false>
 __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, const float* y, const float* bnv, const float* coef,
                                                              const float* noise, float* out, int C, int HW, int64_t nplanes,
                                                              float keep, const BnFuse fz, const BnFold fold = BnFold{}) {
@@ -1205,7 +1214,8 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
             float4 o;
             o.x = fmaf(k0, av.x, fmaf(k1, yv.x, k2)); o.y = fmaf(k0, av.y, fmaf(k1, yv.y, k2));
             o.z = fmaf(k0, av.z, fmaf(k1, yv.z, k2)); o.w = fmaf(k0, av.w, fmaf(k1, yv.w, k2));
-            reinterpret_cast<float4*>(out + base)[i] = o;
+            if constexpr (OUT16) reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + base)[i] = make_uint2(pm_pk_bf16(o.x, o.y), pm_pk_bf16(o.z, o.w));
+            else reinterpret_cast<float4*>(out + base)[i] = o;
         }
     } else {
         for (int i = lane; i < t.count; i += 64) {
@@ -1220,7 +1230,7 @@ __global__ void __launch_bounds__(NTHREADS) plane_map_kernel(const float* a, con
 // channels): one wave per CHANNEL (and batch chunk) forms the three coefficients once - the replica sums, two f64 products -
 // and walks the batch with 16 lanes per plane, four planes per pass, the loads of four passes in flight.  With one wave per
 // 64-element plane the coefficient arithmetic was most of the kernel (23 us for a 15 MB tensor).
-template <int MODE>
+template <int MODE, bool OUT16 = false>
 __global__ void __launch_bounds__(NTHREADS) bn_bwd_apply_small_kernel(const float* a, const float* y, const float* bnv, float* out,
                                                                       int B, int C, int HW, int lpp, const BnFuse fz) {
     const int lane = threadIdx.x & 63;
@@ -1272,19 +1282,20 @@ __global__ void __launch_bounds__(NTHREADS) bn_bwd_apply_small_kernel(const floa
             float4 o;
             o.x = fmaf(k0, g.x, fmaf(k1, yy.x, k2)); o.y = fmaf(k0, g.y, fmaf(k1, yy.y, k2));
             o.z = fmaf(k0, g.z, fmaf(k1, yy.z, k2)); o.w = fmaf(k0, g.w, fmaf(k1, yy.w, k2));
-            *reinterpret_cast<float4*>(out + ((int64_t)b * C + c) * HW + 4 * li) = o;
+            if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + ((int64_t)b * C + c) * HW + 4 * li) = make_uint2(pm_pk_bf16(o.x, o.y), pm_pk_bf16(o.z, o.w));
+            else *reinterpret_cast<float4*>(out + ((int64_t)b * C + c) * HW + 4 * li) = o;
         }
     }
 }
 
-template <int MODE>
+template <int MODE, bool OUT16 = false>
 static bool launch_bn_bwd_apply_small(const float* a, const float* y, const float* bnv, float* out, int B, int C, int HW,
                                       hipStream_t st, const BnFuse& fz) {
     if (HW > 64 || (HW & 3) || B < 2) return false;
     int lpp = 1;
     while (4 * lpp < HW) lpp <<= 1;
     const int bsplit = std::max(1, std::min(cdiv(B, 64 / lpp), cdiv(2048, C)));
-    hipLaunchKernelGGL((bn_bwd_apply_small_kernel<MODE>), dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, st, a, y, bnv, out, B, C, HW, lpp, fz);
+    hipLaunchKernelGGL((bn_bwd_apply_small_kernel<MODE, OUT16>), dim3(cdiv(C, 4), bsplit), dim3(NTHREADS), 0, st, a, y, bnv, out, B, C, HW, lpp, fz);
     return true;
 }
 
@@ -1346,6 +1357,7 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     if (!gp || !y || !bnv || !dy) { set_error("bn_bwd_apply: bad args"); return S2K_EINVAL; }
     const int B = op.d[S2K_BN_BWD_APPLY_D_B], C = op.d[S2K_BN_BWD_APPLY_D_C], HW = op.d[S2K_BN_BWD_APPLY_D_HW];
     if (coef) {
+        if (op.d[S2K_BN_BWD_APPLY_D_OUT_BF16]) { set_error("bn_bwd_apply: OUT_BF16 needs the fused form (no COEF)"); return S2K_EINVAL; }
         launch_plane_map<0>(gp, y, bnv, coef, nullptr, dy, B, C, HW, 1.0f, c.stream);
         return S2K_OK;
     }
@@ -1358,6 +1370,17 @@ int launch_bn_bwd_apply(const S2kOp& op, const Ctx& c) {
     fz.addscale = op.f[S2K_BN_BWD_APPLY_F_ADDSCALE];
     CHECK_PTRS("bn_bwd_apply", fz.mulbc, fz.addbc, fz.ps);
     if (fz.ps && op.d[S2K_BN_BWD_APPLY_D_ACT] != S2K_PRO_SILU) { set_error("bn_bwd_apply: PS belongs to the recomputing (SiLU) form"); return S2K_EINVAL; }
+    const bool out16 = op.d[S2K_BN_BWD_APPLY_D_OUT_BF16] != 0;
+    if (out16 && (op.d[S2K_BN_BWD_APPLY_D_ACT] != S2K_PRO_NONE || fz.mulbc || fz.addbc || (HW & 3) || dy == gp)) {
+        set_error("bn_bwd_apply: OUT_BF16 is for the plain fused form, HW % 4 == 0, out of place"); return S2K_EINVAL;
+    }
+    if (out16) {
+        if (launch_bn_bwd_apply_small<2, true>(gp, y, bnv, dy, B, C, HW, c.stream, fz)) return S2K_OK;
+        const int64_t nplanes = (int64_t)B * C;
+        hipLaunchKernelGGL((plane_map_kernel<2, true, true>), dim3(task_blocks(HW, nplanes)), dim3(NTHREADS), 0, c.stream, gp, y, bnv,
+                           (const float*)nullptr, (const float*)nullptr, dy, C, HW, nplanes, 1.0f, fz, BnFold{});
+        return S2K_OK;
+    }
     if (op.d[S2K_BN_BWD_APPLY_D_ACT] == S2K_PRO_NONE && !fz.mulbc && !fz.addbc) {
         if (launch_bn_bwd_apply_small<2>(gp, y, bnv, dy, B, C, HW, c.stream, fz)) return S2K_OK;
         launch_plane_map<2>(gp, y, bnv, nullptr, nullptr, dy, B, C, HW, 1.0f, c.stream, fz);

@@ -753,6 +753,7 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.w_sm = d[S2K_CONV_D_W_SM]; p.w_sk = d[S2K_CONV_D_W_SK]; p.w_st = d[S2K_CONV_D_W_ST];
     p.flip = d[S2K_CONV_D_FLIP]; p.beta = d[S2K_CONV_D_BETA]; p.YC = d[S2K_CONV_D_YC];
     p.nrep = d[S2K_CONV_D_NREP] > 0 ? d[S2K_CONV_D_NREP] : 1;
+    p.x1_bf16 = d[S2K_CONV_D_X1_BF16];
     const int T = p.KH * p.KW;
     p.Ctot = p.C1 + p.C2;
     p.HW = p.H * p.W;
@@ -794,6 +795,10 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         if (rc != 1) return rc;
         p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
         p.n_tiles = p.n_mtiles = 0;
+    }
+    if (p.x1_bf16) {   // planned only where conv_bf16.hip takes the stage (plan/bf16.py); the f32 kernels would read the halves as floats
+        set_error("conv: X1_BF16 on a stage the bf16 1x1 kernel does not take (FLAG_BF16 missing or shape not in its list)");
+        return S2K_EINVAL;
     }
     {   // the prologue-light, MFMA-bound shapes run on the producer / consumer kernels (igemm_pc.hip); 1 = not one of theirs
         const int rc = launch_conv_pc(p, st);

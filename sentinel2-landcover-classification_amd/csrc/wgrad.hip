@@ -466,6 +466,7 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
     p.S = d[S2K_WGRAD_D_STRIDE]; p.PT = d[S2K_WGRAD_D_PAD_T]; p.PL = d[S2K_WGRAD_D_PAD_L];
     p.HO = d[S2K_WGRAD_D_HO]; p.WO = d[S2K_WGRAD_D_WO]; p.prop = d[S2K_WGRAD_D_PROP]; p.proq = d[S2K_WGRAD_D_PROQ];
     const int mode = d[S2K_WGRAD_D_MODE];
+    p.p_bf16 = d[S2K_WGRAD_D_P_BF16];
     p.T = p.KH * p.KW;
     p.HWp = p.HO * p.WO;
     p.HWq = p.H * p.W;
@@ -482,6 +483,10 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         const int rc = launch_wgrad_bf16(p, mode, st);
         if (rc != 1) return rc;
         p.R = p.XW = p.XWe = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = 0;
+    }
+    if (p.p_bf16) {   // planned only where wgrad_bf16.hip takes the stage (plan/bf16.py); the f32 kernels would read the halves as floats
+        set_error("wgrad: P_BF16 on a stage the bf16 1x1 kernel does not take (FLAG_BF16 missing or shape not in its list)");
+        return S2K_EINVAL;
     }
     {   // the MFMA-bound shapes run on the producer / consumer kernels (wgrad_pc.hip); 1 = not one of theirs
         const int rc = launch_wgrad_pc(p, mode, st);

@@ -55,9 +55,12 @@ __device__ __forceinline__ wu32x4 pro_unit(const f32x4& a, const f32x4& b, int p
 // pixels of a tile over waves; every wave adds its partial sums in the combine.
 // Pixel tile: 1x1: XW consecutive pixels (R = 1); 3x3: R rows x XW pixels.
 // 1x1: two workgroups per CU; 3x3 (144 accumulator registers per lane + the next tile's staging registers): one.
-template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW>
+// P16 (1x1, no prologue on P): P is stored as bf16 [B][M][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): a lane's 8 pixels are ONE
+// 16-byte load and ARE the LDS unit - the values the f32 path would round to.
+template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW, bool P16 = false>
 __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel(const WgradP p) {
     constexpr bool PIX = MODE == WG_PIX;
+    static_assert(!P16 || PIX, "bf16 P: 1x1");
     constexpr int NT = 256;
     constexpr int T = PIX ? 1 : 9;
     constexpr int WVK = 4 / (WVM * WVC);
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
     }
     const int64_t ntot = (int64_t)p.B * p.HWp;
     const bool img_local = !PIX || (p.HWp % NPJ) == 0;
-    const uint32_t p_rstep = (uint32_t)p.HWp * 4u, q_rstep = (uint32_t)p.HWq * 4u;
+    const uint32_t p_rstep = (uint32_t)p.HWp * (P16 ? 2u : 4u), q_rstep = (uint32_t)p.HWq * 4u;
 
     f32x16 acc[T][WM][WN];
 #pragma unroll
@@ -135,7 +138,8 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
             tb = tile / (p.tiles_x * p.tiles_y);
             y0 = ty * R; x0 = tx * XW;
         }
-        const rsrc_t rp = make_rsrc(p.p + (int64_t)tb * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - tb) * p.M * p.HWp * 4);
+        const rsrc_t rp = P16 ? make_rsrc(reinterpret_cast<const uint16_t*>(p.p) + (int64_t)tb * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - tb) * p.M * p.HWp * 2)
+                              : make_rsrc(p.p + (int64_t)tb * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - tb) * p.M * p.HWp * 4);
         const rsrc_t rq = make_rsrc(p.q + (int64_t)tb * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - tb) * p.C * p.HWq * 4);
 #pragma unroll
         for (int ob = 0; ob < POB; ++ob) {
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
                 ok = ok && n < ntot;
                 const int64_t nn = ok ? n : 0;
                 const int b = (int)(nn / p.HWp);
-                off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (nn - (int64_t)b * p.HWp)) * 4u;
+                off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (nn - (int64_t)b * p.HWp)) * (P16 ? 2u : 4u);
             } else {
                 const int r = oct / XO, k = oct % XO;
                 off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * 4u;
@@ -158,8 +162,8 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
 #pragma unroll
             for (int j = 0; j < PRG; ++j) {
                 const uint32_t a = ok ? off + (uint32_t)prow[j] * p_rstep : BUF_OOB;
-                pxa[ob][j] = bload4(rp, a);
-                pxb[ob][j] = bload4(rp, ok ? a + 16u : BUF_OOB);
+                pxa[ob][j] = bload4(rp, a);                                   // (P16: the whole unit, eight bf16)
+                if constexpr (!P16) pxb[ob][j] = bload4(rp, ok ? a + 16u : BUF_OOB);
             }
         }
 #pragma unroll
@@ -212,8 +216,10 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
             const int oct = ob * 8 + o8;
             if (oct < NPO)
 #pragma unroll
-                for (int j = 0; j < PRG; ++j)
-                    Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pro_unit(pxa[ob][j], pxb[ob][j], p.prop, psc[j], psh[j], 1.0f, pok[ob]);
+                for (int j = 0; j < PRG; ++j) {
+                    if constexpr (P16) Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pok[ob] ? __builtin_bit_cast(wu32x4, pxa[ob][j]) : wu32x4{0u, 0u, 0u, 0u};
+                    else Ps[oct * BM + (wave + 4 * j) * 8 + r8] = pro_unit(pxa[ob][j], pxb[ob][j], p.prop, psc[j], psh[j], 1.0f, pok[ob]);
+                }
         }
 #pragma unroll
         for (int ob = 0; ob < QOB; ++ob) {
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW>
+template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW, bool P16 = false>
 static int launch_wb16(WgradP& p, hipStream_t st) {
     constexpr bool PIX = MODE == WG_PIX;
     constexpr int BM = WVM * WM * 32, BC = WVC * WN * 32;
@@ -320,7 +326,7 @@ static int launch_wb16(WgradP& p, hipStream_t st) {
         const int64_t need = std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 * span;
         if (need >= 0x7ffffff0ll) return 1;
     }
-    auto kern = wgrad_bf16_kernel<MODE, WVM, WVC, WM, WN, R, XW>;
+    auto kern = wgrad_bf16_kernel<MODE, WVM, WVC, WM, WN, R, XW, P16>;
     static PerDeviceOnce attr_once;
     attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     // Pixel splits.  Every split ends in an atomic combine of its accumulator tiles, and float atomics run at ~1.3 TB/s chip-wide
@@ -351,6 +357,16 @@ int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
     if (p.T == 1) {
         if ((p.HWp & 7) || (int64_t)p.B * p.HWp < 512) return 1;
         // thin sides: the waves split the pixels of 256-pixel tiles instead of the (single) accumulator tile
+        if (p.p_bf16) {       // P stored as bf16 (opdefs WGRAD.P_BF16)
+            if (p.prop != S2K_PRO_NONE) { set_error("wgrad: P_BF16 with a prologue on P"); return S2K_EINVAL; }
+            if (em == 32 && ec == 32) return launch_wb16<WG_PIX, 1, 1, 1, 1, 1, 256, true>(p, st);
+            if (em == 32) return launch_wb16<WG_PIX, 1, 2, 1, 1, 1, 128, true>(p, st);
+            if (ec == 32) return launch_wb16<WG_PIX, 2, 1, 1, 1, 1, 128, true>(p, st);
+            if (em == 128 && ec == 128) return launch_wb16<WG_PIX, 2, 2, 2, 2, 1, 64, true>(p, st);
+            if (em == 128) return launch_wb16<WG_PIX, 2, 2, 2, 1, 1, 64, true>(p, st);
+            if (ec == 128) return launch_wb16<WG_PIX, 2, 2, 1, 2, 1, 64, true>(p, st);
+            return launch_wb16<WG_PIX, 2, 2, 1, 1, 1, 64, true>(p, st);
+        }
         if (em == 32 && ec == 32) return launch_wb16<WG_PIX, 1, 1, 1, 1, 1, 256>(p, st);
         if (em == 32) return launch_wb16<WG_PIX, 1, 2, 1, 1, 1, 128>(p, st);          // 32 x 64, two waves per k-step
         if (ec == 32) return launch_wb16<WG_PIX, 2, 1, 1, 1, 1, 128>(p, st);          // 64 x 32
@@ -359,6 +375,7 @@ int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
         if (ec == 128) return launch_wb16<WG_PIX, 2, 2, 1, 2, 1, 64>(p, st);
         return launch_wb16<WG_PIX, 2, 2, 1, 1, 1, 64>(p, st);
     }
+    if (p.p_bf16) return 1;        // (1x1 only: the f32 launcher reports the error)
     if (p.T != 9 || p.KH != 3 || p.KW != 3 || p.PT != 1 || p.PL != 1 || p.gateq || p.prop != S2K_PRO_NONE) return 1;
     if (p.WO % 64 == 0) {
         if (em == 32 && ec == 32) return launch_wb16<WG_SPATIAL, 1, 1, 1, 1, 4, 64>(p, st);     // 32 x 32 tile, 4 x 64 pixels, waves split the pixels

@@ -73,16 +73,19 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # SCRATCH (optional, >= 8 * B*YC*HO*WO floats): lets the kernel cut a long reduction over few output tiles into
     # split-K partials that a tail kernel adds in a fixed order (deep 8x8 / 16x16 layers: 160 tiles cannot fill 256 CUs).
     # WTB (with FLAG_BF16): the bf16 copy of WT written by WEIGHT_PACK (BF16_BASE)
+    # X1_BF16 (bf16-mixed plans, 1x1 stages with FLAG_BF16, PRO1 = NONE, C2 = 0): X1 is stored as bf16 [B][C1][HW] - the output of a
+    # BN_BWD_APPLY with OUT_BF16.  The stage would round exactly these values to bf16 when it builds its MFMA operand, so results are
+    # bit-identical to reading the f32 tensor; the apply pass writes, and both consumers read, half the bytes.
     "CONV": (["X1", "BNV1", "GATE1", "X2", "BNV2", "WT", "BIAS", "Y", "STATS", "RES", "SCRATCH", "WTB"], [],
              ["B", "C1", "C2", "H", "W", "M", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
-              "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP"], []),
+              "PRO1", "PRO2", "MODE", "W_SM", "W_SK", "W_ST", "FLIP", "BETA", "YC", "NREP", "X1_BF16"], []),
     # Weight gradient on f32 MFMA, K = pixels:
     #   WGS[tap][m][c] += sum_{b,yo,xo} Ppro[b][m][yo][xo] * Qpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     # (MODE_GATHER2X2: Q tap (dy,dx) reads Q[b][c][2y+dy][2x+dx]).  Scratch layout [T][M][CTOT]
     # keeps the float atomics 128-B contiguous; WGRAD_FINALIZE folds it into [M][C][T] grads.
     "WGRAD": (["P", "BNVP", "GATEP", "Q", "BNVQ", "GATEQ", "WGS"], [],
               ["B", "M", "C", "CTOT", "H", "W", "KH", "KW", "STRIDE", "PAD_T", "PAD_L", "HO", "WO",
-               "PROP", "PROQ", "MODE"], []),
+               "PROP", "PROQ", "MODE", "P_BF16"], []),     # P_BF16: as CONV.X1_BF16, for P (1x1, PROP = NONE)
     # GRADS[off + (m*C + c)*T + t] += WGS[off + (t*M + m)*C + c] for every TABLE entry {off, M, C, T, start}
     "WGRAD_FINALIZE": (["TABLE", "WGS", "GRADS"], ["TOTAL"], ["N_ENTRIES"], []),
     # depthwise KxK, TF-SAME pads, prologue on X, BN stats of Y
@@ -124,7 +127,7 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # PS given (recomputing form): the sums are combined here from SE_BN_SUMS's plane sums (SE_BN_COMBINE's arithmetic, done by
     # every wave for its channel: 6*B values from L2) and STATS2 is not read - one launch less per depthwise BatchNorm
     "BN_BWD_APPLY": (["GP", "Y", "BNV", "COEF", "DY", "STATS2", "GAMMA", "DGAMMA", "DBETA", "MULBC", "ADDBC", "PS"], ["COUNT"],
-                     ["B", "C", "HW", "NREP", "ACT", "EVAL"], ["ADDSCALE"]),
+                     ["B", "C", "HW", "NREP", "ACT", "EVAL", "OUT_BF16"], ["ADDSCALE"]),     # OUT_BF16: DY is written as bf16 (RNE), HW % 4 == 0
     # XOUT = (scale*Y+shift) * dcs[b] + IDENT
     "BN_RESIDUAL": (["Y", "BNV", "IDENT", "NOISE", "XOUT"] + FOLD_T, FOLD_N, ["B", "C", "HW"] + FOLD_D, ["KEEP"] + FOLD_F),
     # OUT[c] += sum_{b,hw} G[b][c][hw]

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import opdefs as D
 
-ITEMSIZE = {"f32": 4, "f64": 8, "i64": 8, "i32": 4, "i16": 2, "u8": 1}
+ITEMSIZE = {"f32": 4, "f64": 8, "i64": 8, "i32": 4, "i16": 2, "u8": 1, "bf16": 2}
 ALIGN = 256
 
 OP_DTYPE = np.dtype([("kind", "<i4"), ("flags", "<i4"), ("t", "<i8", (D.N_T,)), ("n", "<i8", (D.N_N,)),

@@ -254,9 +254,11 @@ def _stats(p: _P, name: str, C: int) -> TRef:
 
 def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: int, act: int,
                  mulbc=None, addbc=None, addscale=0.0, noise=None, keep=1.0, inplace=True,
-                 pre_stats: TRef | None = None) -> TRef:
+                 pre_stats: TRef | None = None, out_bf16: bool = False) -> TRef:
     """REDUCE -> FINALIZE -> APPLY; returns dY (grad w.r.t. the raw conv output).
-    `pre_stats`: G already is g' and its sums were accumulated by the producer of G (fused dgrad)."""
+    `pre_stats`: G already is g' and its sums were accumulated by the producer of G (fused dgrad).
+    out_bf16 (bf16-mixed plans): dY is written as bf16 into its own tensor - its only readers are bf16 MFMA stages that would round
+    exactly these values themselves (opdefs CONV.X1_BF16), so the results do not change and three passes move half the bytes."""
     B = p.B
     if pre_stats is not None:
         st2, gp = pre_stats, G
@@ -266,10 +268,11 @@ def _bn_backward(p: _P, prefix: str, G: TRef, y: TRef, bnv: TRef, C: int, HW: in
         p.bwd.add("BN_BWD_REDUCE", G=G, Y=y, BNV=bnv, MULBC=mulbc, ADDBC=addbc, NOISE=noise, GOUT=gp, STATS2=st2,
                   B=B, C=C, HW=HW, ACT=act, NREP=D.stats_replicas(C), KEEP=keep, ADDSCALE=addscale)
     # the FINALIZE step (replica sums -> coefficients, dgamma / dbeta) runs inside APPLY: one launch less per BatchNorm
-    p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=None, DY=gp, STATS2=st2, GAMMA=p.param(prefix + ".weight"),
+    dy = p.alloc("dy16:" + prefix, (B, C, HW), "bf16") if out_bf16 else gp
+    p.bwd.add("BN_BWD_APPLY", GP=gp, Y=y, BNV=bnv, COEF=None, DY=dy, STATS2=st2, GAMMA=p.param(prefix + ".weight"),
               DGAMMA=p.pgrad(prefix + ".weight"), DBETA=p.pgrad(prefix + ".bias"), COUNT=B * HW, B=B, C=C, HW=HW,
-              NREP=D.stats_replicas(C), EVAL=int(not p.training))
-    return gp
+              NREP=D.stats_replicas(C), EVAL=int(not p.training), OUT_BF16=int(out_bf16))
+    return dy
 
 
 def _conv_geometry(src: Act, k: int, stride: int, same: bool):
@@ -281,11 +284,31 @@ def _conv_geometry(src: Act, k: int, stride: int, same: bool):
     return Ho, Wo, pt, pl
 
 
+def _dy_bf16_ok(p: _P, srcs: list[Act], M: int, k: int, stride: int, Ho: int, Wo: int, bias_grad_from: str | None) -> bool:
+    """May the dY in front of this conv's backward be STORED as bf16?  Only where every reader is a bf16 1x1 stage without a prologue
+    on that operand (csrc/conv_bf16.hip X16, wgrad_bf16.hip P16): it would round the same values itself."""
+    from . import bf16 as B16
+
+    if not (getattr(p, "bf16", False) and k == 1 and stride == 1 and bias_grad_from is None and (Ho * Wo) % 8 == 0
+            and tune("S2K_DY_BF16", "1") != "0"):
+        return False
+    geo = dict(B=p.B, H=Ho, W=Wo, HO=Ho, WO=Wo, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, MODE=D.MODE_CONV)
+    for s_ in srcs:
+        if s_.H != Ho or s_.W != Wo:
+            return False
+        if not B16.wgrad_ok(dict(geo, M=M, C=s_.C, PROP=D.PRO_NONE, PROQ=s_.pro, GATEP=None, GATEQ=s_.gate)):
+            return False
+        if s_.needs_grad and not B16.conv_ok(dict(geo, C1=M, C2=0, M=s_.C, PRO1=D.PRO_NONE, PRO2=D.PRO_NONE, GATE1=None)):
+            return False
+    return True
+
+
 def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: int, stride: int,
                       pt: int, pl: int, Ho: int, Wo: int, bias_grad_from: str | None):
-    """Backward of a dense conv given dY [B,M,Ho,Wo]."""
+    """Backward of a dense conv given dY [B,M,Ho,Wo] (f32, or bf16 where _dy_bf16_ok said so: dY.dtype tells)."""
     B = p.B
     T = k * k
+    dy16 = int(dY.dtype == "bf16")
     Ctot = sum(s.C for s in srcs)
     # 1x1: the scratch layout [tap][M][C] IS the parameter's layout [M][C][1], so the kernel accumulates straight into the
     # (zeroed) gradient buffer: no scratch memset, no WGRAD_FINALIZE traffic for these weights (most of the encoder / every Linear)
@@ -298,7 +321,7 @@ def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: i
         p.bwd.add("WGRAD", P=dY, BNVP=None, GATEP=None, Q=s.raw, BNVQ=s.bnv, GATEQ=s.gate,
                   WGS=wtarget.at(c_off), B=B, M=M, C=s.C, CTOT=Ctot, H=s.H, W=s.W, KH=k, KW=k,
                   STRIDE=stride, PAD_T=pt, PAD_L=pl, HO=Ho, WO=Wo, PROP=D.PRO_NONE, PROQ=s.pro,
-                  MODE=D.MODE_CONV)
+                  MODE=D.MODE_CONV, P_BF16=dy16)
         c_off += s.C
     if bias_grad_from is not None:
         p.bwd.add("CHANNEL_SUM", G=dY, OUT=p.pgrad(bias_grad_from), B=B, C=M, HW=Ho * Wo)
@@ -319,7 +342,8 @@ def _conv_dgrad_wgrad(p: _P, wname: str, dY: TRef, srcs: list[Act], M: int, k: i
                       WT=wp, BIAS=None, Y=g, STATS=None,
                       B=B, C1=M, C2=0, H=Hd, W=Wd, M=s.C, KH=k, KW=k, STRIDE=1,
                       PAD_T=k - 1 - pt, PAD_L=k - 1 - pl, HO=s.H, WO=s.W, PRO1=D.PRO_NONE, PRO2=D.PRO_NONE,
-                      MODE=D.MODE_CONV, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(s.grad_init), YC=s.C, NREP=1)
+                      MODE=D.MODE_CONV, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(s.grad_init), YC=s.C, NREP=1,
+                      X1_BF16=dy16 if src_dy is dY else 0)
             s.grad_init = True
         c_off += s.C
 
@@ -359,11 +383,13 @@ def conv_bn(p: _P, wname: str, bnprefix: str, srcs: list[Act], M: int, k: int, s
     def backward():
         if not out.grad_init:
             raise RuntimeError(f"no gradient reached {wname}")
+        bias_g = bias if (bias and not p.training) else None
         dY = _bn_backward(p, bnprefix, out.grad, y, bnv, M, Ho * Wo, act,
-                          out.mulbc, out.addbc, out.addscale, pre_stats=out.fused_stats2)
+                          out.mulbc, out.addbc, out.addscale, pre_stats=out.fused_stats2,
+                          out_bf16=_dy_bf16_ok(p, srcs, M, k, stride, Ho, Wo, bias_g))
         # a bias in front of TRAIN-mode BatchNorm has exactly zero gradient (the batch mean absorbs it: sum of dY is 0), so no
         # stage is spent on it; with eval-mode BatchNorm (constant statistics) it is sum(dY) like any other bias
-        _conv_dgrad_wgrad(p, wname, dY, srcs, M, k, stride, pt, pl, Ho, Wo, bias if (bias and not p.training) else None)
+        _conv_dgrad_wgrad(p, wname, dY, srcs, M, k, stride, pt, pl, Ho, Wo, bias_g)
 
     p.tape.append(backward)
     return out
@@ -402,7 +428,8 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
                 ident.grad, ident.grad_init = G, True      # alias: later dgrads accumulate in place
             else:
                 p.bwd.add("AXPY", X=G, Y=ident.grad, COUNT=B * M * H * W)
-        dY = _bn_backward(p, bnprefix, G, y, bnv, M, H * W, D.ACT_NONE, noise=noise, keep=keep, inplace=False)
+        dY = _bn_backward(p, bnprefix, G, y, bnv, M, H * W, D.ACT_NONE, noise=noise, keep=keep, inplace=False,
+                          out_bf16=_dy_bf16_ok(p, [src], M, 1, 1, H, W, None))
         _conv_dgrad_wgrad(p, wname, dY, [src], M, 1, 1, 0, 0, H, W, None)
 
     p.tape.append(backward)

@@ -15,7 +15,8 @@ from s2lc_amd.plan.program import Arena, Program
 pytestmark = pytest.mark.gpu
 
 WS = D.BASE["WS"]
-_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8}
+_DT = {"f32": torch.float32, "f64": torch.float64, "i64": torch.int64, "i32": torch.int32, "i16": torch.int16, "u8": torch.uint8,
+       "bf16": torch.bfloat16}
 
 
 class Case:
@@ -166,6 +167,55 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
           BIAS=bs, Y=y, STATS=st_ref, B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho,
           WO=Wo, PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=beta, YC=YC, **extra)
+
+
+@pytest.mark.parametrize("B,M,C,H,W", [(4, 240, 40, 16, 16), (3, 24, 48, 20, 28), (2, 40, 240, 64, 64), (5, 1056, 176, 8, 16), (2, 32, 16, 64, 64),
+                                        (8, 1824, 304, 8, 8)])       # deep reduction: 128-channel chunks, ragged packed K
+def test_dy_stored_as_bf16_between_bn_apply_and_its_1x1_readers(B, M, C, H, W):
+    """bf16-mixed plans keep the dY of a BatchNorm whose only readers are bf16 1x1 stages in bf16 (opdefs CONV.X1_BF16): BN_BWD_APPLY
+    rounds on store (OUT_BF16), the data-gradient CONV (X1_BF16) and the weight gradient's P operand (P_BF16) read the halves.
+    M = channels of the BatchNorm (the conv's output), C = the conv's input channels."""
+    HW = H * W
+    # 1. the apply pass: same arithmetic as the f32 form, rounded to nearest even on store; an element within an ulp of a rounding
+    #    boundary may land on the other neighbour (2^-8 relative), hence 8e-3 of the largest value
+    c = Case(44)
+    gp, y = c.t("gp", (B, M, HW), scale=0.3), c.t("y", (B, M, HW))
+    bnv, gam = c.bnv("bnv", M), c.t("gamma", (M,), "pos")
+    nrep = D.stats_replicas(M)
+    st2 = c.t("st2", (nrep, 2, M), torch.randn(nrep, 2, M, dtype=torch.float64, generator=c.gen) * 3, "f64")
+    dg, db = c.t("dgamma", (M,)), c.t("dbeta", (M,))
+    dy = c.t("dy", (B, M, HW), "nan", "bf16")
+    c.run("BN_BWD_APPLY", ["dy", "dgamma", "dbeta"], 8e-3, GP=gp, Y=y, BNV=bnv, COEF=None, DY=dy, STATS2=st2, GAMMA=gam, DGAMMA=dg, DBETA=db,
+          COUNT=B * HW, B=B, C=M, HW=HW, NREP=nrep, OUT_BF16=1)
+    # 2. the data gradient reads it: dX[c] = sum_m W[m][c] * dY[m]   (identical operand values on both sides: 1e-4)
+    c2 = Case(45)
+    dyb = c2.t("dy", (B, M, H, W), "randn", "bf16", scale=0.3)
+    wt = c2.t("wt", (C, M, 1), scale=M ** -0.5)
+    dx = c2.t("dx", (B, C, H, W), "randn")
+    pre, wp, MP, wp16 = c2.pack(wt, C, M, 1, M, 1, 1, 0, bf16=True)
+    c2.run("CONV", ["dx"], 1e-4, pre=[pre], want_variant=2, _flags=D.FLAG_BF16, WTB=wp16, X1=dyb, BNV1=None, GATE1=None, X2=None, BNV2=None,
+           WT=wp, BIAS=None, Y=dx, STATS=None, B=B, C1=M, C2=0, H=H, W=W, M=C, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=W,
+           PRO1=D.PRO_NONE, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=1, YC=C, NREP=1, X1_BF16=1)
+    # 3. the weight gradient reads it as P: dW[m][c] += sum_pix dY[m] * Qpro[c]
+    c3 = Case(46)
+    dyb = c3.t("dy", (B, M, H, W), "randn", "bf16", scale=0.3)
+    q, bq = c3.t("q", (B, C, H, W)), c3.bnv("bnvq", C)
+    wgs = c3.t("wgs", (1, M, C), "randn")
+    c3.run("WGRAD", ["wgs"], 1e-3, want_variant=2, _flags=D.FLAG_BF16, P=dyb, BNVP=None, GATEP=None, Q=q, BNVQ=bq, GATEQ=None, WGS=wgs, B=B, M=M,
+           C=C, CTOT=C, H=H, W=W, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=W, PROP=D.PRO_NONE, PROQ=D.PRO_SILU, MODE=D.MODE_CONV, P_BF16=1)
+
+
+def test_bf16_stored_operand_is_refused_by_the_f32_kernels():
+    """nothing but the bf16 1x1 kernels reads a bf16 tensor: an unflagged stage must fail loudly, not read the halves as floats"""
+    from s2lc_amd import _lib
+
+    c = Case(47)
+    B, M, C, H = 2, 16, 8, 8
+    dyb = c.t("dy", (B, M, H, H), "randn", "bf16")
+    q, wgs = c.t("q", (B, C, H, H)), c.t("wgs", (1, M, C), "zeros")
+    with pytest.raises(_lib.S2kError, match="P_BF16"):
+        c.run("WGRAD", ["wgs"], 1e-3, P=dyb, BNVP=None, GATEP=None, Q=q, BNVQ=None, GATEQ=None, WGS=wgs, B=B, M=M, C=C, CTOT=C, H=H, W=H, KH=1, KW=1,
+              STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=H, PROP=D.PRO_NONE, PROQ=D.PRO_NONE, MODE=D.MODE_CONV, P_BF16=1)
 
 
 # ---- bf16-mixed: the same stage records with FLAG_BF16 (csrc/conv_bf16.hip) -----------------------------------------------------------
