@@ -89,6 +89,9 @@ __device__ __forceinline__ float bload_s(rsrc_t r, uint32_t voff, uint32_t soff)
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, uint32_t byte_off) {   // 16-byte aligned offsets only
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+__device__ __forceinline__ uint32_t bload_u16(rsrc_t r, uint32_t byte_off) {      // one 16-bit element, zero-extended (out of range -> 0)
+    return (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, 0);
+}
 // (the vector the b64 builtin returns must be bit-cast as a WHOLE: indexing it - v[0], v[1] - makes this compiler emit a single
 // buffer_load_dword and copy the dword into both elements)
 __device__ __forceinline__ float2 bload2(rsrc_t r, uint32_t byte_off) {

@@ -42,12 +42,13 @@ __device__ __forceinline__ int swz(int s) { return s ^ ((s >> 3) & 3); }
 
 // PRO: S2K_PRO_NONE / RELU / SILU / AFFINE (1x1), NONE / RELU (3x3).  GATE: SE gate [B][C1] multiplies the activated value (1x1).
 // SCATTER (1x1): S2K_MODE_CONVT_SCATTER - rows m = (co, dy, dx) are stored to Y[b][co][2y + dy][2x + dx] (ConvTranspose2d k2 s2).
-// X16 (1x1, no prologue): X1 is stored as bf16 [B][C1][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): four pixels of a channel are one
-// 8-byte load, the operand units are assembled with v_perm_b32 - no conversion, the values are the ones the f32 path would round to.
+// X16 (no prologue, one source): X1 is stored as bf16 [B][C1][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): 1x1 - four pixels of a channel
+// are one 8-byte load; 3x3 - a halo element is one 16-bit load; the operand units are assembled from the halves - no conversion,
+// the values are the ones the f32 path would round to.
 template <int BMODE, int WVM, int WM, int WN, int KCH, int R, int XW, int PRO, bool GATE, bool SCATTER = false, bool X16 = false>
 __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
     constexpr bool PIX = BMODE == BM_PIX;
-    static_assert(!X16 || (PIX && PRO == S2K_PRO_NONE && !GATE && !SCATTER), "bf16 X1: plain 1x1");
+    static_assert(!X16 || (PRO == S2K_PRO_NONE && !GATE && !SCATTER), "bf16 X1: no prologue");
     constexpr int NT = 256;
     constexpr int WVN = 4 / WVM;
     constexpr int BM = WVM * WM * 32, BN = WVN * WN * 32;
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
             const int e = it % USED, co = it / USED;
             const int iy = y0 - p.PT + e / WS, ix = x0 - p.PL + e % WS;
             const bool ok = it < B_ITEMS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            bvoff[i] = ok ? (uint32_t)(iy * p.W + ix) * 4u : BUF_OOB;
+            bvoff[i] = ok ? (uint32_t)(iy * p.W + ix) * (X16 ? 2u : 4u) : BUF_OOB;
             bound[PIX ? 0 : i] = ok ? __builtin_inff() : 0.0f;
             b_dst[i] = co * USED + e;
             b_co[i] = co;
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int c = min(cb + 8 * b_co[i] + q, cn - 1);
-                    bs[PIX ? 0 : i][q] = first ? bload(rx1, bvoff[i] + (uint32_t)c * cs4) : bload(rx2, bvoff[i] + (uint32_t)c * cs4);
+                    if constexpr (X16) bs[PIX ? 0 : i][q] = __builtin_bit_cast(float, bload_u16(rx1, bvoff[i] + (uint32_t)c * cs4));   // (C2 = 0)
+                    else bs[PIX ? 0 : i][q] = first ? bload(rx1, bvoff[i] + (uint32_t)c * cs4) : bload(rx2, bvoff[i] + (uint32_t)c * cs4);
                 }
         }
     };
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sc[q] = s0[q]; sc[4 + q] = s1[q]; sh[q] = h0[q]; sh[4 + q] = h1[q]; }
             }
-            if constexpr (X16) {
+            if constexpr (X16 && PIX) {
                 // dword d of channel q holds pixels 2d (low half) and 2d + 1 (high half): unit e = pixel e of the eight channels
                 uint32_t lo[8], hi[8];
 #pragma unroll
@@ -234,6 +236,11 @@ __global__ void __launch_bounds__(256, 2) conv_bf16_kernel(const ConvP p) {
                     const int s = (b_dst[i] % BN) + e;
                     Bs[(b_dst[i] - (b_dst[i] % BN)) + swz(s)] = w;
                 }
+            } else if constexpr (X16) {
+                uint32_t hb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hb[q] = __builtin_bit_cast(uint32_t, bs[PIX ? 0 : i][q]);      // zero-extended halves; padding = 0
+                Bs[b_dst[i]] = u32x4{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16)};
             } else {
                 float v[8];
 #pragma unroll
@@ -552,7 +559,7 @@ static int launch_b16_pix(ConvP& p, hipStream_t st) {
 int launch_conv_bf16(ConvP& p, hipStream_t st) {
     if (!p.wtb || p.S != 1 || p.HO != p.H || p.WO != p.W) return 1;
     const int T = p.KH * p.KW;
-    if (p.x1_bf16 && (p.mode != S2K_MODE_CONV || T != 1)) return 1;
+    if (p.x1_bf16 && p.mode != S2K_MODE_CONV) return 1;
     if (p.mode == S2K_MODE_CONVT_SCATTER) {
         // ConvTranspose2d(k2, s2) forward: a 1x1 contraction with rows (co, dy, dx) and a scattering epilogue
         if (T != 1 || p.C2 != 0 || (p.HW & 3) || p.gate1 || p.M <= 32 || (p.M & 3)) return 1;
@@ -586,9 +593,9 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
             default: return 1;
         }
     }
-    if (p.x1_bf16) return 1;       // (1x1 only: the f32 launcher reports the error)
     if (T != 9 || p.KH != 3 || p.PT != 1 || p.PL != 1 || p.gate1) return 1;
     if (p.pro1 != S2K_PRO_NONE && p.pro1 != S2K_PRO_RELU) return 1;
+    if (p.x1_bf16 && (p.pro1 != S2K_PRO_NONE || p.C2 != 0)) return 1;      // (the f32 launcher reports the error)
     if (p.C2 > 0 && (p.pro2 != p.pro1 || (p.C1 % 16) != 0)) return 1;
     auto tiles = [&](int r, int xw) {
         p.R = r; p.XW = xw; p.IR = r + 2; p.IC = xw + 2; p.WS = xw + 2; p.CS = p.IR * p.WS;
@@ -598,11 +605,13 @@ int launch_conv_bf16(ConvP& p, hipStream_t st) {
     };
     const bool relu = p.pro1 == S2K_PRO_RELU;
 #define B16_3X3(RR, XX) { const int n = tiles(RR, XX); \
+        if (p.x1_bf16) return launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_NONE, false, false, true>(p, n, st); \
         return relu ? launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_RELU, false>(p, n, st) \
                     : launch_b16_bm<BM_SPATIAL, 16, RR, XX, S2K_PRO_NONE, false>(p, n, st); }
     if (p.M <= 32) {
         if (p.WO < 64 || p.WO % 64 != 0) return 1;
         const int n = tiles(4, 64);
+        if (p.x1_bf16) return launch_b16<BM_SPATIAL, 1, 1, 2, 16, 4, 64, S2K_PRO_NONE, false, false, true>(p, n, st);
         return relu ? launch_b16<BM_SPATIAL, 1, 1, 2, 16, 4, 64, S2K_PRO_RELU, false>(p, n, st)
                     : launch_b16<BM_SPATIAL, 1, 1, 2, 16, 4, 64, S2K_PRO_NONE, false>(p, n, st);
     }

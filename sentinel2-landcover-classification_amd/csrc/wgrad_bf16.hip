@@ -55,12 +55,12 @@ __device__ __forceinline__ wu32x4 pro_unit(const f32x4& a, const f32x4& b, int p
 // pixels of a tile over waves; every wave adds its partial sums in the combine.
 // Pixel tile: 1x1: XW consecutive pixels (R = 1); 3x3: R rows x XW pixels.
 // 1x1: two workgroups per CU; 3x3 (144 accumulator registers per lane + the next tile's staging registers): one.
-// P16 (1x1, no prologue on P): P is stored as bf16 [B][M][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): a lane's 8 pixels are ONE
+// P16 (no prologue on P): P is stored as bf16 [B][M][HW] (a BN_BWD_APPLY with OUT_BF16 wrote it): a lane's 8 pixels are ONE
 // 16-byte load and ARE the LDS unit - the values the f32 path would round to.
 template <int MODE, int WVM, int WVC, int WM, int WN, int R, int XW, bool P16 = false>
 __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel(const WgradP p) {
     constexpr bool PIX = MODE == WG_PIX;
-    static_assert(!P16 || PIX, "bf16 P: 1x1");
+
     constexpr int NT = 256;
     constexpr int T = PIX ? 1 : 9;
     constexpr int WVK = 4 / (WVM * WVC);
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256, MODE == WG_PIX ? 2 : 1) wgrad_bf16_kernel
                 off = (uint32_t)((int64_t)(b - tb) * p.M * p.HWp + (nn - (int64_t)b * p.HWp)) * (P16 ? 2u : 4u);
             } else {
                 const int r = oct / XO, k = oct % XO;
-                off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * 4u;
+                off = (uint32_t)((y0 + r) * p.WO + x0 + 8 * k) * (P16 ? 2u : 4u);
                 ok = ok && y0 + r < p.HO;
             }
             pok[ob] = ok;
@@ -375,17 +375,18 @@ int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st) {
         if (ec == 128) return launch_wb16<WG_PIX, 2, 2, 1, 2, 1, 64>(p, st);
         return launch_wb16<WG_PIX, 2, 2, 1, 1, 1, 64>(p, st);
     }
-    if (p.p_bf16) return 1;        // (1x1 only: the f32 launcher reports the error)
     if (p.T != 9 || p.KH != 3 || p.KW != 3 || p.PT != 1 || p.PL != 1 || p.gateq || p.prop != S2K_PRO_NONE) return 1;
+#define WB16_3X3(...) (p.p_bf16 ? launch_wb16<WG_SPATIAL, __VA_ARGS__, true>(p, st) : launch_wb16<WG_SPATIAL, __VA_ARGS__>(p, st))
     if (p.WO % 64 == 0) {
-        if (em == 32 && ec == 32) return launch_wb16<WG_SPATIAL, 1, 1, 1, 1, 4, 64>(p, st);     // 32 x 32 tile, 4 x 64 pixels, waves split the pixels
-        if (em == 32) return launch_wb16<WG_SPATIAL, 1, 2, 1, 1, 4, 64>(p, st);
-        if (ec == 32) return launch_wb16<WG_SPATIAL, 2, 1, 1, 1, 4, 64>(p, st);
-        return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 64>(p, st);      // 4 x 64 pixel tiles: halo 6 rows per 4
+        if (em == 32 && ec == 32) return WB16_3X3(1, 1, 1, 1, 4, 64);     // 32 x 32 tile, 4 x 64 pixels, waves split the pixels
+        if (em == 32) return WB16_3X3(1, 2, 1, 1, 4, 64);
+        if (ec == 32) return WB16_3X3(2, 1, 1, 1, 4, 64);
+        return WB16_3X3(2, 2, 1, 1, 4, 64);      // 4 x 64 pixel tiles: halo 6 rows per 4
     }
-    if (p.WO % 56 == 0) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 2, 56>(p, st);      // 224-pixel inputs: 56 / 112 / 224 wide maps
-    if (p.WO == 32) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 4, 32>(p, st);
-    if (p.WO == 16) return launch_wb16<WG_SPATIAL, 2, 2, 1, 1, 8, 16>(p, st);
+    if (p.WO % 56 == 0) return WB16_3X3(2, 2, 1, 1, 2, 56);      // 224-pixel inputs: 56 / 112 / 224 wide maps
+    if (p.WO == 32) return WB16_3X3(2, 2, 1, 1, 4, 32);
+    if (p.WO == 16) return WB16_3X3(2, 2, 1, 1, 8, 16);
+#undef WB16_3X3
     return 1;
 }
 

@@ -285,14 +285,14 @@ def _conv_geometry(src: Act, k: int, stride: int, same: bool):
 
 
 def _dy_bf16_ok(p: _P, srcs: list[Act], M: int, k: int, stride: int, Ho: int, Wo: int, bias_grad_from: str | None) -> bool:
-    """May the dY in front of this conv's backward be STORED as bf16?  Only where every reader is a bf16 1x1 stage without a prologue
-    on that operand (csrc/conv_bf16.hip X16, wgrad_bf16.hip P16): it would round the same values itself."""
+    """May the dY in front of this conv's backward be STORED as bf16?  Only where every reader is a bf16 stage (1x1 or 3x3 stride 1)
+    without a prologue on that operand (csrc/conv_bf16.hip X16, wgrad_bf16.hip P16): it would round the same values itself."""
     from . import bf16 as B16
 
-    if not (getattr(p, "bf16", False) and k == 1 and stride == 1 and bias_grad_from is None and (Ho * Wo) % 8 == 0
+    if not (getattr(p, "bf16", False) and k in (1, 3) and stride == 1 and bias_grad_from is None and Wo % 8 == 0
             and tune("S2K_DY_BF16", "1") != "0"):
         return False
-    geo = dict(B=p.B, H=Ho, W=Wo, HO=Ho, WO=Wo, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, MODE=D.MODE_CONV)
+    geo = dict(B=p.B, H=Ho, W=Wo, HO=Ho, WO=Wo, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, MODE=D.MODE_CONV)
     for s_ in srcs:
         if s_.H != Ho or s_.W != Wo:
             return False

@@ -205,6 +205,26 @@ def test_dy_stored_as_bf16_between_bn_apply_and_its_1x1_readers(B, M, C, H, W):
            C=C, CTOT=C, H=H, W=W, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=H, WO=W, PROP=D.PRO_NONE, PROQ=D.PRO_SILU, MODE=D.MODE_CONV, P_BF16=1)
 
 
+@pytest.mark.parametrize("B,M,C,H,W", [(2, 64, 48, 32, 64), (3, 32, 32, 64, 64), (8, 128, 72, 16, 16), (4, 96, 64, 32, 32), (2, 40, 48, 20, 56)])
+def test_dy_stored_as_bf16_read_by_3x3_stages(B, M, C, H, W):
+    """the decoder's double convs: the 3x3 data-gradient CONV reads a halo element as one 16-bit load, the 3x3 weight gradient's P
+    operand 8 pixels as one 16-byte load (M = channels of dY, C = the conv's input channels)"""
+    c2 = Case(48)
+    dyb = c2.t("dy", (B, M, H, W), "randn", "bf16", scale=0.3)
+    wt = c2.t("wt", (C, M, 9), scale=(9 * M) ** -0.5)
+    dx = c2.t("dx", (B, C, H, W), "randn")
+    pre, wp, MP, wp16 = c2.pack(wt, C, M, 9, M * 9, 9, 1, 0, bf16=True)
+    c2.run("CONV", ["dx"], 1e-4, pre=[pre], want_variant=2, _flags=D.FLAG_BF16, WTB=wp16, X1=dyb, BNV1=None, GATE1=None, X2=None, BNV2=None,
+           WT=wp, BIAS=None, Y=dx, STATS=None, B=B, C1=M, C2=0, H=H, W=W, M=C, KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=W,
+           PRO1=D.PRO_NONE, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=9 * MP, W_ST=MP, FLIP=0, BETA=1, YC=C, NREP=1, X1_BF16=1)
+    c3 = Case(49)
+    dyb = c3.t("dy", (B, M, H, W), "randn", "bf16", scale=0.3)
+    q, bq = c3.t("q", (B, C, H, W)), c3.bnv("bnvq", C)
+    wgs = c3.t("wgs", (9, M, C), "randn")
+    c3.run("WGRAD", ["wgs"], 1e-3, want_variant=2, _flags=D.FLAG_BF16, P=dyb, BNVP=None, GATEP=None, Q=q, BNVQ=bq, GATEQ=None, WGS=wgs, B=B, M=M,
+           C=C, CTOT=C, H=H, W=W, KH=3, KW=3, STRIDE=1, PAD_T=1, PAD_L=1, HO=H, WO=W, PROP=D.PRO_NONE, PROQ=D.PRO_RELU, MODE=D.MODE_CONV, P_BF16=1)
+
+
 def test_bf16_stored_operand_is_refused_by_the_f32_kernels():
     """nothing but the bf16 1x1 kernels reads a bf16 tensor: an unflagged stage must fail loudly, not read the halves as floats"""
     from s2lc_amd import _lib
