@@ -12,6 +12,8 @@
 // K and S are compile-time.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace s2k {
@@ -324,6 +326,91 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
     }
 }
 
+// ---- forward on small square planes (8 x 8 and 16 x 16, stride 1: the deep MBConv blocks) --------------------------------------------
+// The band kernel above stages a group of planes, synchronises the workgroup, computes, stores - one pass per workgroup, so its HBM
+// round trip, the SiLU prologue, the K*K multiply-adds and the stores follow one another and only other workgroups on the CU overlap
+// them (16 x 16, k = 5: 42 us for 69 MB = 1.65 TB/s; the bare structure without prologue and statistics: 26 us; a copy: 11 us).
+// Here ONE WAVE owns a channel and walks (a chunk of) the batch with no workgroup barrier at all: the plane after the current one is
+// already in flight (one 16-byte load per lane = the whole 16 x 16 plane per instruction; four 8 x 8 planes), the current one goes
+// through the prologue into a wave-private LDS tile whose zero halo is written once, every lane computes 4 outputs from K rows of
+// three aligned 16-byte LDS reads, stores them and keeps the channel's BatchNorm sums in registers: one f64 atomic pair per wave,
+// the input BatchNorm's fold (opdefs.FOLD_*) and the K*K weights once per wave.  LDS operations of one wave execute in order, so
+// the tile needs no barrier; two tiles alternate so that a pass never overwrites what the previous one may still be reading.
+template <int K, int PRO, int W>
+__global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p, int bchunk) {
+    constexpr int PADK = (K - 1) / 2;
+    constexpr int LPP = W * W / 4;                 // lanes per plane: 64 (16 x 16) or 16 (8 x 8)
+    constexpr int PW = 64 / LPP;                   // planes per wave pass
+    constexpr int XGW = W / 4;
+    constexpr int TH = W + K - 1, TW = W + 8;      // tile rows; columns: image column x sits at 4 + x
+    constexpr int TILE = TH * TW;
+    constexpr int HW = W * W;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= p.C) return;                          // (no workgroup barrier anywhere in this kernel)
+    const int b_lo = blockIdx.y * bchunk, b_hi = min(p.B, b_lo + bchunk);
+    float sc = 1.0f, sh = 0.0f;
+    if (PRO != S2K_PRO_NONE) {
+        if (p.fold.stats) bn_fold_wave(p.fold, p.C, c, blockIdx.y == 0, sc, sh);
+        else { sc = p.bnv[c]; sh = p.bnv[p.C + c]; }
+    }
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = p.w[c * (K * K) + i];
+    float* tiles = smem + wave * (2 * PW * TILE);
+    for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
+    const int sub = lane / LPP, li = lane % LPP;
+    const int r = li / XGW, xg = li % XGW;
+    const float* src = p.x + (int64_t)c * HW + 4 * li;
+    float* dst = p.out + (int64_t)c * HW + 4 * li;
+    const int64_t bstride = (int64_t)p.C * HW;
+    f32x4 cur = {0.f, 0.f, 0.f, 0.f};
+    if (b_lo + sub < b_hi) cur = *reinterpret_cast<const f32x4*>(src + (b_lo + sub) * bstride);
+    float s = 0.0f, q = 0.0f;
+    int buf = 0;
+    for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
+        const int bb = b0 + sub;
+        const bool ok = bb < b_hi;
+        f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
+        if (bb + PW < b_hi) nxt = *reinterpret_cast<const f32x4*>(src + (bb + PW) * bstride);     // in flight during this pass
+        float* t = tiles + (buf * PW + sub) * TILE;
+        f32x4 v = cur;
+        if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+        }
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = v;
+        __builtin_amdgcn_wave_barrier();
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* t0 = t + r * TW + 4 * xg;           // rows r .. r + K - 1, tile columns 4 xg .. 4 xg + 11 = image columns 4 xg - 4 ..
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            float win[12];
+            read_window<3>(t0 + ky * TW, win);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], win[4 - PADK + j + kx], o[j]);
+        }
+        if (ok) {
+            *reinterpret_cast<f32x4*>(dst + bb * bstride) = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
+        }
+        cur = nxt;
+    }
+    if (p.stats) {
+        const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
+        if (lane == 0) {
+            double* st = p.stats + (int64_t)((blockIdx.x + blockIdx.y) % p.nrep) * 2 * p.C;
+            atomic_add_d(st + c, sd);
+            atomic_add_d(st + p.C + c, qd);
+        }
+    }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------
 template <int K, int S, int PL, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
@@ -577,6 +664,84 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
     }
 }
 
+// ---- data gradient on small square planes (8 x 8, 16 x 16; stride 1): the wave-per-channel scheme of dwconv_fwd_plane_kernel ------------
+// dY goes through the wave-private tile unchanged (the correlation with the flipped kernel), the producer's raw output XRAW of the
+// same 4 pixels - for act' and the BatchNorm-backward sums - is prefetched beside it.
+template <int K, int PRO, int W>
+__global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP p, int bchunk) {
+    constexpr int PADK = (K - 1) / 2;
+    constexpr int LPP = W * W / 4, PW = 64 / LPP, XGW = W / 4;
+    constexpr int TH = W + K - 1, TW = W + 8, TILE = TH * TW, HW = W * W;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= p.C) return;
+    const int b_lo = blockIdx.y * bchunk, b_hi = min(p.B, b_lo + bchunk);
+    float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
+    if (PRO != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = p.w[c * (K * K) + (K * K - 1 - i)];        // flipped
+    float* tiles = smem + wave * (2 * PW * TILE);
+    for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
+    const int sub = lane / LPP, li = lane % LPP;
+    const int r = li / XGW, xg = li % XGW;
+    const int64_t coff = (int64_t)c * HW + 4 * li, bstride = (int64_t)p.C * HW;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cur = zero, xcur = zero;
+    if (b_lo + sub < b_hi) {
+        cur = *reinterpret_cast<const f32x4*>(p.dy + coff + (b_lo + sub) * bstride);
+        if (PRO != S2K_PRO_NONE) xcur = *reinterpret_cast<const f32x4*>(p.x + coff + (b_lo + sub) * bstride);
+    }
+    float s1 = 0.0f, s2 = 0.0f;
+    int buf = 0;
+    for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
+        const int bb = b0 + sub;
+        const bool ok = bb < b_hi;
+        f32x4 nxt = zero, xnxt = zero, ob = zero;
+        if (bb + PW < b_hi) {
+            nxt = *reinterpret_cast<const f32x4*>(p.dy + coff + (bb + PW) * bstride);
+            if (PRO != S2K_PRO_NONE) xnxt = *reinterpret_cast<const f32x4*>(p.x + coff + (bb + PW) * bstride);
+        }
+        if (p.beta && ok) ob = *reinterpret_cast<const f32x4*>(p.out + coff + bb * bstride);
+        float* t = tiles + (buf * PW + sub) * TILE;
+        *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = ok ? cur : zero;
+        __builtin_amdgcn_wave_barrier();
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* t0 = t + r * TW + 4 * xg;
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            float win[12];
+            read_window<3>(t0 + a * TW, win);
+#pragma unroll
+            for (int b = 0; b < K; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], win[4 - PADK + j + b], o[j]);
+        }
+        if (ok) {
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] *= act_grad(fmaf(xcur[j], scale, shift), PRO);
+                    s1 += o[j];
+                    s2 = fmaf(o[j], (xcur[j] - mean) * invstd, s2);
+                }
+            }
+            *reinterpret_cast<f32x4*>(p.out + coff + bb * bstride) = f32x4{o[0] + ob[0], o[1] + ob[1], o[2] + ob[2], o[3] + ob[3]};
+        }
+        cur = nxt;
+        xcur = xnxt;
+    }
+    if (p.stats) {
+        const double sd = wave_sum_d((double)s1), qd = wave_sum_d((double)s2);
+        if (lane == 0) {
+            double* st = p.stats + (int64_t)((blockIdx.x + blockIdx.y) % p.nrep) * 2 * p.C;
+            atomic_add_d(st + c, sd);
+            atomic_add_d(st + p.C + c, qd);
+        }
+    }
+}
+
 // ---- data gradient, stride 2 (4 layers of a b5) ------------------------------------------------------
 // A lane computes a 2x2 block of input pixels.  Input pixel (iy, ix) only meets the taps with (iy + PT - ky) and
 // (ix + PL - kx) even, i.e. each of the K*K taps feeds exactly ONE of the block's four pixels, and which one depends only on
@@ -756,11 +921,31 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (int e = fill_bn_fold(p.fold, c, &op.t[S2K_DWCONV_FWD_T_FSTATS], op.n[S2K_DWCONV_FWD_N_FCOUNT], op.d[S2K_DWCONV_FWD_D_FNREP],
                              op.f[S2K_DWCONV_FWD_F_FEPS], op.f[S2K_DWCONV_FWD_F_FMOM], const_cast<float*>(p.bnv), "dwconv_fwd")) return e;
     if (p.fold.stats && p.pro == S2K_PRO_NONE) { set_error("dwconv_fwd: FSTATS without a prologue"); return S2K_EINVAL; }
+    const bool silu = p.pro == S2K_PRO_SILU;
+    static const int plane_on = tune_int("S2K_DW_PLANE", 1);
+    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16) && p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) &&
+        p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 && (p.pro == S2K_PRO_NONE || silu)) {
+        // small square planes: one wave per channel walks the batch (dwconv_fwd_plane_kernel)
+        const int pw = p.W == 16 ? 1 : 4;
+        int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(6144, p.C)));      // ~24 waves per CU, at least two passes per wave
+        const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
+        bsplit = cdiv(p.B, bchunk);
+        const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
+        const dim3 grid(cdiv(p.C, 4), bsplit);
+#define DW_PLANE(KK, WW) do { \
+            if (silu) hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+            else hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+        if (p.K == 3 && p.W == 8) DW_PLANE(3, 8);
+        else if (p.K == 3) DW_PLANE(3, 16);
+        else if (p.W == 8) DW_PLANE(5, 8);
+        else DW_PLANE(5, 16);
+#undef DW_PLANE
+        return S2K_OK;
+    }
     // tile columns: source column cc - 4; the widest window ends at 4 - PL + (4*XG - 1)*S + K - 1
     const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
     if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
     const size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, true, true) + (p.fold.stats ? 2 * (size_t)p.PPB * sizeof(float) : 0);
-    const bool silu = p.pro == S2K_PRO_SILU;
 #define DW_FWD(KK, SS, PP) (silu ? launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_SILU>, p, lds, c.stream) \
                                  : launch_dw(dwconv_fwd_kernel<KK, SS, PP, S2K_PRO_NONE>, p, lds, c.stream))
 #define DW_FWD_PL(KK, SS) (p.PL == 0 ? DW_FWD(KK, SS, 0) : p.PL == 1 ? DW_FWD(KK, SS, 1) : DW_FWD(KK, SS, 2))
@@ -841,6 +1026,27 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
         if (p.HO != p.H || p.WO != p.W) { set_error("dwconv_dgrad: stride-1 geometry mismatch"); return S2K_EINVAL; }
         const int pr = p.K - 1 - p.PL;       // right padding of the forward = left reach of the correlation
         if (pr < 0 || pr > 2) { set_error("dwconv_dgrad: padding %d is not on this path", p.PL); return S2K_EINVAL; }
+        static const int plane_on = tune_int("S2K_DW_PLANE", 1);
+        if (plane_on && p.H == p.W && (p.W == 8 || p.W == 16) && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 &&
+            (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
+            // small square planes: one wave per channel walks the batch (dwconv_dgrad_plane_kernel)
+            const int pw = p.W == 16 ? 1 : 4;
+            int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(6144, p.C)));
+            const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
+            bsplit = cdiv(p.B, bchunk);
+            const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
+            const dim3 grid(cdiv(p.C, 4), bsplit);
+            const bool sl = p.pro == S2K_PRO_SILU;
+#define DW_DGP(KK, WW) do { \
+                if (sl) hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+                else hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+            if (p.K == 3 && p.W == 8) DW_DGP(3, 8);
+            else if (p.K == 3) DW_DGP(3, 16);
+            else if (p.W == 8) DW_DGP(5, 8);
+            else DW_DGP(5, 16);
+#undef DW_DGP
+            return S2K_OK;
+        }
         const int lw = 4 - pr + cdiv(p.W, 4) * 4 + p.K - 1;
         const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad1, lw, true, true);
         const bool silu = p.pro == S2K_PRO_SILU;

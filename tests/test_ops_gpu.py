@@ -498,7 +498,9 @@ def test_wgrad_finalize():
 # depthwise
 # ---------------------------------------------------------------------------------------------------
 DW_GEOS = [(2, 24, 16, 16, 3, 1), (2, 40, 16, 16, 5, 2), (3, 16, 7, 7, 5, 1), (2, 8, 40, 40, 3, 2), (1, 6, 15, 13, 5, 2),
-           (1, 4, 64, 64, 5, 1), (2, 100, 8, 8, 3, 1), (1, 3, 130, 70, 3, 1)]
+           (1, 4, 64, 64, 5, 1), (2, 100, 8, 8, 3, 1), (1, 3, 130, 70, 3, 1),
+           # small square planes at stride 1: one wave per channel walks a chunk of the batch (ragged chunks, 4 planes per pass at 8 x 8)
+           (33, 12, 16, 16, 5, 1), (37, 10, 8, 8, 5, 1), (9, 6, 8, 8, 3, 1), (5, 70, 16, 16, 3, 1)]
 
 
 def _dw_geo(B, C, H, W, K, S):
@@ -910,7 +912,8 @@ def _fold_fields(c: "Case", C: int, n: int, nrep: int):
     return f, c.t("bnv", (4, C), "nan")
 
 
-@pytest.mark.parametrize("geo", [(2, 48, 32, 32, 3, 1), (2, 20, 17, 17, 5, 2), (3, 600, 8, 8, 5, 1), (1, 70, 64, 64, 3, 2), (4, 7, 4, 4, 3, 1)])
+@pytest.mark.parametrize("geo", [(2, 48, 32, 32, 3, 1), (2, 20, 17, 17, 5, 2), (3, 600, 8, 8, 5, 1), (1, 70, 64, 64, 3, 2), (4, 7, 4, 4, 3, 1),
+                                 (19, 9, 16, 16, 5, 1), (21, 5, 8, 8, 3, 1)])
 def test_dwconv_fwd_with_folded_bn_finalize(geo):
     B, C, H, W, K, S = geo
     g, Ho, Wo = _dw_geo(*geo)
