@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
     }
 }
 
-// ---- forward on small square planes (8 x 8 and 16 x 16, stride 1: the deep MBConv blocks) --------------------------------------------
+// ---- forward on small square planes (8 x 8, 16 x 16, 32 x 32; stride 1: the deep MBConv blocks) --------------------------------------------
 // The band kernel above stages a group of planes, synchronises the workgroup, computes, stores - one pass per workgroup, so its HBM
 // round trip, the SiLU prologue, the K*K multiply-adds and the stores follow one another and only other workgroups on the CU overlap
 // them (16 x 16, k = 5: 42 us for 69 MB = 1.65 TB/s; the bare structure without prologue and statistics: 26 us; a copy: 11 us).
@@ -339,7 +339,9 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
 template <int K, int PRO, int W>
 __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p, int bchunk) {
     constexpr int PADK = (K - 1) / 2;
-    constexpr int LPP = W * W / 4;                 // lanes per plane: 64 (16 x 16) or 16 (8 x 8)
+    constexpr int GPP = W * W / 4;                 // 4-pixel groups per plane
+    constexpr int NG = GPP > 64 ? GPP / 64 : 1;    // groups per lane (32 x 32: 4)
+    constexpr int LPP = GPP > 64 ? 64 : GPP;       // lanes per plane: 64 (16 x 16, 32 x 32) or 16 (8 x 8)
     constexpr int PW = 64 / LPP;                   // planes per wave pass
     constexpr int XGW = W / 4;
     constexpr int TH = W + K - 1, TW = W + 8;      // tile rows; columns: image column x sits at 4 + x
@@ -361,45 +363,56 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
     float* tiles = smem + wave * (2 * PW * TILE);
     for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
     const int sub = lane / LPP, li = lane % LPP;
-    const int r = li / XGW, xg = li % XGW;
     const float* src = p.x + (int64_t)c * HW + 4 * li;
     float* dst = p.out + (int64_t)c * HW + 4 * li;
     const int64_t bstride = (int64_t)p.C * HW;
-    f32x4 cur = {0.f, 0.f, 0.f, 0.f};
-    if (b_lo + sub < b_hi) cur = *reinterpret_cast<const f32x4*>(src + (b_lo + sub) * bstride);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cur[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cur[g] = (b_lo + sub < b_hi) ? *reinterpret_cast<const f32x4*>(src + (b_lo + sub) * bstride + 256 * g) : zero;
     float s = 0.0f, q = 0.0f;
     int buf = 0;
     for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
         const int bb = b0 + sub;
         const bool ok = bb < b_hi;
-        f32x4 nxt = {0.f, 0.f, 0.f, 0.f};
-        if (bb + PW < b_hi) nxt = *reinterpret_cast<const f32x4*>(src + (bb + PW) * bstride);     // in flight during this pass
+        f32x4 nxt[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) nxt[g] = (bb + PW < b_hi) ? *reinterpret_cast<const f32x4*>(src + (bb + PW) * bstride + 256 * g) : zero;   // in flight during this pass
         float* t = tiles + (buf * PW + sub) * TILE;
-        f32x4 v = cur;
-        if (PRO != S2K_PRO_NONE) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            f32x4 v = cur[g];
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+            }
+            if (!ok) v = zero;
+            *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = v;
         }
-        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = v;
         __builtin_amdgcn_wave_barrier();
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* t0 = t + r * TW + 4 * xg;           // rows r .. r + K - 1, tile columns 4 xg .. 4 xg + 11 = image columns 4 xg - 4 ..
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            float win[12];
-            read_window<3>(t0 + ky * TW, win);
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* t0 = t + r * TW + 4 * xg;       // rows r .. r + K - 1, tile columns 4 xg .. 4 xg + 11 = image columns 4 xg - 4 ..
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx)
+            for (int ky = 0; ky < K; ++ky) {
+                float win[12];
+                read_window<3>(t0 + ky * TW, win);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], win[4 - PADK + j + kx], o[j]);
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], win[4 - PADK + j + kx], o[j]);
+            }
+            if (ok) {
+                *reinterpret_cast<f32x4*>(dst + bb * bstride + 256 * g) = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
+            }
         }
-        if (ok) {
-            *reinterpret_cast<f32x4*>(dst + bb * bstride) = f32x4{o[0], o[1], o[2], o[3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
-        }
-        cur = nxt;
+        for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
     }
     if (p.stats) {
         const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
@@ -664,13 +677,13 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
     }
 }
 
-// ---- data gradient on small square planes (8 x 8, 16 x 16; stride 1): the wave-per-channel scheme of dwconv_fwd_plane_kernel ------------
+// ---- data gradient on small square planes (8 x 8, 16 x 16, 32 x 32; stride 1): the wave-per-channel scheme of dwconv_fwd_plane_kernel ------------
 // dY goes through the wave-private tile unchanged (the correlation with the flipped kernel), the producer's raw output XRAW of the
 // same 4 pixels - for act' and the BatchNorm-backward sums - is prefetched beside it.
 template <int K, int PRO, int W>
 __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP p, int bchunk) {
     constexpr int PADK = (K - 1) / 2;
-    constexpr int LPP = W * W / 4, PW = 64 / LPP, XGW = W / 4;
+    constexpr int GPP = W * W / 4, NG = GPP > 64 ? GPP / 64 : 1, LPP = GPP > 64 ? 64 : GPP, PW = 64 / LPP, XGW = W / 4;
     constexpr int TH = W + K - 1, TW = W + 8, TILE = TH * TW, HW = W * W;
     extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -685,52 +698,62 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP 
     float* tiles = smem + wave * (2 * PW * TILE);
     for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
     const int sub = lane / LPP, li = lane % LPP;
-    const int r = li / XGW, xg = li % XGW;
     const int64_t coff = (int64_t)c * HW + 4 * li, bstride = (int64_t)p.C * HW;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cur = zero, xcur = zero;
-    if (b_lo + sub < b_hi) {
-        cur = *reinterpret_cast<const f32x4*>(p.dy + coff + (b_lo + sub) * bstride);
-        if (PRO != S2K_PRO_NONE) xcur = *reinterpret_cast<const f32x4*>(p.x + coff + (b_lo + sub) * bstride);
+    f32x4 cur[NG], xcur[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const bool ok0 = b_lo + sub < b_hi;
+        cur[g] = ok0 ? *reinterpret_cast<const f32x4*>(p.dy + coff + (b_lo + sub) * bstride + 256 * g) : zero;
+        xcur[g] = (ok0 && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + coff + (b_lo + sub) * bstride + 256 * g) : zero;
     }
     float s1 = 0.0f, s2 = 0.0f;
     int buf = 0;
     for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
         const int bb = b0 + sub;
-        const bool ok = bb < b_hi;
-        f32x4 nxt = zero, xnxt = zero, ob = zero;
-        if (bb + PW < b_hi) {
-            nxt = *reinterpret_cast<const f32x4*>(p.dy + coff + (bb + PW) * bstride);
-            if (PRO != S2K_PRO_NONE) xnxt = *reinterpret_cast<const f32x4*>(p.x + coff + (bb + PW) * bstride);
+        const bool ok = bb < b_hi, more = bb + PW < b_hi;
+        f32x4 nxt[NG], xnxt[NG], ob[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            nxt[g] = more ? *reinterpret_cast<const f32x4*>(p.dy + coff + (bb + PW) * bstride + 256 * g) : zero;
+            xnxt[g] = (more && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + coff + (bb + PW) * bstride + 256 * g) : zero;
+            ob[g] = (p.beta && ok) ? *reinterpret_cast<const f32x4*>(p.out + coff + bb * bstride + 256 * g) : zero;
         }
-        if (p.beta && ok) ob = *reinterpret_cast<const f32x4*>(p.out + coff + bb * bstride);
         float* t = tiles + (buf * PW + sub) * TILE;
-        *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = ok ? cur : zero;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = ok ? cur[g] : zero;
+        }
         __builtin_amdgcn_wave_barrier();
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* t0 = t + r * TW + 4 * xg;
 #pragma unroll
-        for (int a = 0; a < K; ++a) {
-            float win[12];
-            read_window<3>(t0 + a * TW, win);
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* t0 = t + r * TW + 4 * xg;
 #pragma unroll
-            for (int b = 0; b < K; ++b)
+            for (int a = 0; a < K; ++a) {
+                float win[12];
+                read_window<3>(t0 + a * TW, win);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], win[4 - PADK + j + b], o[j]);
-        }
-        if (ok) {
-            if (PRO != S2K_PRO_NONE) {
+                for (int b = 0; b < K; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] *= act_grad(fmaf(xcur[j], scale, shift), PRO);
-                    s1 += o[j];
-                    s2 = fmaf(o[j], (xcur[j] - mean) * invstd, s2);
-                }
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[a * K + b], win[4 - PADK + j + b], o[j]);
             }
-            *reinterpret_cast<f32x4*>(p.out + coff + bb * bstride) = f32x4{o[0] + ob[0], o[1] + ob[1], o[2] + ob[2], o[3] + ob[3]};
+            if (ok) {
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] *= act_grad(fmaf(xcur[g][j], scale, shift), PRO);
+                        s1 += o[j];
+                        s2 = fmaf(o[j], (xcur[g][j] - mean) * invstd, s2);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(p.out + coff + bb * bstride + 256 * g) = f32x4{o[0] + ob[g][0], o[1] + ob[g][1], o[2] + ob[g][2], o[3] + ob[g][3]};
+            }
         }
-        cur = nxt;
-        xcur = xnxt;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { cur[g] = nxt[g]; xcur[g] = xnxt[g]; }
     }
     if (p.stats) {
         const double sd = wave_sum_d((double)s1), qd = wave_sum_d((double)s2);
@@ -923,11 +946,12 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (p.fold.stats && p.pro == S2K_PRO_NONE) { set_error("dwconv_fwd: FSTATS without a prologue"); return S2K_EINVAL; }
     const bool silu = p.pro == S2K_PRO_SILU;
     static const int plane_on = tune_int("S2K_DW_PLANE", 1);
-    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16) && p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) &&
+    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32) && p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) &&
         p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 && (p.pro == S2K_PRO_NONE || silu)) {
         // small square planes: one wave per channel walks the batch (dwconv_fwd_plane_kernel)
-        const int pw = p.W == 16 ? 1 : 4;
-        int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(6144, p.C)));      // ~24 waves per CU, at least two passes per wave
+        const int pw = p.W == 8 ? 4 : 1;
+        static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
+        int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(plane_waves, p.C)));      // ~24 waves per CU, at least two passes per wave
         const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
         bsplit = cdiv(p.B, bchunk);
         const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
@@ -936,9 +960,11 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
             if (silu) hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
             else hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
         if (p.K == 3 && p.W == 8) DW_PLANE(3, 8);
-        else if (p.K == 3) DW_PLANE(3, 16);
+        else if (p.K == 3 && p.W == 16) DW_PLANE(3, 16);
+        else if (p.K == 3) DW_PLANE(3, 32);
         else if (p.W == 8) DW_PLANE(5, 8);
-        else DW_PLANE(5, 16);
+        else if (p.W == 16) DW_PLANE(5, 16);
+        else DW_PLANE(5, 32);
 #undef DW_PLANE
         return S2K_OK;
     }
@@ -1027,11 +1053,12 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
         const int pr = p.K - 1 - p.PL;       // right padding of the forward = left reach of the correlation
         if (pr < 0 || pr > 2) { set_error("dwconv_dgrad: padding %d is not on this path", p.PL); return S2K_EINVAL; }
         static const int plane_on = tune_int("S2K_DW_PLANE", 1);
-        if (plane_on && p.H == p.W && (p.W == 8 || p.W == 16) && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 &&
+        if (plane_on && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32) && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 &&
             (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
             // small square planes: one wave per channel walks the batch (dwconv_dgrad_plane_kernel)
-            const int pw = p.W == 16 ? 1 : 4;
-            int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(6144, p.C)));
+            const int pw = p.W == 8 ? 4 : 1;
+            static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
+            int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(plane_waves, p.C)));
             const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
             bsplit = cdiv(p.B, bchunk);
             const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
@@ -1041,9 +1068,11 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
                 if (sl) hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
                 else hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
             if (p.K == 3 && p.W == 8) DW_DGP(3, 8);
-            else if (p.K == 3) DW_DGP(3, 16);
+            else if (p.K == 3 && p.W == 16) DW_DGP(3, 16);
+            else if (p.K == 3) DW_DGP(3, 32);
             else if (p.W == 8) DW_DGP(5, 8);
-            else DW_DGP(5, 16);
+            else if (p.W == 16) DW_DGP(5, 16);
+            else DW_DGP(5, 32);
 #undef DW_DGP
             return S2K_OK;
         }
