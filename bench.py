@@ -84,8 +84,9 @@ def csrc_fingerprint() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted((ROOT / "sentinel2-landcover-classification_amd" / "csrc").glob("*.h*")):
-        h.update(f.name.encode()); h.update(f.read_bytes())
+    for f in sorted((ROOT / "sentinel2-landcover-classification_amd" / "csrc").iterdir()):
+        if f.suffix in (".hip", ".h"):                 # sources only (the objects built beside them - *.hip.o - differ from box to box)
+            h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
 
