@@ -336,22 +336,30 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_kernel(const DwP p) {
 // three aligned 16-byte LDS reads, stores them and keeps the channel's BatchNorm sums in registers: one f64 atomic pair per wave,
 // the input BatchNorm's fold (opdefs.FOLD_*) and the K*K weights once per wave.  LDS operations of one wave execute in order, so
 // the tile needs no barrier; two tiles alternate so that a pass never overwrites what the previous one may still be reading.
-template <int K, int PRO, int W>
+// R < W (64 x 64 and 128 x 128 planes): the wave's unit of work is a band of R rows of one plane instead of a whole plane; the K - 1
+// halo rows above / below the band come with one extra (bounds-checked) 16-byte load per lane and are rewritten for every band.
+template <int K, int PRO, int W, int R = W>
 __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p, int bchunk) {
     constexpr int PADK = (K - 1) / 2;
-    constexpr int GPP = W * W / 4;                 // 4-pixel groups per plane
-    constexpr int NG = GPP > 64 ? GPP / 64 : 1;    // groups per lane (32 x 32: 4)
-    constexpr int LPP = GPP > 64 ? 64 : GPP;       // lanes per plane: 64 (16 x 16, 32 x 32) or 16 (8 x 8)
-    constexpr int PW = 64 / LPP;                   // planes per wave pass
+    constexpr bool BAND = R != W;
+    constexpr int NB = W / R;                      // bands per plane
+    constexpr int GPP = R * W / 4;                 // 4-pixel groups per work item
+    constexpr int NG = GPP > 64 ? GPP / 64 : 1;    // groups per lane
+    constexpr int LPP = GPP > 64 ? 64 : GPP;       // lanes per item: 64, or 16 (8 x 8 planes)
+    constexpr int PW = 64 / LPP;                   // items per wave pass
     constexpr int XGW = W / 4;
-    constexpr int TH = W + K - 1, TW = W + 8;      // tile rows; columns: image column x sits at 4 + x
+    constexpr int HG = BAND ? (K - 1) * XGW : 0;   // halo groups of a band (<= 64: one per lane)
+    constexpr int TH = R + K - 1, TW = W + 8;      // tile rows; columns: image column x sits at 4 + x
     constexpr int TILE = TH * TW;
     constexpr int HW = W * W;
+    static_assert(HG <= 64 && (!BAND || PW == 1) && W % R == 0, "band geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
     if (c >= p.C) return;                          // (no workgroup barrier anywhere in this kernel)
-    const int b_lo = blockIdx.y * bchunk, b_hi = min(p.B, b_lo + bchunk);
+    // work items of this channel: (image, band) pairs; this wave takes items [i_lo, i_hi)
+    const int n_items = p.B * NB;
+    const int i_lo = blockIdx.y * bchunk, i_hi = min(n_items, i_lo + bchunk);
     float sc = 1.0f, sh = 0.0f;
     if (PRO != S2K_PRO_NONE) {
         if (p.fold.stats) bn_fold_wave(p.fold, p.C, c, blockIdx.y == 0, sc, sh);
@@ -363,21 +371,42 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
     float* tiles = smem + wave * (2 * PW * TILE);
     for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
     const int sub = lane / LPP, li = lane % LPP;
-    const float* src = p.x + (int64_t)c * HW + 4 * li;
-    float* dst = p.out + (int64_t)c * HW + 4 * li;
-    const int64_t bstride = (int64_t)p.C * HW;
+    const int64_t bstride = (int64_t)p.C * HW, coff = (int64_t)c * HW;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cur[NG];
+    // halo group of this lane: tile row / image row offset relative to the band's first row
+    const int hrow = lane / XGW, hxg = lane % XGW;                            // (used when lane < HG)
+    const int h_trow = hrow < PADK ? hrow : R + hrow;                         // tile row
+    const int h_dy = hrow < PADK ? hrow - PADK : R + hrow - PADK;             // image row - y0
+    auto item_off = [&](int it, int& y0) -> int64_t {                         // element offset of an item's first row
+        const int b = BAND ? it / NB : it;
+        y0 = BAND ? (it - b * NB) * R : 0;
+        return (int64_t)b * bstride + coff + (int64_t)y0 * W;
+    };
+    f32x4 cur[NG], hcur = zero;
+    {
+        int y0;
+        const int it = i_lo + sub;
+        const int64_t off = item_off(it < i_hi ? it : i_lo, y0);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) cur[g] = (b_lo + sub < b_hi) ? *reinterpret_cast<const f32x4*>(src + (b_lo + sub) * bstride + 256 * g) : zero;
+        for (int g = 0; g < NG; ++g) cur[g] = (it < i_hi) ? *reinterpret_cast<const f32x4*>(p.x + off + 4 * li + 256 * g) : zero;
+        if (BAND && lane < HG && it < i_hi && y0 + h_dy >= 0 && y0 + h_dy < W) hcur = *reinterpret_cast<const f32x4*>(p.x + off + (int64_t)h_dy * W + 4 * hxg);
+    }
     float s = 0.0f, q = 0.0f;
     int buf = 0;
-    for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
-        const int bb = b0 + sub;
-        const bool ok = bb < b_hi;
-        f32x4 nxt[NG];
+    for (int i0 = i_lo; i0 < i_hi; i0 += PW, buf ^= 1) {
+        const int it = i0 + sub;
+        const bool ok = it < i_hi;
+        int y0;
+        const int64_t off = item_off(ok ? it : i_lo, y0);
+        f32x4 nxt[NG], hnxt = zero;
+        {
+            int y1;
+            const bool more = it + PW < i_hi;
+            const int64_t offn = item_off(more ? it + PW : i_lo, y1);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) nxt[g] = (bb + PW < b_hi) ? *reinterpret_cast<const f32x4*>(src + (bb + PW) * bstride + 256 * g) : zero;   // in flight during this pass
+            for (int g = 0; g < NG; ++g) nxt[g] = more ? *reinterpret_cast<const f32x4*>(p.x + offn + 4 * li + 256 * g) : zero;   // in flight during this pass
+            if (BAND && lane < HG && more && y1 + h_dy >= 0 && y1 + h_dy < W) hnxt = *reinterpret_cast<const f32x4*>(p.x + offn + (int64_t)h_dy * W + 4 * hxg);
+        }
         float* t = tiles + (buf * PW + sub) * TILE;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -389,6 +418,16 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
             }
             if (!ok) v = zero;
             *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = v;
+        }
+        if (BAND && lane < HG) {
+            f32x4 v = hcur;
+            const bool inside = ok && y0 + h_dy >= 0 && y0 + h_dy < W;        // the reference pads ACTIVATED maps with zeros
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+            }
+            if (!inside) v = zero;
+            *reinterpret_cast<f32x4*>(t + h_trow * TW + 4 + 4 * hxg) = v;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -406,13 +445,14 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
                     for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], win[4 - PADK + j + kx], o[j]);
             }
             if (ok) {
-                *reinterpret_cast<f32x4*>(dst + bb * bstride + 256 * g) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(p.out + off + 4 * li + 256 * g) = f32x4{o[0], o[1], o[2], o[3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) cur[g] = nxt[g];
+        hcur = hnxt;
     }
     if (p.stats) {
         const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
@@ -680,16 +720,20 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_s1_kernel(const DwP p) 
 // ---- data gradient on small square planes (8 x 8, 16 x 16, 32 x 32; stride 1): the wave-per-channel scheme of dwconv_fwd_plane_kernel ------------
 // dY goes through the wave-private tile unchanged (the correlation with the flipped kernel), the producer's raw output XRAW of the
 // same 4 pixels - for act' and the BatchNorm-backward sums - is prefetched beside it.
-template <int K, int PRO, int W>
+template <int K, int PRO, int W, int R = W>
 __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP p, int bchunk) {
     constexpr int PADK = (K - 1) / 2;
-    constexpr int GPP = W * W / 4, NG = GPP > 64 ? GPP / 64 : 1, LPP = GPP > 64 ? 64 : GPP, PW = 64 / LPP, XGW = W / 4;
-    constexpr int TH = W + K - 1, TW = W + 8, TILE = TH * TW, HW = W * W;
+    constexpr bool BAND = R != W;
+    constexpr int NB = W / R, GPP = R * W / 4, NG = GPP > 64 ? GPP / 64 : 1, LPP = GPP > 64 ? 64 : GPP, PW = 64 / LPP, XGW = W / 4;
+    constexpr int HG = BAND ? (K - 1) * XGW : 0;
+    constexpr int TH = R + K - 1, TW = W + 8, TILE = TH * TW, HW = W * W;
+    static_assert(HG <= 64 && (!BAND || PW == 1) && W % R == 0, "band geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
     if (c >= p.C) return;
-    const int b_lo = blockIdx.y * bchunk, b_hi = min(p.B, b_lo + bchunk);
+    const int n_items = p.B * NB;
+    const int i_lo = blockIdx.y * bchunk, i_hi = min(n_items, i_lo + bchunk);
     float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
     if (PRO != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
     float wk[K * K];
@@ -698,33 +742,52 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP 
     float* tiles = smem + wave * (2 * PW * TILE);
     for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
     const int sub = lane / LPP, li = lane % LPP;
-    const int64_t coff = (int64_t)c * HW + 4 * li, bstride = (int64_t)p.C * HW;
+    const int64_t bstride = (int64_t)p.C * HW, coff = (int64_t)c * HW;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cur[NG], xcur[NG];
+    const int hrow = lane / XGW, hxg = lane % XGW;
+    const int h_trow = hrow < PADK ? hrow : R + hrow;
+    const int h_dy = hrow < PADK ? hrow - PADK : R + hrow - PADK;
+    auto item_off = [&](int it, int& y0) -> int64_t {
+        const int b = BAND ? it / NB : it;
+        y0 = BAND ? (it - b * NB) * R : 0;
+        return (int64_t)b * bstride + coff + (int64_t)y0 * W;
+    };
+    f32x4 cur[NG], xcur[NG], hcur = zero;
+    {
+        int y0;
+        const int it = i_lo + sub;
+        const bool ok0 = it < i_hi;
+        const int64_t off = item_off(ok0 ? it : i_lo, y0);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const bool ok0 = b_lo + sub < b_hi;
-        cur[g] = ok0 ? *reinterpret_cast<const f32x4*>(p.dy + coff + (b_lo + sub) * bstride + 256 * g) : zero;
-        xcur[g] = (ok0 && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + coff + (b_lo + sub) * bstride + 256 * g) : zero;
+        for (int g = 0; g < NG; ++g) {
+            cur[g] = ok0 ? *reinterpret_cast<const f32x4*>(p.dy + off + 4 * li + 256 * g) : zero;
+            xcur[g] = (ok0 && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + off + 4 * li + 256 * g) : zero;
+        }
+        if (BAND && lane < HG && ok0 && y0 + h_dy >= 0 && y0 + h_dy < W) hcur = *reinterpret_cast<const f32x4*>(p.dy + off + (int64_t)h_dy * W + 4 * hxg);
     }
     float s1 = 0.0f, s2 = 0.0f;
     int buf = 0;
-    for (int b0 = b_lo; b0 < b_hi; b0 += PW, buf ^= 1) {
-        const int bb = b0 + sub;
-        const bool ok = bb < b_hi, more = bb + PW < b_hi;
-        f32x4 nxt[NG], xnxt[NG], ob[NG];
+    for (int i0 = i_lo; i0 < i_hi; i0 += PW, buf ^= 1) {
+        const int it = i0 + sub;
+        const bool ok = it < i_hi, more = it + PW < i_hi;
+        int y0, y1;
+        const int64_t off = item_off(ok ? it : i_lo, y0);
+        const int64_t offn = item_off(more ? it + PW : i_lo, y1);
+        f32x4 nxt[NG], xnxt[NG], ob[NG], hnxt = zero;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            nxt[g] = more ? *reinterpret_cast<const f32x4*>(p.dy + coff + (bb + PW) * bstride + 256 * g) : zero;
-            xnxt[g] = (more && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + coff + (bb + PW) * bstride + 256 * g) : zero;
-            ob[g] = (p.beta && ok) ? *reinterpret_cast<const f32x4*>(p.out + coff + bb * bstride + 256 * g) : zero;
+            nxt[g] = more ? *reinterpret_cast<const f32x4*>(p.dy + offn + 4 * li + 256 * g) : zero;
+            xnxt[g] = (more && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(p.x + offn + 4 * li + 256 * g) : zero;
+            ob[g] = (p.beta && ok) ? *reinterpret_cast<const f32x4*>(p.out + off + 4 * li + 256 * g) : zero;
         }
+        if (BAND && lane < HG && more && y1 + h_dy >= 0 && y1 + h_dy < W) hnxt = *reinterpret_cast<const f32x4*>(p.dy + offn + (int64_t)h_dy * W + 4 * hxg);
         float* t = tiles + (buf * PW + sub) * TILE;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
             *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = ok ? cur[g] : zero;
         }
+        if (BAND && lane < HG) *reinterpret_cast<f32x4*>(t + h_trow * TW + 4 + 4 * hxg) = (ok && y0 + h_dy >= 0 && y0 + h_dy < W) ? hcur : zero;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -749,11 +812,12 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP 
                         s2 = fmaf(o[j], (xcur[g][j] - mean) * invstd, s2);
                     }
                 }
-                *reinterpret_cast<f32x4*>(p.out + coff + bb * bstride + 256 * g) = f32x4{o[0] + ob[g][0], o[1] + ob[g][1], o[2] + ob[g][2], o[3] + ob[g][3]};
+                *reinterpret_cast<f32x4*>(p.out + off + 4 * li + 256 * g) = f32x4{o[0] + ob[g][0], o[1] + ob[g][1], o[2] + ob[g][2], o[3] + ob[g][3]};
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) { cur[g] = nxt[g]; xcur[g] = xnxt[g]; }
+        hcur = hnxt;
     }
     if (p.stats) {
         const double sd = wave_sum_d((double)s1), qd = wave_sum_d((double)s2);
@@ -946,25 +1010,29 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
     if (p.fold.stats && p.pro == S2K_PRO_NONE) { set_error("dwconv_fwd: FSTATS without a prologue"); return S2K_EINVAL; }
     const bool silu = p.pro == S2K_PRO_SILU;
     static const int plane_on = tune_int("S2K_DW_PLANE", 1);
-    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32) && p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) &&
-        p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 && (p.pro == S2K_PRO_NONE || silu)) {
-        // small square planes: one wave per channel walks the batch (dwconv_fwd_plane_kernel)
+    static const int band_on = tune_int("S2K_DW_BAND", 1);
+    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32 || (band_on && (p.W == 64 || (p.W == 128 && p.K == 3)))) &&
+        p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 && (p.pro == S2K_PRO_NONE || silu)) {
+        // square planes at stride 1: one wave per channel walks (image, band) items with no workgroup barrier (dwconv_fwd_plane_kernel)
         const int pw = p.W == 8 ? 4 : 1;
+        const int rows = p.W == 64 ? 16 : p.W == 128 ? 8 : p.W;              // rows per work item
+        const int n_items = p.B * (p.W / rows);
         static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
-        int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(plane_waves, p.C)));      // ~24 waves per CU, at least two passes per wave
-        const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
-        bsplit = cdiv(p.B, bchunk);
-        const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
+        int bsplit = std::max(1, std::min(cdiv(n_items, 2 * pw), cdiv(plane_waves, p.C)));      // ~24 waves per CU, at least two passes per wave
+        const int bchunk = cdiv(cdiv(n_items, bsplit), pw) * pw;
+        bsplit = cdiv(n_items, bchunk);
+        const size_t lds = (size_t)4 * 2 * pw * (rows + p.K - 1) * (p.W + 8) * sizeof(float);
         const dim3 grid(cdiv(p.C, 4), bsplit);
-#define DW_PLANE(KK, WW) do { \
-            if (silu) hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
-            else hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
-        if (p.K == 3 && p.W == 8) DW_PLANE(3, 8);
-        else if (p.K == 3 && p.W == 16) DW_PLANE(3, 16);
-        else if (p.K == 3) DW_PLANE(3, 32);
-        else if (p.W == 8) DW_PLANE(5, 8);
-        else if (p.W == 16) DW_PLANE(5, 16);
-        else DW_PLANE(5, 32);
+#define DW_PLANE(KK, WW, RR) do { \
+            if (silu) hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_SILU, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+            else hipLaunchKernelGGL((dwconv_fwd_plane_kernel<KK, S2K_PRO_NONE, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+        if (p.K == 3) {
+            if (p.W == 8) DW_PLANE(3, 8, 8); else if (p.W == 16) DW_PLANE(3, 16, 16); else if (p.W == 32) DW_PLANE(3, 32, 32);
+            else if (p.W == 64) DW_PLANE(3, 64, 16); else DW_PLANE(3, 128, 8);
+        } else {
+            if (p.W == 8) DW_PLANE(5, 8, 8); else if (p.W == 16) DW_PLANE(5, 16, 16); else if (p.W == 32) DW_PLANE(5, 32, 32);
+            else DW_PLANE(5, 64, 16);
+        }
 #undef DW_PLANE
         return S2K_OK;
     }
@@ -1053,26 +1121,30 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
         const int pr = p.K - 1 - p.PL;       // right padding of the forward = left reach of the correlation
         if (pr < 0 || pr > 2) { set_error("dwconv_dgrad: padding %d is not on this path", p.PL); return S2K_EINVAL; }
         static const int plane_on = tune_int("S2K_DW_PLANE", 1);
-        if (plane_on && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32) && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 &&
-            (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
-            // small square planes: one wave per channel walks the batch (dwconv_dgrad_plane_kernel)
+        static const int band_on = tune_int("S2K_DW_BAND", 1);
+        if (plane_on && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32 || (band_on && (p.W == 64 || (p.W == 128 && p.K == 3)))) &&
+            (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 && (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
+            // square planes at stride 1: one wave per channel walks (image, band) items (dwconv_dgrad_plane_kernel)
             const int pw = p.W == 8 ? 4 : 1;
+            const int rows = p.W == 64 ? 16 : p.W == 128 ? 8 : p.W;
+            const int n_items = p.B * (p.W / rows);
             static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
-            int bsplit = std::max(1, std::min(cdiv(p.B, 2 * pw), cdiv(plane_waves, p.C)));
-            const int bchunk = cdiv(cdiv(p.B, bsplit), pw) * pw;
-            bsplit = cdiv(p.B, bchunk);
-            const size_t lds = (size_t)4 * 2 * pw * (p.W + p.K - 1) * (p.W + 8) * sizeof(float);
+            int bsplit = std::max(1, std::min(cdiv(n_items, 2 * pw), cdiv(plane_waves, p.C)));
+            const int bchunk = cdiv(cdiv(n_items, bsplit), pw) * pw;
+            bsplit = cdiv(n_items, bchunk);
+            const size_t lds = (size_t)4 * 2 * pw * (rows + p.K - 1) * (p.W + 8) * sizeof(float);
             const dim3 grid(cdiv(p.C, 4), bsplit);
             const bool sl = p.pro == S2K_PRO_SILU;
-#define DW_DGP(KK, WW) do { \
-                if (sl) hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_SILU, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
-                else hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_NONE, WW>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
-            if (p.K == 3 && p.W == 8) DW_DGP(3, 8);
-            else if (p.K == 3 && p.W == 16) DW_DGP(3, 16);
-            else if (p.K == 3) DW_DGP(3, 32);
-            else if (p.W == 8) DW_DGP(5, 8);
-            else if (p.W == 16) DW_DGP(5, 16);
-            else DW_DGP(5, 32);
+#define DW_DGP(KK, WW, RR) do { \
+                if (sl) hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_SILU, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+                else hipLaunchKernelGGL((dwconv_dgrad_plane_kernel<KK, S2K_PRO_NONE, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+            if (p.K == 3) {
+                if (p.W == 8) DW_DGP(3, 8, 8); else if (p.W == 16) DW_DGP(3, 16, 16); else if (p.W == 32) DW_DGP(3, 32, 32);
+                else if (p.W == 64) DW_DGP(3, 64, 16); else DW_DGP(3, 128, 8);
+            } else {
+                if (p.W == 8) DW_DGP(5, 8, 8); else if (p.W == 16) DW_DGP(5, 16, 16); else if (p.W == 32) DW_DGP(5, 32, 32);
+                else DW_DGP(5, 64, 16);
+            }
 #undef DW_DGP
             return S2K_OK;
         }
