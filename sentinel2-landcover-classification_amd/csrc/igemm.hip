@@ -726,7 +726,7 @@ static bool spatial_tiling(ConvP& p, int BN, int cap) {
 }
 
 int launch_conv(const S2kOp& op, const Ctx& c) {
-    ConvP p;
+    ConvP p{};
     p.x1 = ref_ptr<const float>(c, op.t[S2K_CONV_T_X1]);
     p.bnv1 = ref_ptr<const float>(c, op.t[S2K_CONV_T_BNV1]);
     p.gate1 = ref_ptr<const float>(c, op.t[S2K_CONV_T_GATE1]);

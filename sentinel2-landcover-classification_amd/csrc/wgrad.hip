@@ -449,7 +449,7 @@ static int launch_wg(WgradP& p, hipStream_t st) {
 }
 
 int launch_wgrad(const S2kOp& op, const Ctx& c) {
-    WgradP p;
+    WgradP p{};
     p.p = ref_ptr<const float>(c, op.t[S2K_WGRAD_T_P]);
     p.bnvp = ref_ptr<const float>(c, op.t[S2K_WGRAD_T_BNVP]);
     p.gatep = ref_ptr<const float>(c, op.t[S2K_WGRAD_T_GATEP]);
