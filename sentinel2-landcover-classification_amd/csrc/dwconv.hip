@@ -464,6 +464,141 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
     }
 }
 
+// ---- forward at stride 2 (even sizes, TF-SAME: K - 2 pad rows / columns, the larger half below / right): the same wave-per-channel
+// scheme; a work item = RO output rows = 2 RO input rows (+ K - 2 halo rows), 4 input groups and 1 output group per lane
+template <int K, int PRO, int WO, int RO>
+__global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_s2_kernel(const DwP p, int bchunk) {
+    constexpr int WI = 2 * WO, PT = (K - 2) / 2, PB = K - 2 - PT;     // pads: top / left PT, bottom / right PB
+    constexpr int NB = WO / RO;                    // bands per plane (RO == WO: whole planes)
+    constexpr bool BAND = NB > 1;
+    constexpr int GO = RO * WO / 4;                // output groups per item: 64, or 16 (8 x 8 outputs)
+    constexpr int LPP = GO, PW = 64 / LPP;
+    constexpr int XGO = WO / 4, XGI = WI / 4;
+    constexpr int NGI = 2 * RO * XGI / LPP;        // input groups per lane (= 4)
+    constexpr int HGT = BAND ? (K - 2) * XGI : 0;  // halo groups of a band
+    constexpr int NH = (HGT + 63) / 64;
+    constexpr int TH = 2 * RO + K - 2, TW = WI + 8, TILE = TH * TW;
+    constexpr int HWI = WI * WI, HWO = WO * WO;
+    static_assert(NGI == 4 && (!BAND || PW == 1), "stride-2 plane geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= p.C) return;
+    const int n_items = p.B * NB;
+    const int i_lo = blockIdx.y * bchunk, i_hi = min(n_items, i_lo + bchunk);
+    float sc = 1.0f, sh = 0.0f;
+    if (PRO != S2K_PRO_NONE) {
+        if (p.fold.stats) bn_fold_wave(p.fold, p.C, c, blockIdx.y == 0, sc, sh);
+        else { sc = p.bnv[c]; sh = p.bnv[p.C + c]; }
+    }
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = p.w[c * (K * K) + i];
+    float* tiles = smem + wave * (2 * PW * TILE);
+    for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
+    const int sub = lane / LPP, li = lane % LPP;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int64_t istride = (int64_t)p.C * HWI, ostride = (int64_t)p.C * HWO;
+    // item -> (image, first output row)
+    auto split = [&](int it, int& b, int& yo0) { b = BAND ? it / NB : it; yo0 = BAND ? (it - b * NB) * RO : 0; };
+    // halo group h (0 .. HGT-1) of a band: tile row / input row relative to the band's first input row 2 yo0
+    auto halo_geo = [&](int h, int& trow, int& dy, int& xg) {
+        const int hr = h / XGI; xg = h % XGI;
+        trow = hr < PT ? hr : 2 * RO + hr;
+        dy = hr < PT ? hr - PT : 2 * RO + hr - PT;
+    };
+    f32x4 cur[NGI], hcur[NH > 0 ? NH : 1];
+    auto fetch = [&](int it, bool valid, f32x4 (&v)[NGI], f32x4 (&hv)[NH > 0 ? NH : 1]) {
+        int b, yo0;
+        split(valid ? it : i_lo, b, yo0);
+        const float* src = p.x + (int64_t)b * istride + (int64_t)c * HWI + (int64_t)(2 * yo0) * WI;
+#pragma unroll
+        for (int g = 0; g < NGI; ++g) v[g] = valid ? *reinterpret_cast<const f32x4*>(src + 4 * (li + LPP * g)) : zero;
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            hv[k] = zero;
+            const int h = lane + 64 * k;
+            if (BAND && h < HGT && valid) {
+                int trow, dy, xg;
+                halo_geo(h, trow, dy, xg);
+                const int iy = 2 * yo0 + dy;
+                if (iy >= 0 && iy < WI) hv[k] = *reinterpret_cast<const f32x4*>(src + (int64_t)dy * WI + 4 * xg);
+            }
+        }
+    };
+    fetch(i_lo + sub, i_lo + sub < i_hi, cur, hcur);
+    float s = 0.0f, q = 0.0f;
+    int buf = 0;
+    for (int i0 = i_lo; i0 < i_hi; i0 += PW, buf ^= 1) {
+        const int it = i0 + sub;
+        const bool ok = it < i_hi;
+        f32x4 nxt[NGI], hnxt[NH > 0 ? NH : 1];
+        fetch(it + PW, it + PW < i_hi, nxt, hnxt);                       // in flight during this pass
+        int b, yo0;
+        split(ok ? it : i_lo, b, yo0);
+        float* t = tiles + (buf * PW + sub) * TILE;
+#pragma unroll
+        for (int g = 0; g < NGI; ++g) {
+            const int gi = li + LPP * g, r = gi / XGI, xg = gi % XGI;
+            f32x4 v = cur[g];
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+            }
+            if (!ok) v = zero;
+            *reinterpret_cast<f32x4*>(t + (r + PT) * TW + 4 + 4 * xg) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+            const int h = lane + 64 * k;
+            if (BAND && h < HGT) {
+                int trow, dy, xg;
+                halo_geo(h, trow, dy, xg);
+                const int iy = 2 * yo0 + dy;
+                f32x4 v = hcur[k];
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+                }
+                if (!(ok && iy >= 0 && iy < WI)) v = zero;               // the reference pads ACTIVATED maps with zeros
+                *reinterpret_cast<f32x4*>(t + trow * TW + 4 + 4 * xg) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int r = li / XGO, xg = li % XGO;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* t0 = t + (2 * r) * TW + 8 * xg;                 // input rows 2r .., tile columns 8 xg .. 8 xg + 15
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                float win[16];
+                read_window<4>(t0 + ky * TW, win);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(wk[ky * K + kx], win[4 - PT + 2 * j + kx], o[j]);
+            }
+            if (ok) {
+                *reinterpret_cast<f32x4*>(p.out + (int64_t)b * ostride + (int64_t)c * HWO + (int64_t)(yo0 + r) * WO + 4 * xg) = f32x4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s += o[j]; q = fmaf(o[j], o[j], q); }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NGI; ++g) cur[g] = nxt[g];
+#pragma unroll
+        for (int k = 0; k < NH; ++k) hcur[k] = hnxt[k];
+    }
+    if (p.stats) {
+        const double sd = wave_sum_d((double)s), qd = wave_sum_d((double)q);
+        if (lane == 0) {
+            double* st = p.stats + (int64_t)((blockIdx.x + blockIdx.y) % p.nrep) * 2 * p.C;
+            atomic_add_d(st + c, sd);
+            atomic_add_d(st + p.C + c, qd);
+        }
+    }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------
 template <int K, int S, int PL, int PRO>
 __global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_kernel(const DwP p) {
@@ -1034,6 +1169,30 @@ int launch_dwconv_fwd(const S2kOp& op, const Ctx& c) {
             else DW_PLANE(5, 64, 16);
         }
 #undef DW_PLANE
+        return S2K_OK;
+    }
+    static const int s2_on = tune_int("S2K_DW_PLANE_S2", 1);
+    if (plane_on && s2_on && p.S == 2 && p.H == p.W && p.HO == p.WO && p.H == 2 * p.HO && (p.WO == 8 || p.WO == 16 || p.WO == 32 || p.WO == 64) &&
+        (p.K == 3 || p.K == 5) && p.PT == (p.K - 2) / 2 && p.PL == (p.K - 2) / 2 && (p.pro == S2K_PRO_NONE || silu)) {
+        // stride 2 on even square planes (dwconv_fwd_plane_s2_kernel)
+        const int pw = p.WO == 8 ? 4 : 1;
+        const int ro = p.WO == 64 ? 4 : p.WO == 32 ? 8 : p.WO;              // output rows per work item
+        const int n_items = p.B * (p.WO / ro);
+        static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
+        int bsplit = std::max(1, std::min(cdiv(n_items, 2 * pw), cdiv(plane_waves, p.C)));
+        const int bchunk = cdiv(cdiv(n_items, bsplit), pw) * pw;
+        bsplit = cdiv(n_items, bchunk);
+        const size_t lds = (size_t)4 * 2 * pw * (2 * ro + p.K - 2) * (p.W + 8) * sizeof(float);
+        const dim3 grid(cdiv(p.C, 4), bsplit);
+#define DW_S2(KK, WW, RR) do { \
+            if (silu) hipLaunchKernelGGL((dwconv_fwd_plane_s2_kernel<KK, S2K_PRO_SILU, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+            else hipLaunchKernelGGL((dwconv_fwd_plane_s2_kernel<KK, S2K_PRO_NONE, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+        if (p.K == 3) {
+            if (p.WO == 8) DW_S2(3, 8, 8); else if (p.WO == 16) DW_S2(3, 16, 16); else if (p.WO == 32) DW_S2(3, 32, 8); else DW_S2(3, 64, 4);
+        } else {
+            if (p.WO == 8) DW_S2(5, 8, 8); else if (p.WO == 16) DW_S2(5, 16, 16); else if (p.WO == 32) DW_S2(5, 32, 8); else DW_S2(5, 64, 4);
+        }
+#undef DW_S2
         return S2K_OK;
     }
     // tile columns: source column cc - 4; the widest window ends at 4 - PL + (4*XG - 1)*S + K - 1

@@ -501,7 +501,8 @@ DW_GEOS = [(2, 24, 16, 16, 3, 1), (2, 40, 16, 16, 5, 2), (3, 16, 7, 7, 5, 1), (2
            (1, 4, 64, 64, 5, 1), (2, 100, 8, 8, 3, 1), (1, 3, 130, 70, 3, 1),
            # small square planes at stride 1: one wave per channel walks a chunk of the batch (ragged chunks, 4 planes per pass at 8 x 8)
            (33, 12, 16, 16, 5, 1), (37, 10, 8, 8, 5, 1), (9, 6, 8, 8, 3, 1), (5, 70, 16, 16, 3, 1), (5, 10, 32, 32, 5, 1), (3, 6, 32, 32, 3, 1),
-           (3, 6, 64, 64, 3, 1), (5, 9, 64, 64, 5, 1), (2, 5, 128, 128, 3, 1)]      # row bands of 16 / 8 rows with halo rows from the neighbouring bands
+           (3, 6, 64, 64, 3, 1), (5, 9, 64, 64, 5, 1), (2, 5, 128, 128, 3, 1),      # row bands of 16 / 8 rows with halo rows from the neighbouring bands
+           (3, 6, 128, 128, 3, 2), (5, 7, 64, 64, 5, 2), (9, 5, 32, 32, 3, 2), (4, 6, 32, 32, 5, 2), (6, 5, 16, 16, 3, 2)]   # stride 2 on even planes
 
 
 def _dw_geo(B, C, H, W, K, S):
