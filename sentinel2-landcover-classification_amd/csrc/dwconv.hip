@@ -964,6 +964,120 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_kernel(const DwP 
     }
 }
 
+// ---- data gradient at stride 2 on even square planes: the wave-per-channel scheme --------------------------------------------------
+// A lane owns one 4-pixel group of dY (row r, columns 4 xg ..) and computes the 2 x 8 input pixels below it (rows 2r, 2r + 1, columns
+// 8 xg .. 8 xg + 7): input pixel (2r + py, 8 xg + 2q + px) only meets the taps with ky = (py + PT) mod 2, kx = (px + PL) mod 2 - every tap
+// feeds exactly one of the four parities, and which dY element it reads ((py + PT - ky) / 2 rows, (px + PL - kx) / 2 columns away) is
+// a compile-time constant: K * K multiply-adds per dY pixel, three aligned 16-byte LDS reads per dY row.
+template <int K, int PRO, int WO, int RO>
+__global__ void __launch_bounds__(NTHREADS) dwconv_dgrad_plane_s2_kernel(const DwP p, int bchunk) {
+    constexpr int WI = 2 * WO, PT = (K - 2) / 2;
+    constexpr int NB = WO / RO;
+    constexpr bool BAND = NB > 1;
+    constexpr int GO = RO * WO / 4, LPP = GO, PW = 64 / LPP, XGO = WO / 4;
+    constexpr int HT = 1, HB = K == 5 ? 1 : 0;     // dY halo rows above / below a band (row offsets -1 .. +1 for k = 5, -1 .. 0 for k = 3)
+    constexpr int HGT = BAND ? (HT + HB) * XGO : 0;
+    constexpr int TH = RO + HT + HB, TW = WO + 8, TILE = TH * TW;
+    constexpr int HWI = WI * WI, HWO = WO * WO;
+    static_assert((GO == 64 || GO == 16) && HGT <= 64 && (!BAND || PW == 1), "stride-2 plane geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= p.C) return;
+    const int n_items = p.B * NB;
+    const int i_lo = blockIdx.y * bchunk, i_hi = min(n_items, i_lo + bchunk);
+    float scale = 1.0f, shift = 0.0f, mean = 0.0f, invstd = 1.0f;
+    if (PRO != S2K_PRO_NONE) { scale = p.bnv[c]; shift = p.bnv[p.C + c]; mean = p.bnv[2 * p.C + c]; invstd = p.bnv[3 * p.C + c]; }
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = p.w[c * (K * K) + i];
+    float* tiles = smem + wave * (2 * PW * TILE);
+    for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
+    const int sub = lane / LPP, li = lane % LPP;
+    const int r = li / XGO, xg = li % XGO;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int64_t istride = (int64_t)p.C * HWI, ostride = (int64_t)p.C * HWO;
+    auto split = [&](int it, int& b, int& yo0) { b = BAND ? it / NB : it; yo0 = BAND ? (it - b * NB) * RO : 0; };
+    const int hr = lane / XGO, hxg = lane % XGO;                        // halo group of this lane (lane < HGT)
+    const int h_trow = hr < HT ? hr : RO + hr, h_dy = hr < HT ? hr - HT : RO + hr - HT;
+    f32x4 cur = zero, hcur = zero, xcur[4];
+    auto fetch = [&](int it, bool valid, f32x4& v, f32x4& hv, f32x4 (&xv)[4]) {
+        int b, yo0;
+        split(valid ? it : i_lo, b, yo0);
+        const float* src = p.dy + (int64_t)b * ostride + (int64_t)c * HWO + (int64_t)yo0 * WO;
+        v = valid ? *reinterpret_cast<const f32x4*>(src + 4 * li) : zero;
+        hv = zero;
+        if (BAND && lane < HGT && valid && yo0 + h_dy >= 0 && yo0 + h_dy < WO) hv = *reinterpret_cast<const f32x4*>(src + (int64_t)h_dy * WO + 4 * hxg);
+        const float* xs = p.x + (int64_t)b * istride + (int64_t)c * HWI + (int64_t)(2 * (yo0 + r)) * WI + 8 * xg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = (valid && PRO != S2K_PRO_NONE) ? *reinterpret_cast<const f32x4*>(xs + (k >> 1) * WI + 4 * (k & 1)) : zero;
+    };
+    fetch(i_lo + sub, i_lo + sub < i_hi, cur, hcur, xcur);
+    float s1 = 0.0f, s2 = 0.0f;
+    int buf = 0;
+    for (int i0 = i_lo; i0 < i_hi; i0 += PW, buf ^= 1) {
+        const int it = i0 + sub;
+        const bool ok = it < i_hi;
+        f32x4 nxt, hnxt, xnxt[4];
+        fetch(it + PW, it + PW < i_hi, nxt, hnxt, xnxt);
+        int b, yo0;
+        split(ok ? it : i_lo, b, yo0);
+        float* gout = p.out + (int64_t)b * istride + (int64_t)c * HWI + (int64_t)(2 * (yo0 + r)) * WI + 8 * xg;
+        f32x4 ob[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ob[k] = (p.beta && ok) ? *reinterpret_cast<const f32x4*>(gout + (k >> 1) * WI + 4 * (k & 1)) : zero;
+        float* t = tiles + (buf * PW + sub) * TILE;
+        *reinterpret_cast<f32x4*>(t + (r + HT) * TW + 4 + 4 * xg) = ok ? cur : zero;
+        if (BAND && lane < HGT) *reinterpret_cast<f32x4*>(t + h_trow * TW + 4 + 4 * hxg) = (ok && yo0 + h_dy >= 0 && yo0 + h_dy < WO) ? hcur : zero;
+        __builtin_amdgcn_wave_barrier();
+        float acc[2][4][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[a][q][0] = acc[a][q][1] = 0.0f;
+        float win[3][12];
+#pragma unroll
+        for (int d = 0; d < HT + 1 + HB; ++d) read_window<3>(t + (r + d) * TW + 4 * xg, win[d]);      // dY rows r - 1 .. r (+ 1), dY columns 4 xg - 4 .. 4 xg + 7
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int py = (ky + PT) & 1, dyo = (py + PT - ky) >> 1;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int px = (kx + PT) & 1, dxo = (px + PT - kx) >> 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[py][q][px] = fmaf(wk[ky * K + kx], win[dyo + HT][4 + q + dxo], acc[py][q][px]);
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int py = k >> 1, h = k & 1;                       // row 2r + py, columns 8 xg + 4 h .. + 3
+                float o[4] = {acc[py][2 * h][0], acc[py][2 * h][1], acc[py][2 * h + 1][0], acc[py][2 * h + 1][1]};
+                if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] *= act_grad(fmaf(xcur[k][j], scale, shift), PRO);
+                        s1 += o[j];
+                        s2 = fmaf(o[j], (xcur[k][j] - mean) * invstd, s2);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(gout + py * WI + 4 * h) = f32x4{o[0] + ob[k][0], o[1] + ob[k][1], o[2] + ob[k][2], o[3] + ob[k][3]};
+            }
+        }
+        cur = nxt; hcur = hnxt;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xcur[k] = xnxt[k];
+    }
+    if (p.stats) {
+        const double sd = wave_sum_d((double)s1), qd = wave_sum_d((double)s2);
+        if (lane == 0) {
+            double* st = p.stats + (int64_t)((blockIdx.x + blockIdx.y) % p.nrep) * 2 * p.C;
+            atomic_add_d(st + c, sd);
+            atomic_add_d(st + p.C + c, qd);
+        }
+    }
+}
+
 // ---- data gradient, stride 2 (4 layers of a b5) ------------------------------------------------------
 // A lane computes a 2x2 block of input pixels.  Input pixel (iy, ix) only meets the taps with (iy + PT - ky) and
 // (ix + PL - kx) even, i.e. each of the K*K taps feeds exactly ONE of the block's four pixels, and which one depends only on
@@ -1315,6 +1429,31 @@ int launch_dwconv_dgrad(const S2kOp& op, const Ctx& c) {
         if (p.K == 3) return pr == 0 ? DW_DG(3, 0) : pr == 1 ? DW_DG(3, 1) : DW_DG(3, 2);
         return pr == 0 ? DW_DG(5, 0) : pr == 1 ? DW_DG(5, 1) : DW_DG(5, 2);
 #undef DW_DG
+    }
+    static const int s2_on = tune_int("S2K_DW_PLANE_S2", 1);
+    if (s2_on && p.S == 2 && p.H == p.W && p.HO == p.WO && p.H == 2 * p.HO && (p.WO == 8 || p.WO == 16 || p.WO == 32 || p.WO == 64) &&
+        (p.K == 3 || p.K == 5) && p.PT == (p.K - 2) / 2 && p.PL == (p.K - 2) / 2 && (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
+        // even square planes (dwconv_dgrad_plane_s2_kernel)
+        const int pw = p.WO == 8 ? 4 : 1;
+        const int ro = p.WO == 64 ? 4 : p.WO == 32 ? 8 : p.WO;              // dY rows per work item
+        const int n_items = p.B * (p.WO / ro);
+        static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
+        int bsplit = std::max(1, std::min(cdiv(n_items, 2 * pw), cdiv(plane_waves, p.C)));
+        const int bchunk = cdiv(cdiv(n_items, bsplit), pw) * pw;
+        bsplit = cdiv(n_items, bchunk);
+        const size_t lds2 = (size_t)4 * 2 * pw * (ro + (p.K == 5 ? 2 : 1)) * (p.WO + 8) * sizeof(float);
+        const dim3 grid(cdiv(p.C, 4), bsplit);
+        const bool sl = p.pro == S2K_PRO_SILU;
+#define DW_DG2(KK, WW, RR) do { \
+            if (sl) hipLaunchKernelGGL((dwconv_dgrad_plane_s2_kernel<KK, S2K_PRO_SILU, WW, RR>), grid, dim3(NTHREADS), lds2, c.stream, p, bchunk); \
+            else hipLaunchKernelGGL((dwconv_dgrad_plane_s2_kernel<KK, S2K_PRO_NONE, WW, RR>), grid, dim3(NTHREADS), lds2, c.stream, p, bchunk); } while (0)
+        if (p.K == 3) {
+            if (p.WO == 8) DW_DG2(3, 8, 8); else if (p.WO == 16) DW_DG2(3, 16, 16); else if (p.WO == 32) DW_DG2(3, 32, 8); else DW_DG2(3, 64, 4);
+        } else {
+            if (p.WO == 8) DW_DG2(5, 8, 8); else if (p.WO == 16) DW_DG2(5, 16, 16); else if (p.WO == 32) DW_DG2(5, 32, 8); else DW_DG2(5, 64, 4);
+        }
+#undef DW_DG2
+        return S2K_OK;
     }
     const size_t lds = tile_rows(p, p.H, p.W, irt_dgrad2, p.WO + 2, true, false);   // one zero column on either side
     return p.K == 3 ? launch_dw(dwconv_dgrad_s2_kernel<3>, p, lds, c.stream) : launch_dw(dwconv_dgrad_s2_kernel<5>, p, lds, c.stream);
