@@ -464,6 +464,117 @@ __global__ void __launch_bounds__(NTHREADS) dwconv_fwd_plane_kernel(const DwP p,
     }
 }
 
+// ---- weight gradient on square planes at stride 1: the wave-per-channel scheme of dwconv_fwd_plane_kernel ----------------------------
+// The activated input goes through the wave-private tile exactly as in the forward; the lane's dY pixels stay in registers, and every
+// lane keeps the K * K tap sums of its pixels over ALL the items the wave walks: one wave reduction and one float atomic per tap at
+// the very end (the band kernel: per plane group).
+template <int K, int PRO, int W, int R = W>
+__global__ void __launch_bounds__(NTHREADS) dwconv_wgrad_plane_kernel(const DwP p, int bchunk) {
+    constexpr int PADK = (K - 1) / 2;
+    constexpr bool BAND = R != W;
+    constexpr int NB = W / R, GPP = R * W / 4, NG = GPP > 64 ? GPP / 64 : 1, LPP = GPP > 64 ? 64 : GPP, PW = 64 / LPP, XGW = W / 4;
+    constexpr int HG = BAND ? (K - 1) * XGW : 0;
+    constexpr int TH = R + K - 1, TW = W + 8, TILE = TH * TW, HW = W * W;
+    static_assert(HG <= 64 && (!BAND || PW == 1) && W % R == 0, "band geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [4 waves][2][PW][TILE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= p.C) return;
+    const int n_items = p.B * NB;
+    const int i_lo = blockIdx.y * bchunk, i_hi = min(n_items, i_lo + bchunk);
+    float sc = 1.0f, sh = 0.0f;
+    if (PRO != S2K_PRO_NONE) { sc = p.bnv[c]; sh = p.bnv[p.C + c]; }
+    float* tiles = smem + wave * (2 * PW * TILE);
+    for (int i = lane; i < 2 * PW * TILE; i += 64) tiles[i] = 0.0f;
+    const int sub = lane / LPP, li = lane % LPP;
+    const int64_t bstride = (int64_t)p.C * HW, coff = (int64_t)c * HW;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int hrow = lane / XGW, hxg = lane % XGW;
+    const int h_trow = hrow < PADK ? hrow : R + hrow;
+    const int h_dy = hrow < PADK ? hrow - PADK : R + hrow - PADK;
+    auto item_off = [&](int it, int& y0) -> int64_t {
+        const int b = BAND ? it / NB : it;
+        y0 = BAND ? (it - b * NB) * R : 0;
+        return (int64_t)b * bstride + coff + (int64_t)y0 * W;
+    };
+    f32x4 cur[NG], dcur[NG], hcur = zero;
+    {
+        int y0;
+        const int it = i_lo + sub;
+        const bool ok0 = it < i_hi;
+        const int64_t off = item_off(ok0 ? it : i_lo, y0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            cur[g] = ok0 ? *reinterpret_cast<const f32x4*>(p.x + off + 4 * li + 256 * g) : zero;
+            dcur[g] = ok0 ? *reinterpret_cast<const f32x4*>(p.dy + off + 4 * li + 256 * g) : zero;
+        }
+        if (BAND && lane < HG && ok0 && y0 + h_dy >= 0 && y0 + h_dy < W) hcur = *reinterpret_cast<const f32x4*>(p.x + off + (int64_t)h_dy * W + 4 * hxg);
+    }
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.0f;
+    int buf = 0;
+    for (int i0 = i_lo; i0 < i_hi; i0 += PW, buf ^= 1) {
+        const int it = i0 + sub;
+        const bool ok = it < i_hi, more = it + PW < i_hi;
+        int y0, y1;
+        (void)item_off(ok ? it : i_lo, y0);
+        const int64_t offn = item_off(more ? it + PW : i_lo, y1);
+        f32x4 nxt[NG], dnxt[NG], hnxt = zero;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            nxt[g] = more ? *reinterpret_cast<const f32x4*>(p.x + offn + 4 * li + 256 * g) : zero;
+            dnxt[g] = more ? *reinterpret_cast<const f32x4*>(p.dy + offn + 4 * li + 256 * g) : zero;
+        }
+        if (BAND && lane < HG && more && y1 + h_dy >= 0 && y1 + h_dy < W) hnxt = *reinterpret_cast<const f32x4*>(p.x + offn + (int64_t)h_dy * W + 4 * hxg);
+        float* t = tiles + (buf * PW + sub) * TILE;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            f32x4 v = cur[g];
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+            }
+            if (!ok) v = zero;
+            *reinterpret_cast<f32x4*>(t + (r + PADK) * TW + 4 + 4 * xg) = v;
+        }
+        if (BAND && lane < HG) {
+            f32x4 v = hcur;
+            if (PRO != S2K_PRO_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_pro_c<PRO>(v[j], sc, sh);
+            }
+            if (!(ok && y0 + h_dy >= 0 && y0 + h_dy < W)) v = zero;
+            *reinterpret_cast<f32x4*>(t + h_trow * TW + 4 + 4 * hxg) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int gi = li + 64 * g, r = gi / XGW, xg = gi % XGW;
+            const float* t0 = t + r * TW + 4 * xg;
+            const f32x4 d = dcur[g];                                  // zero when the item does not exist
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                float win[12];
+                read_window<3>(t0 + ky * TW, win);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ky * K + kx] = fmaf(d[j], win[4 - PADK + j + kx], acc[ky * K + kx]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { cur[g] = nxt[g]; dcur[g] = dnxt[g]; }
+        hcur = hnxt;
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) atomicAdd(p.out + c * (K * K) + i, v);
+    }
+}
+
 // ---- forward at stride 2 (even sizes, TF-SAME: K - 2 pad rows / columns, the larger half below / right): the same wave-per-channel
 // scheme; a work item = RO output rows = 2 RO input rows (+ K - 2 halo rows), 4 input groups and 1 output group per lane
 template <int K, int PRO, int WO, int RO>
@@ -1333,6 +1444,39 @@ int launch_dwconv_wgrad(const S2kOp& op, const Ctx& c) {
     p.out = ref_ptr<float>(c, op.t[S2K_DWCONV_WGRAD_T_DW]);
     if (bad(p.x) || bad(p.bnv) || bad(p.dy) || bad(p.out)) { set_error("dwconv_wgrad: null base"); return S2K_EFAULT; }
     if (!p.x || !p.dy || !p.out || (p.pro != S2K_PRO_NONE && !p.bnv)) { set_error("dwconv_wgrad: missing tensor"); return S2K_EINVAL; }
+    static const int plane_on = tune_int("S2K_DW_PLANE", 1);
+    if (plane_on && p.S == 1 && p.H == p.W && (p.W == 8 || p.W == 16 || p.W == 32 || p.W == 64 || (p.W == 128 && p.K == 3)) &&
+        p.HO == p.H && p.WO == p.W && (p.K == 3 || p.K == 5) && p.PT == (p.K - 1) / 2 && p.PL == (p.K - 1) / 2 &&
+        (p.pro == S2K_PRO_NONE || p.pro == S2K_PRO_SILU)) {
+        // square planes at stride 1: one wave per channel walks (image, band) items (dwconv_wgrad_plane_kernel)
+        const int pw = p.W == 8 ? 4 : 1;
+        const int rows = p.W == 64 ? 16 : p.W == 128 ? 8 : p.W;
+        const int n_items = p.B * (p.W / rows);
+        static const int plane_waves = tune_int("S2K_DW_PLANE_WAVES", 6144);
+        int bsplit = std::max(1, std::min(cdiv(n_items, 2 * pw), cdiv(plane_waves, p.C)));
+        // every wave ends in K * K float atomics on its channel's taps, and a 128-byte line of DW holds the taps of ~3 channels: atomics
+        // on one line execute one after the other (24 channels at 128 x 128 with 256 waves per channel: 8 k atomics per line = 0.1 ms
+        // for a 0.03 ms contraction), so at most 48 waves share a channel
+        static const int wg_split_max = tune_int("S2K_DW_WGP_SPLIT_MAX", 48);
+        bsplit = std::min(bsplit, wg_split_max);
+        const int bchunk = cdiv(cdiv(n_items, bsplit), pw) * pw;
+        bsplit = cdiv(n_items, bchunk);
+        const size_t lds = (size_t)4 * 2 * pw * (rows + p.K - 1) * (p.W + 8) * sizeof(float);
+        const dim3 grid(cdiv(p.C, 4), bsplit);
+        const bool sl = p.pro == S2K_PRO_SILU;
+#define DW_WGP(KK, WW, RR) do { \
+            if (sl) hipLaunchKernelGGL((dwconv_wgrad_plane_kernel<KK, S2K_PRO_SILU, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); \
+            else hipLaunchKernelGGL((dwconv_wgrad_plane_kernel<KK, S2K_PRO_NONE, WW, RR>), grid, dim3(NTHREADS), lds, c.stream, p, bchunk); } while (0)
+        if (p.K == 3) {
+            if (p.W == 8) DW_WGP(3, 8, 8); else if (p.W == 16) DW_WGP(3, 16, 16); else if (p.W == 32) DW_WGP(3, 32, 32);
+            else if (p.W == 64) DW_WGP(3, 64, 16); else DW_WGP(3, 128, 8);
+        } else {
+            if (p.W == 8) DW_WGP(5, 8, 8); else if (p.W == 16) DW_WGP(5, 16, 16); else if (p.W == 32) DW_WGP(5, 32, 32);
+            else DW_WGP(5, 64, 16);
+        }
+#undef DW_WGP
+        return S2K_OK;
+    }
     const int lw = 4 - p.PL + (cdiv(p.WO, 4) * 4 - 1) * p.S + p.K;
     if (p.PL < 0 || p.PL > 2) { set_error("dwconv: left padding %d is not on this path", p.PL); return S2K_EINVAL; }
     size_t lds = tile_rows(p, p.HO, p.WO, irt_fwd, lw, false, true);
