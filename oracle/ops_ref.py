@@ -523,6 +523,10 @@ def op_act_fwd(m: Mem, o):
         bnv = m.view(o["BNV"], (4, C))
         x = (x.view(-1, C, HW) * bnv[0].view(1, C, 1) + bnv[1].view(1, C, 1)).reshape(-1)
     y = F.gelu(x) if act == 4 else (F.silu(x) if act == 2 else (F.relu(x) if act == 3 else x))
+    if o.get("GATE", -1) >= 0:
+        C, HW = o["C"], o["HW"]
+        B = n // (C * HW)
+        y = (y.view(B, C, HW) * m.view(o["GATE"], (B, C)).view(B, C, 1)).reshape(-1)
     m.view(o["Y"], (n,)).copy_(y)
 
 

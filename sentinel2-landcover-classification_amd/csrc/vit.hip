@@ -272,11 +272,44 @@ __global__ void act_fwd_kernel(const float* x, float* y, int64_t n, int act, con
     }
 }
 
+// BatchNorm + SiLU + SE gate of a whole [B][C][HW] tensor (HW % 4 == 0): one wave per plane chunk, 16-byte loads / stores, the
+// plane's three constants once per wave
+__global__ void __launch_bounds__(256) act_gate_planes_kernel(const float* x, float* y, const float* bnv, const float* gate, int C, int HW,
+                                                              int64_t nplanes, int chunks) {
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= nplanes * chunks) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = task / chunks;
+    const int ck = (int)(task - plane * chunks);
+    const int c = (int)(plane % C);
+    const float sc = bnv[c], sh = bnv[C + c], g = gate[plane];
+    const int start = ck * 4096, n4 = (min(4096, HW - start)) >> 2;
+    const float4* src = reinterpret_cast<const float4*>(x + plane * HW + start);
+    float4* dst = reinterpret_cast<float4*>(y + plane * HW + start);
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = src[i];
+        dst[i] = make_float4(silu_f(fmaf(v.x, sc, sh)) * g, silu_f(fmaf(v.y, sc, sh)) * g, silu_f(fmaf(v.z, sc, sh)) * g, silu_f(fmaf(v.w, sc, sh)) * g);
+    }
+}
+
 int launch_act_fwd(const S2kOp& op, const Ctx& c) {
     const float* x = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_X]);
     float* y = ref_ptr<float>(c, op.t[S2K_ACT_FWD_T_Y]);
     const float* bnv = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_BNV]);
-    CHECK_PTRS("act_fwd", x, y, bnv);
+    const float* gate = ref_ptr<const float>(c, op.t[S2K_ACT_FWD_T_GATE]);
+    CHECK_PTRS("act_fwd", x, y, bnv, gate);
+    if (gate) {
+        const int64_t n = op.n[S2K_ACT_FWD_N_COUNT];
+        const int C = op.d[S2K_ACT_FWD_D_C], HW = op.d[S2K_ACT_FWD_D_HW];
+        if (!x || !y || !bnv || op.d[S2K_ACT_FWD_D_ACT] != S2K_PRO_SILU || C <= 0 || HW <= 0 || (HW & 3) || n % ((int64_t)C * HW)) {
+            set_error("act_fwd: the gated form is BatchNorm + SiLU on [B][C][HW] with HW % 4 == 0"); return S2K_EINVAL;
+        }
+        const int64_t nplanes = n / HW;
+        const int chunks = (HW + 4095) / 4096;
+        if (nplanes * chunks >= 0x7fffffffll) { set_error("act_fwd: too many planes"); return S2K_EINVAL; }
+        hipLaunchKernelGGL(act_gate_planes_kernel, dim3((unsigned)cdiv64(nplanes * chunks, 4)), dim3(256), 0, c.stream, x, y, bnv, gate, C, HW, nplanes, chunks);
+        return S2K_OK;
+    }
     const int64_t n = op.n[S2K_ACT_FWD_N_COUNT];
     const int act = op.d[S2K_ACT_FWD_D_ACT], C = op.d[S2K_ACT_FWD_D_C], HW = op.d[S2K_ACT_FWD_D_HW];
     if (!x || !y || n <= 0 || (act != S2K_PRO_GELU && act != S2K_PRO_SILU && act != S2K_PRO_RELU) || (bnv && (C <= 0 || HW <= 0))) {

@@ -157,7 +157,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # per element, and a conv / wgrad prologue would re-evaluate it for every output-channel tile that reads the element)
     # BNV given (with C, HW): Y = act(scale[c] * X + shift[c]) on [.][C][HW] — EfficientNet.encode materialises SiLU(BN(conv_head)),
     # which the fused network only ever applies as a load prologue
-    "ACT_FWD": (["X", "Y", "BNV"], ["COUNT"], ["ACT", "C", "HW"], []),
+    # GATE given (with BNV): Y = act(scale[c] * X + shift[c]) * GATE[b][c] - the SE-gated MBConv activation materialised once for the f32 plans,
+    # whose project conv and weight gradient then read a plain tensor on the producer / consumer kernels (no 8-instruction prologue)
+    "ACT_FWD": (["X", "Y", "BNV", "GATE"], ["COUNT"], ["ACT", "C", "HW"], []),
     # multi-head attention on QKV [B][3*HEADS*HD][LS] (rows q | k | v, each (head, d); LS >= L is the row stride, 0 = L):
     #   O[b][h*HD + d][i] = sum_j softmax_j(SCALE * <q_i, k_j>) * v_j[d];  LSE[b][h][i] = log sum_j exp(SCALE * <q_i, k_j>)
     # backward reads O and LSE back, uses DELTA [B][HEADS][LS] as scratch (sum_d DO * O);  O / DQKV / LSE columns L..LS-1 := 0

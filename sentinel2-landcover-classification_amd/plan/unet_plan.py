@@ -404,9 +404,19 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
     y = p.alloc("y:" + wname, (B, M, H, W))
     stats = _stats(p, "stats:" + bnprefix, M) if p.training else None
     wp, MP = p.pack_weight("fwd", wname, M, src.C, 1, src.C, 1, 1, 0)
-    p.fwd.add("CONV", X1=src.raw, BNV1=src.bnv, GATE1=src.gate, X2=None, BNV2=None, WT=wp, BIAS=None,
+    csrc = src          # what the conv (and its weight gradient) read
+    if (not getattr(p, "bf16", False) and src.gate is not None and src.pro == D.PRO_SILU and (H * W) % 4 == 0 and src.C >= 256
+            and tune("S2K_SE_MATERIALIZE", "0") == "1"):
+        # Experiment (off by default, S2K_TUNING=1 S2K_SE_MATERIALIZE=1): SiLU(BN(y)) * gate written out once, so that the project conv and
+        # its weight gradient read a plain tensor on the producer / consumer kernels instead of re-evaluating the 8-instruction prologue
+        # per output-channel tile.  Measured on b5 13x256x256 bs 32 (gpurun_out/sem_{on,off}.json): WGRAD 9.71 -> 9.25 ms, CONV 16.15 ->
+        # 16.04 ms, the extra pass 0.46 ms - 980 vs 984 tiles/s, no gain (the weight gradients already hide on the side stream).
+        a = p.alloc("a:" + wname, (B, src.C, H, W))
+        p.fwd.add("ACT_FWD", X=src.raw, Y=a, BNV=src.bnv, GATE=src.gate, COUNT=B * src.C * H * W, ACT=D.ACT_SILU, C=src.C, HW=H * W)
+        csrc = Act(a, src.C, H, W, needs_grad=src.needs_grad)
+    p.fwd.add("CONV", X1=csrc.raw, BNV1=csrc.bnv, GATE1=csrc.gate, X2=None, BNV2=None, WT=wp, BIAS=None,
               Y=y, STATS=stats, B=B, C1=src.C, C2=0, H=H, W=W, M=M, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0,
-              HO=H, WO=W, PRO1=src.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=M,
+              HO=H, WO=W, PRO1=csrc.pro, PRO2=0, MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=0, YC=M,
               NREP=D.stats_replicas(M))
     bnv = _bn_forward(p, bnprefix, y, M, B * H * W, stats, eps, mom)
     xout = out_ref if out_ref is not None else p.alloc(f"x:block{idx}", (B, M, H, W))
@@ -430,7 +440,10 @@ def project_conv_bn_residual(p: _P, idx: int, wname: str, bnprefix: str, src: Ac
                 p.bwd.add("AXPY", X=G, Y=ident.grad, COUNT=B * M * H * W)
         dY = _bn_backward(p, bnprefix, G, y, bnv, M, H * W, D.ACT_NONE, noise=noise, keep=keep, inplace=False,
                           out_bf16=_dy_bf16_ok(p, [src], M, 1, 1, H, W, None))
-        _conv_dgrad_wgrad(p, wname, dY, [src], M, 1, 1, 0, 0, H, W, None)
+        _conv_dgrad_wgrad(p, wname, dY, [csrc], M, 1, 1, 0, 0, H, W, None)
+        if csrc is not src:       # the gradient w.r.t. the conv's input IS the gradient w.r.t. the gated activation the SE backward expects
+            assert not src.grad_init
+            src.grad, src.grad_init = csrc.grad, csrc.grad_init
 
     p.tape.append(backward)
     return out

@@ -57,6 +57,16 @@ def test_act_fwd(act):
     c.run("ACT_FWD", ["y"], tol=1e-5, X=x, Y=y, COUNT=n, ACT=act)
 
 
+@pytest.mark.parametrize("B,C,HW", [(2, 5, 64), (3, 7, 4100), (1, 300, 16), (2, 3, 8192)])
+def test_act_fwd_bn_silu_gate(B, C, HW):
+    """the SE-gated MBConv activation written out once: Y = SiLU(scale[c] * X + shift[c]) * GATE[b][c]"""
+    c = Case(5)
+    x, y = c.t("x", (B, C, HW), scale=2.0), c.t("y", (B, C, HW), "nan")
+    bnv = c.t("bnv", (4, C))
+    gate = c.t("gate", (B, C), "pos")
+    c.run("ACT_FWD", ["y"], tol=1e-5, X=x, Y=y, BNV=bnv, GATE=gate, COUNT=B * C * HW, ACT=D.ACT_SILU, C=C, HW=HW)
+
+
 def _ident_bnv(c, name, C):
     return c.t(name, (4, C), torch.cat([torch.ones(C), torch.zeros(C), torch.zeros(C), torch.ones(C)]))
 
