@@ -858,6 +858,81 @@ __global__ void __launch_bounds__(NTHREADS) se_fc_bwd_b_kernel(const float* dgp,
     }
 }
 
+// The same parameter gradients from LDS (Q <= SEW_QMAX, every EfficientNet): the four operands are a few hundred KB, so the kernel above is a
+// chain of dependent L2 round trips (32 x 2 loads per output, four loops: 18 us for microseconds of arithmetic).  Here a workgroup owns
+// SEW_CT channels: one round trip brings 32 samples of hs / dhp (whole) and of its dgp / pool columns into LDS, the sums run from
+// there in the same sample order (bit-identical results), and the tiles are added to dw2[c][.] / dw1[.][c] once at the end.
+constexpr int SEW_CT = 8, SEW_BT = 32, SEW_QMAX = 224, SEW_U = SEW_CT * SEW_QMAX / NTHREADS;
+__global__ void __launch_bounds__(NTHREADS) se_fc_wgrad_tile_kernel(const float* dgp, const float* hs, const float* dhp, const float* pool,
+                                                                    float* dw1, float* db1, float* dw2, float* db2, int B, int C, int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hs_s = smem;                         // [SEW_BT][Q]
+    float* dhp_s = hs_s + SEW_BT * Q;           // [SEW_BT][Q]
+    float* dgp_s = dhp_s + SEW_BT * Q;          // [SEW_BT][SEW_CT]
+    float* pool_s = dgp_s + SEW_BT * SEW_CT;    // [SEW_BT][SEW_CT]
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * SEW_CT, nc = min(SEW_CT, C - c0);
+    const int per = SEW_CT * Q;                 // elements of each of the two tiles, <= SEW_U per thread
+    float a1[SEW_U], a2[SEW_U];
+#pragma unroll
+    for (int u = 0; u < SEW_U; ++u) a1[u] = a2[u] = 0.0f;
+    float sb1 = 0.0f, sb2 = 0.0f;
+    for (int b0 = 0; b0 < B; b0 += SEW_BT) {
+        const int nb = min(SEW_BT, B - b0);
+        if (b0) __syncthreads();
+        for (int i = t; i < nb * Q; i += NTHREADS) {          // rows b0 .. b0 + nb of [B][Q] are one contiguous range
+            hs_s[i] = hs[(int64_t)b0 * Q + i];
+            dhp_s[i] = dhp[(int64_t)b0 * Q + i];
+        }
+        for (int i = t; i < nb * SEW_CT; i += NTHREADS) {
+            const int b = i / SEW_CT, k = i % SEW_CT;
+            const bool in = k < nc;
+            dgp_s[i] = in ? dgp[(int64_t)(b0 + b) * C + c0 + k] : 0.0f;
+            pool_s[i] = in ? pool[(int64_t)(b0 + b) * C + c0 + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SEW_U; ++u) {
+            const int e = t + u * NTHREADS;
+            if (e < per) {
+                const int c2 = (int)((uint32_t)e / (uint32_t)Q), j2 = e - c2 * Q;       // dw2 tile [SEW_CT][Q], j fastest
+                const int j1 = e / SEW_CT, c1 = e % SEW_CT;                             // dw1 tile [Q][SEW_CT], c fastest
+                float s1 = a1[u], s2 = a2[u];
+                for (int b = 0; b < nb; ++b) {
+                    s2 = fmaf(dgp_s[b * SEW_CT + c2], hs_s[b * Q + j2], s2);
+                    s1 = fmaf(dhp_s[b * Q + j1], pool_s[b * SEW_CT + c1], s1);
+                }
+                a1[u] = s1; a2[u] = s2;
+            }
+        }
+        if (t < SEW_CT) for (int b = 0; b < nb; ++b) sb2 += dgp_s[b * SEW_CT + t];
+        if (blockIdx.x == 0 && t < Q) for (int b = 0; b < nb; ++b) sb1 += dhp_s[b * Q + t];
+    }
+#pragma unroll
+    for (int u = 0; u < SEW_U; ++u) {
+        const int e = t + u * NTHREADS;
+        if (e < per) {
+            const int c2 = (int)((uint32_t)e / (uint32_t)Q), j2 = e - c2 * Q;
+            const int j1 = e / SEW_CT, c1 = e % SEW_CT;
+            if (c2 < nc) dw2[(int64_t)(c0 + c2) * Q + j2] += a2[u];
+            if (c1 < nc) dw1[(int64_t)j1 * C + c0 + c1] += a1[u];
+        }
+    }
+    if (t < nc) db2[c0 + t] += sb2;
+    if (blockIdx.x == 0 && t < Q) db1[t] += sb1;
+}
+
+static void launch_se_fc_param_grads(const float* dgp, const float* hs, const float* dhp, const float* pool, float* dw1, float* db1, float* dw2,
+                                     float* db2, int B, int C, int Q, hipStream_t st) {
+    if (Q <= SEW_QMAX) {
+        const size_t lds = (size_t)(2 * SEW_BT * Q + 2 * SEW_BT * SEW_CT) * sizeof(float);       // <= 59,392 bytes
+        hipLaunchKernelGGL(se_fc_wgrad_tile_kernel, dim3(cdiv(C, SEW_CT)), dim3(NTHREADS), lds, st, dgp, hs, dhp, pool, dw1, db1, dw2, db2, B, C, Q);
+        return;
+    }
+    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
+    hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, st, dgp, hs, dhp, pool, dw1, db1, dw2, db2, B, C, Q);
+}
+
 // Phases A1 + A2 in one launch for the layers whose squeeze width fits a wave (Q <= 64, 28 of the 39 blocks of a b5): one
 // workgroup of 16 waves per sample; the two-kernel form costs two launches for microseconds of arithmetic.  (The same merge of
 // the FORWARD pair was slower: its first Linear wants Q / 4 workgroups per sample, not one.)
@@ -966,8 +1041,7 @@ int launch_se_fc_bwd(const S2kOp& op, const Ctx& c) {
     hipLaunchKernelGGL(se_fc_bwd_a2_kernel, dim3(cdiv(C, NTHREADS), B), dim3(NTHREADS), Q * sizeof(float), c.stream, dgate, gate, hpre, w1, dpool, B, C, Q);
     }
     if (!params) return S2K_OK;
-    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
-    hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q);
+    launch_se_fc_param_grads(dgate, hs, hpre, pool, dw1, db1, dw2, db2, B, C, Q, c.stream);
     return S2K_OK;
 }
 
@@ -983,8 +1057,7 @@ int launch_se_fc_wgrad(const S2kOp& op, const Ctx& c) {
     CHECK_PTRS("se_fc_wgrad", dgp, hs, dhp, pool, dw1, db1, dw2, db2);
     const int B = op.d[S2K_SE_FC_WGRAD_D_B], C = op.d[S2K_SE_FC_WGRAD_D_C], Q = op.d[S2K_SE_FC_WGRAD_D_CSQ];
     if (!dgp || !hs || !dhp || !pool || !dw1 || !db1 || !dw2 || !db2 || B <= 0 || C <= 0 || Q <= 0) { set_error("se_fc_wgrad: bad args"); return S2K_EINVAL; }
-    const int blocks = (int)std::min<int64_t>(cdiv64((int64_t)C * Q, 256), 1024);
-    hipLaunchKernelGGL(se_fc_bwd_b_kernel, dim3(blocks), dim3(NTHREADS), 0, c.stream, dgp, hs, dhp, pool, dw1, db1, dw2, db2, B, C, Q);
+    launch_se_fc_param_grads(dgp, hs, dhp, pool, dw1, db1, dw2, db2, B, C, Q, c.stream);
     return S2K_OK;
 }
 

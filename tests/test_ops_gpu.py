@@ -648,7 +648,8 @@ def test_se_pool_bwd_reduce_channel_sum(B, C, HW):
     c.run("CHANNEL_SUM", ["out"], 1e-4, G=g, OUT=out, B=B, C=C, HW=HW)
 
 
-@pytest.mark.parametrize("B,C,Q", [(2, 48, 4), (3, 144, 6), (2, 3072, 128), (1, 1056, 44), (5, 768, 32), (2, 1824, 76), (3, 1100, 64)])   # (Q <= 64: one launch)
+@pytest.mark.parametrize("B,C,Q", [(2, 48, 4), (3, 144, 6), (2, 3072, 128), (1, 1056, 44), (5, 768, 32), (2, 1824, 76), (3, 1100, 64),
+                                   (40, 250, 10), (33, 96, 240), (32, 3840, 160)])   # (Q <= 64: one launch; B > 32: two sample chunks of the parameter-gradient tiles; Q > 224: its generic kernel)
 def test_se_fc_and_backward(B, C, Q):
     c = Case(13)
     pool = c.t("pool", (B, C), "rand")
