@@ -8,7 +8,8 @@ the dominant kernel measured live with HIP events (spec peak and the peak measur
 same run), the Adam time, a bounded CPU baseline of the same step (the CPU oracle, rank 0, N = 1
 only), and - N = 1 only, skipped with --no-prithvi - the Prithvi workloads of BASELINE.json
 configs[3] / [4] as extra keys (`prithvi_mae`, `prithvi_seg_frozen`, `prithvi_seg_unfrozen`); the
-headline `value` is always configs[1].
+headline `value` is always configs[1].  N > 1 adds `allreduce` (what the gradient all-reduce costs) and
+`prithvi_mae` = the data-parallel Prithvi-100M MAE step (configs[4]) on the same ranks, under a watchdog.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -38,6 +39,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the ~5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 GUIDE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of the 8 TB/s spec)
+MAE_DP_LIMIT_S = float(os.environ.get("S2K_MAE_DP_LIMIT_S", "240"))   # watchdog of the N > 1 Prithvi leg (an extra key must never cost the headline line)
 # SURVEY §8d, whole-step denominators (fp32): the layer-wise roofline T = sum over layers of max(FLOP / peak, bytes / BW) of
 # efficientnet-unet-b5 13x256x256 is 0.464 ms per tile (pure MFMA 0.418, pure HBM 0.140) = 2,154 tiles/s per GPU; the Prithvi
 # steps are compute-bound: forward + backward FLOP per sample / the f32 MFMA peak.
@@ -421,6 +423,51 @@ def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms:
             "backend": dist.get_backend(), "op": "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
 
 
+def prithvi_mae_dp_leg(dist, dev, rank: int, world: int, batch: int = 64, steps: int = 5, warmup: int = 2) -> dict:
+    """BASELINE.json configs[4]'s data-parallel leg (Prithvi-100M MAE pre-training, bs 64 per GPU, mask 0.75) on the N ranks of this
+    run: the same `FlatGradReducer` (segmented backward, suffix buckets of the flat gradient buffer all-reduced on a side stream),
+    timed under the headline's protocol (barrier + synchronize on both sides, MAX over ranks).  Every rank runs it; rank 0 reports."""
+    from s2lc_amd.ddp import FlatGradReducer
+    from s2lc_amd.optim import FlatAdam
+    from s2lc_amd.utils import load_untrained_prithvi
+
+    torch.manual_seed(42)
+    model = load_untrained_prithvi(1).to(dev)
+    model.train()
+    opt = FlatAdam(model, lr=1e-4)
+    ddp = FlatGradReducer(model, dist)
+    ddp.broadcast_parameters(0)
+    x = torch.randn(batch, 6, 1, 224, 224, device=dev, generator=torch.Generator(device=dev).manual_seed(1042 + rank))
+
+    def step():
+        opt.zero_grad()
+        loss = model(x, mask_ratio=0.75)[0]
+        loss.backward()
+        ddp.finish()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    dt = time_steps(step, steps, dist, dev)
+    calls = []
+    model._bwd_segment_hook = lambda lo, hi, grads: calls.append((lo, hi))     # the same segmented backward, no collective
+    step()
+    calls.clear()
+    loss = step()
+    buckets = list(calls)
+    noop_dt = time_steps(step, steps, dist, dev)
+    model._bwd_segment_hook = ddp.on_segment
+    try:
+        ar = allreduce_report(model, ddp, dist, dev, world, dt / steps * 1e3, noop_dt / steps * 1e3, buckets)
+    except Exception as e:  # noqa: BLE001
+        ar = {"error": repr(e)[:300]}
+    return {"workload": f"prithvi-100M MAE pre-training step 6x1x224x224 bs{batch}/GPU mask 0.75 (fwd+loss+bwd+allreduce+adam)",
+            "value": round(world * batch * steps / dt, 2), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "warmup": warmup, "global_batch": world * batch, "parallelism": f"dp{world}", "scaling": "weak", "dtype": "f32",
+            "n1_same_plan_samples_per_s": round(batch * steps / noop_dt, 2), "allreduce": ar, "loss": round(float(loss.item()), 6)}
+
+
 def bf16_mixed_leg(model, cfg, x, y, loss_fn, args, dev, f32_tiles_per_s, with_oracle, _lib, D) -> dict:
     """The bf16-MIXED mode, reported separately (never instead of the f32 headline): the arithmetic class the reference itself
     trains with (`precision="bf16"`, /root/reference/src/configs/segmentation.py:146,153).  Same network, same weights as the f32
@@ -545,8 +592,10 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1 only; the headline is unaffected)")
+    ap.add_argument("--no-prithvi", action="store_true", help="skip the extra Prithvi keys (N = 1: MAE and the two segmentation steps; N > 1: the data-parallel MAE step; the headline is unaffected)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra key `bf16_mixed` (N = 1 only)")
+    ap.add_argument("--mae-batch", type=int, default=64, help="per-GPU batch of the data-parallel Prithvi leg (N > 1 only)")
+    ap.add_argument("--mae-steps", type=int, default=5, help="timed steps of the data-parallel Prithvi leg (N > 1 only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"],
                     help="arithmetic of the HEADLINE run (default f32, the parity path; bf16-mixed is otherwise reported as the extra key `bf16_mixed`)")
     args = ap.parse_args()
@@ -737,7 +786,33 @@ def main() -> None:
             "n1_same_plan_tiles_per_s": same_plan,
             "allreduce": allreduce, **extra,
         }
-        print(json.dumps(line))
+    if dist is not None and not args.no_prithvi:
+        # N > 1: the data-parallel Prithvi leg (configs[4]).  It is collective, so it runs on every rank after rank 0's profile legs;
+        # an extra key must never cost the headline line: a watchdog prints the line without the key and ends the rank if the leg hangs
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["prithvi_mae"] = {"error": f"the data-parallel Prithvi leg did not finish within {MAE_DP_LIMIT_S} s"}
+                print(json.dumps(line), flush=True)
+            print(f"bench.py: rank {rank}: data-parallel Prithvi leg timed out", file=sys.stderr, flush=True)
+            os._exit(0)
+        dog = threading.Timer(MAE_DP_LIMIT_S, give_up)
+        dog.daemon = True
+        dist.barrier()          # (the other ranks waited here while rank 0 profiled)
+        dog.start()
+        try:
+            del model, opt
+            torch.cuda.empty_cache()
+            mae = prithvi_mae_dp_leg(dist, dev, rank, world, batch=args.mae_batch, steps=args.mae_steps, warmup=2 if args.mae_steps >= 3 else 1)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: prithvi_mae (data-parallel) failed: {e!r}", file=sys.stderr, flush=True)
+            mae = {"error": repr(e)[:300]}
+        dog.cancel()
+        if rank == 0:
+            line["prithvi_mae"] = mae
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()          # rank 0 profiles after the timed region: nobody tears the group down under it
         dist.destroy_process_group()

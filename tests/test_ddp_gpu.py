@@ -223,8 +223,8 @@ def test_bench_self_launches_its_ranks(tmp_path):
     env = dict(os.environ, S2K_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-prithvi",
-                        "--no-cpu-baseline", "--version", "b0", "--bands", "4", "--size", "64", "--batch", "2"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mae-batch", "2",
+                        "--mae-steps", "1", "--no-cpu-baseline", "--version", "b0", "--bands", "4", "--size", "64", "--batch", "2"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -235,6 +235,30 @@ def test_bench_self_launches_its_ranks(tmp_path):
     ar = doc["allreduce"]
     assert ar["buckets"] >= 1 and ar["bytes"] > 0 and ar["backend"] == "gloo" and "ms_exposed" in ar and ar["bus_gbps"] > 0
     assert doc["n1_same_plan_tiles_per_s"] > 0
+    # the data-parallel Prithvi-100M MAE leg (BASELINE.json configs[4]) on the same two ranks
+    mae = doc["prithvi_mae"]
+    assert "error" not in mae, mae
+    assert mae["n_gpus"] == 2 and mae["parallelism"] == "dp2" and mae["global_batch"] == 4 and mae["value"] > 0
+    assert mae["allreduce"]["buckets"] >= 1 and mae["allreduce"]["bytes"] > 4 * 80e6 and mae["n1_same_plan_samples_per_s"] > 0
+
+
+def test_bench_headline_survives_a_hung_prithvi_leg():
+    """The N > 1 Prithvi leg is an extra key under a watchdog: when it does not finish in time, rank 0 still prints the headline
+    line (with an error in place of the key) and every rank ends with exit code 0."""
+    import json
+    import os
+
+    env = dict(os.environ, S2K_DIST_BACKEND="gloo", S2K_MAE_DP_LIMIT_S="0.05")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile",
+                        "--version", "b0", "--bands", "4", "--size", "64", "--batch", "2"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["value"] > 0 and "did not finish" in doc["prithvi_mae"]["error"]
 
 
 def test_rccl_world_size_one_reducer(tmp_path):
