@@ -1,0 +1,117 @@
+"""A short TRAINING RUN against the CPU oracle: the same weights, batches, drop-connect draws and optimiser settings, step after
+step (forward + focal loss + backward + Adam with L2-coupled weight decay, BatchNorm running statistics carried along) - the
+loop of the reference's `training_step` + `configure_optimizers` (/root/reference/src/train_segmentation.py:129-147, :222-237).
+Single steps are pinned elsewhere (tests/test_unet_gpu.py, tests/test_parity_r2_gpu.py); this one checks that nothing drifts
+when the steps are chained: per-step losses, the BatchNorm buffers and the parameters after the last step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, losses_ref
+from oracle import efficientnet_unet_ref as R
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 12
+LR, WD = 1e-3, 0.05          # (the reference's lr is 1.5e-6: far too small for a 12-step run to move anything)
+
+
+def _batch(t, B, C, H, ncls):
+    x = detgen.normal(f"traj.x{t % 3}", (B, C, H, H), seed=77)
+    y = x[:, :ncls].argmax(dim=1)                 # a learnable rule: the brightest of the first bands (class 0 is ignored by the loss)
+    return x, y
+
+
+def _oracle_run(net, sd, dtype, C, H, B, ncls):
+    osd = {}
+    for k, v in sd.items():
+        v = v.detach().clone()
+        if v.dtype.is_floating_point:
+            v = v.to(dtype)
+            if not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        osd[k] = v
+    oopt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=LR, weight_decay=WD)
+    losses = []
+    for t in range(STEPS):
+        x, y = _batch(t, B, C, H, ncls)
+        noise = detgen.uniform(f"traj.dc{t}", (len(net.blocks), B), 0.0, 1.0, seed=77)
+        newbuf = {}
+        logits = R.unet_forward(osd, net, x.to(dtype), training=True, dc_noise=noise.to(dtype), new_buffers=newbuf)
+        loss = losses_ref.focal(logits, y, torch.ones(ncls, dtype=dtype), 2.0, 0.0, ignore_index=0)
+        oopt.zero_grad()
+        loss.backward()
+        oopt.step()
+        for k, v in newbuf.items():
+            osd[k] = v
+        losses.append(float(loss.item()))
+    return np.array(losses), {k: v.detach() for k, v in osd.items()}
+
+
+def _distance(got: dict, ref: dict, sd0: dict):
+    """worst running-statistic error, worst parameter error (both relative to the tensor's largest value), smallest cosine between
+    the parameter UPDATES of a tensor (>= 64 elements)"""
+    worst_buf, worst_par, cos_min = 0.0, 0.0, 1.0
+    for k, r in ref.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(r), k
+            continue
+        g, r = got[k].double(), r.double()
+        err = (g - r).abs().max().item() / max(r.abs().max().item(), 1e-6)
+        if k.endswith(("running_mean", "running_var")):
+            worst_buf = max(worst_buf, err)
+        else:
+            worst_par = max(worst_par, err)
+            dg, dr = (g - sd0[k].double()).flatten(), (r - sd0[k].double()).flatten()
+            if dr.norm() > 0 and dr.numel() >= 64:
+                cos_min = min(cos_min, float(dg @ dr / (dg.norm() * dr.norm() + 1e-30)))
+    return worst_buf, worst_par, cos_min
+
+
+@pytest.mark.parametrize("version,C,H,B", [("b0", 4, 64, 4), ("b2", 6, 96, 2)])
+def test_training_trajectory_matches_the_oracle(version, C, H, B, record_property):
+    from s2lc_amd.losses import FocalLoss
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+    from s2lc_amd.optim import FlatAdam
+
+    ncls = 4
+    dev = torch.device("cuda:0")
+    net = R.build(version, C, ncls, drop_connect_rate=0.2)
+    sd = detgen.fill_state(R.state_shapes(net), seed=77)
+    model = EfficientnetUnet(EfficientNetConfig(version, C, ncls, class_distribution=[1.0 / ncls] * ncls, drop_connect_rate=0.2))
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    opt = FlatAdam(model, lr=LR, weight_decay=WD)
+    loss_fn = FocalLoss(torch.ones(ncls), 2.0, 0.0, ignore_index=0)
+    lg = []
+    for t in range(STEPS):
+        x, y = _batch(t, B, C, H, ncls)
+        model.drop_connect_noise = detgen.uniform(f"traj.dc{t}", (len(net.blocks), B), 0.0, 1.0, seed=77)
+        opt.zero_grad()
+        loss = loss_fn(model(x.to(dev)), y.to(dev))
+        loss.backward()
+        opt.step()
+        lg.append(float(loss.item()))
+    lg = np.array(lg)
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    # Adam divides by sqrt(v): an element whose gradient is rounding noise around zero moves by lr per step in EITHER direction, so
+    # two correct fp32 runs separate from the first update on.  The yardstick is therefore the fp32 oracle's own distance from the
+    # float64 oracle on the same run: the product must stay within a small multiple of it (same rule as tests/test_unet_gpu.py).
+    l64, sd64 = _oracle_run(net, sd, torch.float64, C, H, B, ncls)
+    l32, sd32 = _oracle_run(net, sd, torch.float32, C, H, B, ncls)
+    e_gpu, e_or = np.abs(lg - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
+    buf_g, par_g, cos_g = _distance(got, sd64, sd)
+    buf_o, par_o, cos_o = _distance(sd32, sd64, sd)
+    for k, v in (("loss_first", l64[0]), ("loss_last", l64[-1]), ("loss_rel_err_max", e_gpu.max()), ("loss_rel_err_max_fp32_oracle", e_or.max()),
+                 ("running_stat_rel_err_max", buf_g), ("running_stat_rel_err_max_fp32_oracle", buf_o), ("param_rel_err_max", par_g),
+                 ("param_rel_err_max_fp32_oracle", par_o), ("param_update_cosine_min", cos_g), ("param_update_cosine_min_fp32_oracle", cos_o)):
+        record_property(k, float(v))
+    print("trajectory", version, "loss64", np.round(l64, 5).tolist(), "\n  e_gpu", np.round(e_gpu, 6).tolist(), "\n  e_or ", np.round(e_or, 6).tolist(),
+          "\n  buf", buf_g, buf_o, "par", par_g, par_o, "cos", cos_g, cos_o)
+    assert e_gpu[0] < 1e-4, (lg[0], l64[0])                                        # the first step is a single forward: exact parity
+    assert l64[-3:].mean() < l64[:3].mean() and lg[-3:].mean() < lg[:3].mean()     # it trains, on both sides
+    assert e_gpu.max() < 4 * e_or.max() + 1e-4, (e_gpu.max(), e_or.max())
+    assert buf_g < 4 * buf_o + 1e-4, (buf_g, buf_o)
+    assert par_g < 4 * par_o + 1e-4, (par_g, par_o)
+    assert cos_g > min(0.9, cos_o - 0.1), (cos_g, cos_o)
