@@ -158,3 +158,65 @@ def test_bf16_mixed_training_trajectory_tracks_the_f32_one(record_property):
     assert e16.max() < 2e-2, e16            # measured 6.4e-3 (the f32 path: 5.8e-3)
     assert curves["bf16-mixed"][-3:].mean() < 0.7 * curves["bf16-mixed"][:3].mean()
     assert abs(curves["bf16-mixed"][-3:].mean() - l64[-3:].mean()) < 0.03 * l64[-3:].mean()
+
+
+def test_mae_training_trajectory_matches_the_oracle(record_property):
+    """The Prithvi MAE pre-training loop (/root/reference/src/train_mae_prithvi.py:76-106: loss of the masked forward, backward, Adam)
+    chained for 12 steps on a small configuration, fresh masking noise per step, against the float64 oracle doing the same."""
+    from oracle import prithvi_ref as P
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.optim import FlatAdam
+    from tests.helpers import PRITHVI_SMALL
+
+    dev = torch.device("cuda:0")
+    args, B, ratio = dict(PRITHVI_SMALL, depth=3, decoder_depth=2), 8, 0.75
+    cfg = P.MaeCfg(**args)
+    sd = detgen.fill_state(P.mae_state_shapes(cfg), seed=91)
+    sd["pos_embed"] = P.sincos_pos_embed(cfg.embed_dim, cfg.grid)
+    sd["decoder_pos_embed"] = P.sincos_pos_embed(cfg.decoder_embed_dim, cfg.grid)
+    xs = [detgen.normal(f"mtraj.x{i}", (B, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), seed=91) for i in range(3)]
+    noises = [detgen.uniform(f"mtraj.n{t}", (B, cfg.num_patches), 0.0, 1.0, seed=91) for t in range(STEPS)]
+
+    model = MaskedAutoencoderViT(**args)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    opt = FlatAdam(model, lr=LR, weight_decay=WD)
+    lg = []
+    for t in range(STEPS):
+        model.masking_noise = noises[t]
+        opt.zero_grad()
+        loss = model(xs[t % 3].to(dev), mask_ratio=ratio)[0]
+        loss.backward()
+        opt.step()
+        lg.append(float(loss.item()))
+    lg = np.array(lg)
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+    def oracle(dtype):
+        osd = {k: v.detach().clone().to(dtype).requires_grad_(not k.endswith("pos_embed")) for k, v in sd.items()}
+        oopt = torch.optim.Adam([v for v in osd.values() if v.requires_grad], lr=LR, weight_decay=WD)
+        ls = []
+        for t in range(STEPS):
+            loss = P.mae_forward(osd, cfg, xs[t % 3].to(dtype), ratio, noises[t].to(dtype))[0]
+            oopt.zero_grad()
+            loss.backward()
+            oopt.step()
+            ls.append(float(loss.item()))
+        return np.array(ls), {k: v.detach() for k, v in osd.items()}
+
+    l64, sd64 = oracle(torch.float64)
+    l32, sd32 = oracle(torch.float32)
+    e_gpu, e_or = np.abs(lg - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
+    _, par_g, cos_g = _distance(got, sd64, sd)
+    _, par_o, cos_o = _distance(sd32, sd64, sd)
+    for k, v in (("loss_first", l64[0]), ("loss_last", l64[-1]), ("loss_rel_err_max", e_gpu.max()), ("loss_rel_err_max_fp32_oracle", e_or.max()),
+                 ("param_rel_err_max", par_g), ("param_rel_err_max_fp32_oracle", par_o), ("param_update_cosine_min", cos_g),
+                 ("param_update_cosine_min_fp32_oracle", cos_o)):
+        record_property(k, float(v))
+    print("mae trajectory loss64", np.round(l64, 5).tolist(), "\n  e_gpu", np.round(e_gpu, 7).tolist(), "\n  e_or ", np.round(e_or, 7).tolist(),
+          "\n  par", par_g, par_o, "cos", cos_g, cos_o)
+    assert e_gpu[0] < 1e-4, (lg[0], l64[0])
+    assert l64[-3:].mean() < l64[:3].mean() and lg[-3:].mean() < lg[:3].mean()
+    assert e_gpu.max() < 4 * e_or.max() + 1e-4, (e_gpu.max(), e_or.max())
+    assert par_g < 4 * par_o + 1e-4, (par_g, par_o)
+    assert cos_g > min(0.9, cos_o - 0.1), (cos_g, cos_o)
