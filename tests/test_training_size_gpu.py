@@ -273,6 +273,48 @@ def test_prithvi_100m_mae_bs2_gradients_match_reference(record_property):
     assert errs[0][0] < 2e-3, errs[:5]
 
 
+def test_prithvi_100m_mae_bs64_plan_equals_the_replicated_bs2_step(record_property):
+    """BASELINE.json configs[3] / [4] at the benchmark's batch: the bs-64 plan tiles its Linears differently from the bs-2 one (64 x 64
+    producer / consumer tiles chosen by token count, other pixel splits in the weight gradients, attention over 64 x 12 heads).  A
+    batch of 32 copies of the bs-2 tiles with the same masking noise must give the same predictions per copy, the same loss and
+    - the loss being a mean over masked patches - the same gradients: a property of the arithmetic at any size, checked against the
+    bs-2 step that the test above pins to the reference."""
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+
+    tag, B, ratio, seed, rep = "full_bs2_grads", 2, 0.75, 15, 32
+    cfg = P.MaeCfg(**PRITHVI_FULL)
+    sd = detgen.fill_state(P.mae_state_shapes(cfg), seed=seed)
+    sd["pos_embed"] = P.sincos_pos_embed(cfg.embed_dim, cfg.grid)
+    sd["decoder_pos_embed"] = P.sincos_pos_embed(cfg.decoder_embed_dim, cfg.grid)
+    x = detgen.normal(f"{tag}.x", (B, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), seed=seed)
+    noise = detgen.uniform(f"{tag}.noise", (B, cfg.num_patches), 0.0, 1.0, seed=seed)
+    model = MaskedAutoencoderViT(**PRITHVI_FULL)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    model.masking_noise = noise
+    loss2, pred2, mask2 = model(x.to(DEV), mask_ratio=ratio)
+    loss2.backward()
+    g2 = model._grad_buffer().detach().clone()
+    for p_ in model.parameters():
+        p_.grad = None
+    model._grad_buffer().zero_()
+    model.masking_noise = noise.repeat(rep, 1)
+    loss64, pred64, mask64 = model(x.repeat(rep, 1, 1, 1, 1).to(DEV), mask_ratio=ratio)
+    loss64.backward()
+    torch.cuda.synchronize()
+    g64 = model._grad_buffer().detach()
+    assert torch.equal(mask64.view(rep, B, -1), mask2.unsqueeze(0).expand(rep, -1, -1))
+    p2 = pred2.detach().cpu().numpy()
+    for r in (0, 13, rep - 1):
+        assert rel_err(pred64[B * r:B * r + B].detach().cpu().numpy(), p2) < 2e-4, r
+    assert abs(loss64.item() - loss2.item()) < 2e-5 * abs(loss2.item())
+    n2 = (g64.double() - g2.double()).norm().item() / g2.double().norm().item()
+    r2 = g64.double().pow(2).sum().item() / g2.double().pow(2).sum().item()
+    print(f"prithvi-100M MAE bs 64 (32 x the bs-2 batch) vs bs 2: |g64 - g2| / |g2| = {n2:.2e}, |g64|^2 / |g2|^2 = {r2:.6f}")
+    record_property("grad_rel_l2_err_bs64_vs_bs2", n2)
+    assert n2 < 2e-3 and abs(r2 - 1.0) < 1e-3, (n2, r2)
+
+
 def test_prithvi_100m_seg_bs1_train_unfrozen_through_product_loss(record_property):
     """configs[3]'s model, the step as benchmarked: PrithviSegmentationNet (Prithvi-100M, unfrozen) in train mode -> PRODUCT
     CrossEntropyLoss(ignore_index=0) -> product backward; logits / loss / class mask / BatchNorm buffers against the imported
@@ -331,3 +373,53 @@ def test_prithvi_100m_seg_bs1_train_unfrozen_through_product_loss(record_propert
     assert rel_err(st["head.net.1.running_mean"].cpu().numpy(), g["rm:head.net.1"]) < 1e-4
     assert rel_err(st["head.net.1.running_var"].cpu().numpy(), g["rv:head.net.1"]) < 1e-4
     assert int(st["head.net.1.num_batches_tracked"]) == int(g["nbt:head.net.1"][0])
+
+
+def test_prithvi_100m_seg_bs16_plan_equals_the_replicated_bs1_step(record_property):
+    """BASELINE.json configs[4]'s fine-tuning step at the benchmark's batch (bs 16, unfrozen backbone, product CE): 16 copies of the
+    bs-1 tile with the same masking / dropout draws.  Every BatchNorm of the head sees the same batch mean and variance as at bs 1, so
+    logits repeat, the loss is the same and the gradients are the bs-1 gradients - the bs-16 plan (2.4 GiB neck activations, other
+    tiles and splits) against the bs-1 step the test above pins to the reference."""
+    from s2lc_amd.losses import CrossEntropyLoss
+    from s2lc_amd.modules.prithvi import MaskedAutoencoderViT
+    from s2lc_amd.modules.prithvi_segmentation import PrithviSegmentationNet, PrithviSegmentationNetConfig
+
+    tag, fcn_out, seed, rep = "full_train_unfrozen_bs1", 256, 25, 16
+    m = P.MaeCfg(**PRITHVI_FULL)
+    cfg = P.SegCfg(mae=m, num_classes=NCLS, fcn_out_channels=fcn_out, fcn_num_convs=1, fcn_dropout=0.1, frozen_backbone=False)
+    sd = detgen.fill_state(P.seg_state_shapes(cfg), seed=seed)
+    sd["backbone.pos_embed"] = P.sincos_pos_embed(m.embed_dim, m.grid)
+    sd["backbone.decoder_pos_embed"] = P.sincos_pos_embed(m.decoder_embed_dim, m.grid)
+    x = detgen.normal(f"{tag}.x", (1, m.in_chans, m.num_frames, m.img_size, m.img_size), seed=seed)
+    y = detgen.labels(f"{tag}.y", (1, m.img_size, m.img_size), NCLS, seed=seed)
+    noise = detgen.uniform(f"{tag}.noise", (1, m.num_patches), 0.0, 1.0, seed=seed)
+    drop_u = detgen.uniform(f"{tag}.drop", (1, fcn_out), 0.0, 1.0, seed=seed)
+    bb = MaskedAutoencoderViT(**PRITHVI_FULL, _decoder=False, _flat=False)
+    net = PrithviSegmentationNet(PrithviSegmentationNetConfig(1, NCLS, fcn_out, 1, 0.1, False), backbone=bb)
+    net.load_state_dict(sd)
+    net.to(DEV).train()
+    lossf = CrossEntropyLoss(ignore_index=0)
+    bufs0 = net._flat_bufs.detach().clone()
+    net.masking_noise, net.dropout_noise = noise, drop_u
+    lg1 = net(x.to(DEV))
+    ce1 = lossf(lg1, y.to(DEV))
+    ce1.backward()
+    g1 = net._grad_buffer().detach().clone()
+    for p_ in net.parameters():
+        p_.grad = None
+    net._flat_bufs.copy_(bufs0)                                   # the same BatchNorm running state in front of the second step
+    net.masking_noise, net.dropout_noise = noise.repeat(rep, 1), drop_u.repeat(rep, 1)
+    lg16 = net(x.repeat(rep, 1, 1, 1, 1).to(DEV))
+    ce16 = lossf(lg16, y.repeat(rep, 1, 1).to(DEV))
+    ce16.backward()
+    torch.cuda.synchronize()
+    g16 = net._grad_buffer().detach()
+    l1 = lg1.detach().cpu().numpy()
+    for r in (0, 7, rep - 1):
+        assert rel_err(lg16[r:r + 1].detach().cpu().numpy(), l1) < 2e-4, r
+    assert abs(ce16.item() - ce1.item()) < 2e-5 * abs(ce1.item())
+    n2 = (g16.double() - g1.double()).norm().item() / g1.double().norm().item()
+    r2 = g16.double().pow(2).sum().item() / g1.double().pow(2).sum().item()
+    print(f"prithvi-100M segmentation bs 16 (16 x the bs-1 tile) vs bs 1: |g16 - g1| / |g1| = {n2:.2e}, |g16|^2 / |g1|^2 = {r2:.6f}")
+    record_property("grad_rel_l2_err_bs16_vs_bs1", n2)
+    assert n2 < 5e-3 and abs(r2 - 1.0) < 2e-3, (n2, r2)
