@@ -817,9 +817,14 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         bwd_aux_end = p.aux.mark()
         defer = getattr(p, "defer_wgrads", None)
         if defer is None:
-            defer = tune("S2K_DEFER_WGRAD", "1") != "0"
+            # f32: the decoder's large weight gradients (>= 8 GFLOP: 19 of 23 at the benchmark size) are issued during the encoder's
+            # HBM-bound backward instead of beside the MFMA-bound decoder convs.  Re-measured in round 3 after the depthwise / bandwidth
+            # kernels got faster (tools/exp_defer_ab.sh, alternating runs on one box): threshold 4 -> 8 GFLOP +0.5 % (the encoder has less
+            # slack to hide them: deferred work finished ~0.13 ms after the main queue); bf16-mixed: no deferral at all +1.1 % (its decoder
+            # convs are HBM-bound too, nothing is gained by moving MFMA work away from them), threshold 8 only +0.25 %.
+            defer = tune("S2K_DEFER_WGRAD", "0" if getattr(p, "bf16", False) else "1") != "0"
         if defer:
-            p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(tune("S2K_DEFER_MIN_GFLOP", "4")))
+            p.bwd.ops[:] = _defer_decoder_wgrads(p.bwd.ops, float(tune("S2K_DEFER_MIN_GFLOP", "8")))
         # zero the weight-gradient scratch of the convs that go through WGRAD_FINALIZE (3x3, 2x2-gather): one range from the
         # first to the last such weight (1x1 convs / Linears accumulate straight into the gradient buffer and need none)
         pre_ops = []
