@@ -840,13 +840,18 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         # weight / bias gradients feed nothing in the backward chain until the bucket's WGRAD_FINALIZE: the executor may run
         # them on its side stream, concurrently with the (mostly HBM-bound) BatchNorm / depthwise stages of the layers below
         side_max = float(tune("S2K_SIDE_MAX_GFLOP", "1e9")) * 1e9
+        finalize_on_side = tune("S2K_FINALIZE_SIDE", "1") != "0"
         for kind, f in p.bwd.ops:
             if kind == "WGRAD" and 2.0 * f["M"] * f["C"] * f["KH"] * f["KW"] * f["B"] * f["HO"] * f["WO"] > side_max:
                 continue      # two large MFMA-bound kernels side by side only fight for the same units
             if kind in ("WGRAD", "DWCONV_WGRAD", "CHANNEL_SUM", "SE_FC_WGRAD"):
                 f["_flags"] = D.FLAG_SIDE
             elif kind == "WGRAD_FINALIZE":
-                f["_flags"] = D.FLAG_JOIN
+                # the fold of a bucket's conv-weight scratch into the gradient buffer reads what the weight gradients wrote: on the
+                # side stream it is ordered behind them by the stream itself and the main queue does not wait (a JOIN here stalled the
+                # main queue ~0.17 ms per step in tape-order plans, where the decoder's bucket closes while its weight gradients are
+                # still running); the executor joins at the end of every run, so a bucket is still final when its segment returns
+                f["_flags"] = D.FLAG_SIDE if finalize_on_side else D.FLAG_JOIN
         side_stream_hazards(p.bwd)
         n_before = len(p.bwd.ops)
         pack_op(p.bwd, p.pack_rows["bwd"])

@@ -286,8 +286,9 @@ def test_no_main_stream_stage_overwrites_what_a_side_stream_stage_still_reads():
     plan = mae._make_plan(2, True, 0.75, True)
     j = check(plan.bwd)
     # the residual-stream gradient gets a fresh buffer at every update (CHAN_LN_BWD with DXIN), so no LayerNorm backward has to
-    # wait for the side stream: the only joins are the buckets' WGRAD_FINALIZE stages
-    assert j == sum(1 for k, _ in plan.bwd.ops if k == "WGRAD_FINALIZE")
+    # wait for the side stream: the only joins would be buckets' WGRAD_FINALIZE stages kept on the main stream (since round 3 they run on the
+    # side stream, behind the weight gradients whose scratch they fold: none)
+    assert j == sum(1 for k, f in plan.bwd.ops if k == "WGRAD_FINALIZE" and not f.get("_flags", 0) & D.FLAG_SIDE)
     lnb = [f for k, f in plan.bwd.ops if k == "CHAN_LN_BWD"]
     assert sum(1 for f in lnb if f.get("DXIN") is not None) == 2 * (PRITHVI_SMALL["depth"] + PRITHVI_SMALL["decoder_depth"])
     # the proj / fc2 bias gradients come out of those stages: one CHANNEL_SUM per block less two
@@ -299,4 +300,5 @@ def test_no_main_stream_stage_overwrites_what_a_side_stream_stage_still_reads():
     check(PrithviSegmentationNet(cfg, backbone=bb)._make_plan(2, True, 0.0, True).bwd)
     unet = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.25] * 4))
     plan = unet._make_plan(2, 64, 64, True)
-    assert check(plan.bwd) == sum(1 for k, _ in plan.bwd.ops if k == "WGRAD_FINALIZE")      # nothing added for the U-Net
+    fin = [f for k, f in plan.bwd.ops if k == "WGRAD_FINALIZE"]
+    assert fin and all(f.get("_flags", 0) & D.FLAG_SIDE for f in fin) and check(plan.bwd) == 0      # no join at all in the U-Net's backward
