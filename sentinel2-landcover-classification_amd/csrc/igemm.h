@@ -36,6 +36,8 @@ void launch_splitk_reduce(const ConvP& p, hipStream_t st);
 
 // igemm_pc.hip: S2K_OK = launched, 1 = not one of its shapes (the caller takes the generic kernels), < 0 = error
 int launch_conv_pc(ConvP& p, hipStream_t st);
+// conv_dma.hip: prologue-free 1x1 contractions on the LDS-DMA ring kernel; same return convention
+int launch_conv_dma(ConvP& p, hipStream_t st);
 // conv_bf16.hip (bf16-mixed plans only: p.wtb set): same return convention
 int launch_conv_bf16(ConvP& p, hipStream_t st);
 

@@ -806,6 +806,13 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         p.R = p.XW = p.tiles_x = p.tiles_y = p.IR = p.IC = p.WS = p.CS = 0;
         p.n_tiles = p.n_mtiles = 0;
     }
+    {   // prologue-free 1x1 contractions the producer / consumer kernel leaves (short or deep reductions, few pixels): the LDS-DMA
+        // ring kernel of conv_dma.hip; 1 = not one of its shapes
+        const int rc = launch_conv_dma(p, st);
+        if (rc != 1) return rc;
+        p.n_tiles = p.n_mtiles = 0;
+        p.splits = 1;
+    }
     const int bm = pick_bm(p.M);
     if (pix) {
         // small problems (deep 8x8 / 16x16 maps): 64x64 tiles keep more CUs busy

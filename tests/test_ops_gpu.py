@@ -121,7 +121,7 @@ def test_mfma_lane_maps_exact():
 # CONV (implicit GEMM)
 # ---------------------------------------------------------------------------------------------------
 def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias, stats, beta=0, mode=0, flip=0,
-               strides=None, seed=0, tol=1e-4, yc=None, bf16=False):
+               strides=None, seed=0, tol=1e-4, yc=None, bf16=False, res=False, scratch=False, want_variant=None):
     """bf16: the stage carries FLAG_BF16 + the bf16 weight copy, must run on the bf16 MFMA kernels (csrc/conv_bf16.hip) and is
     compared with the oracle on bf16-ROUNDED operands (f32 products and sums): what is left is f32 summation order, so the
     tolerance stays 1e-4 - rounding of the operands is arithmetic the oracle states too, not kernel error."""
@@ -153,6 +153,12 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     st_ref = c.t("stats", (nrep, 2, M), "zeros", "f64") if stats else None
     outs = ["y"] + (["stats"] if stats else [])
     extra = {}
+    if res:
+        extra["RES"] = c.t("res", (B, YC, Ho, Wo))
+    if scratch:
+        extra["SCRATCH"] = c.t("scratch", (8 * B * YC * Ho * Wo,), "nan")
+    if want_variant is not None:
+        extra["want_variant"] = want_variant
     if bf16:
         # An activated value within an ulp of a bf16 rounding boundary may round to the other neighbour on the GPU (its SiLU is
         # v_exp + v_rcp, its BatchNorm affine one fma): one operand then differs by 2^-8 relative.  Over a long reduction a few
@@ -161,7 +167,7 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
         if pro1 or pro2:
             tol = max(tol, 1e-3)
         pre, wp, MP, wp16 = c.pack(wt, M, Ct, T, sm, sk, st, flip, bf16=True)
-        extra = dict(WTB=wp16, _flags=D.FLAG_BF16, want_variant=2)
+        extra.update(WTB=wp16, _flags=D.FLAG_BF16, want_variant=2)
     else:
         pre, wp, MP = c.pack(wt, M, Ct, T, sm, sk, st, flip)
     c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
@@ -309,6 +315,24 @@ def test_conv3x3(B, C1, C2, H, W, M, pro1, pro2):
 def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
     """shapes that take the producer / consumer kernels (csrc/igemm_pc.hip): >= 192 tiles of 128 pixels"""
     _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, pro, 0, False, bias=bias, stats=stats, beta=beta)
+
+
+@pytest.mark.parametrize("B,C1,H,W,M,bias,stats,beta,res,scratch", [
+    (32, 40, 16, 16, 240, False, True, 0, False, False),     # short reduction (K = 40 = two stages + a half stage), 256 x 128 tiles, statistics
+    (8, 24, 32, 32, 144, False, True, 0, False, False),      # K = 24 (one stage + a half stage), M = 144 on 192-row tiles
+    (32, 176, 16, 16, 1056, False, True, 0, False, True),    # the 16x16 expand conv: 192 x 64 tiles in three whole rounds, no split (K = 176 < 8 chunks x 4)
+    (32, 1824, 8, 8, 304, False, False, 1, False, True),     # deep data gradient over 2,048 pixels: 320-row tiles are refused with an accumulate -> narrower tile, K cut, prefetched old values
+    (32, 1824, 8, 8, 304, False, True, 0, False, True),      # the same layer forward-shaped: 320 x 64 tiles, K cut 8 ways (balanced partition), statistics in the reduce tail
+    (32, 3072, 8, 8, 512, True, False, 0, False, True),      # 256-row tiles x 2, K cut, bias applied by the reduce tail
+    (5, 100, 10, 10, 72, True, True, 0, False, False),       # HW = 100: tiles straddle images, ragged last tile, K tail of 4 channels
+    (3, 52, 1, 52, 96, True, False, 1, True, False),         # a Linear over 52-token rows (H = 1): bias + residual + accumulate, all prefetched
+    (2, 768, 1, 200, 768, True, False, 0, True, True),       # ViT proj Linear: residual stream, few tokens -> K cut
+    (6, 17, 4, 4, 48, False, True, 0, False, False),         # 4x4 maps (16 pixels per image), K = 17
+    (2, 64, 64, 64, 40, False, False, 1, False, False),      # M = 40 on a 64-row tile, accumulate
+])
+def test_conv1x1_dma_ring(B, C1, H, W, M, bias, stats, beta, res, scratch):
+    """prologue-free 1x1 contractions that the producer / consumer kernel leaves: the LDS-DMA ring kernel (csrc/conv_dma.hip)"""
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, 0, 0, False, bias=bias, stats=stats, beta=beta, res=res, scratch=scratch, want_variant=3)
 
 
 @pytest.mark.parametrize("B,C1,C2,H,W,M,pro,beta", [

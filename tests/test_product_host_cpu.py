@@ -155,3 +155,40 @@ def test_standalone_efficientnet_accepts_foreign_state_dict_like_the_reference_s
         own = {k: torch.full_like(v, 0.5) if v.dtype.is_floating_point else v for k, v in m.state_dict().items()}
         m.load_state_dict(own)
         assert float(m.fc[3].weight.min()) == 0.5 and float(m._flat_params[: m.stem[0].weight.numel()].max()) == 0.5
+
+
+def test_classification_bias_prior_equals_reference():
+    """`initialize_classification_layer_bias` (reference utils.py:174-188) against the reference's own output
+    (tests/golden/make_golden_r4.py): the two-class log(p1 / p0) fill, non-uniform log priors on Conv2d and Linear, and the
+    reference's error behaviour - its sum check runs on the eps-shifted float32 distribution, so it refuses a valid 10-class
+    ramp and an unnormalised one alike; the drop-in refuses exactly the same inputs and leaves the bias untouched."""
+    from torch import nn
+
+    from s2lc_amd.utils import initialize_classification_layer_bias
+
+    g = load("class_bias_prior.npz")
+    names = sorted({k.split(".")[0] for k in g.files})
+    assert {"two_class_conv2", "nonuniform4_conv", "ramp10_conv", "not_normalised"} <= set(names)
+    for name in names:
+        dist = [float(v) for v in g[f"{name}.dist"]]
+        is_linear, n = (int(v) for v in g[f"{name}.kind"])
+        torch.manual_seed(0)
+        layer = nn.Linear(16, n) if is_linear else nn.Conv2d({2: 8, 1: 8, 3: 8}.get(n, 32), n, 1)
+        before = layer.bias.detach().clone()
+        if int(g[f"{name}.raised"][0]):
+            with pytest.raises(AssertionError):
+                initialize_classification_layer_bias(layer, dist)
+            assert torch.equal(layer.bias.detach(), before), name
+        else:
+            initialize_classification_layer_bias(layer, dist)
+            assert np.array_equal(layer.bias.detach().numpy(), g[f"{name}.bias"]), name       # bit-identical
+        assert layer.bias.requires_grad
+
+
+def test_unet_classifier_bias_follows_the_class_distribution():
+    """the model constructor applies the prior to out_conv1x1 (reference efficientnet_unet.py:131-134)"""
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+    g = load("class_bias_prior.npz")
+    m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.5, 0.3, 0.15, 0.05]))
+    assert np.array_equal(m.out_conv1x1.bias.detach().cpu().numpy(), g["nonuniform4_conv.bias"])

@@ -25,19 +25,31 @@ DEV = torch.device("cuda:0")
 NCLS = 4
 
 
+# Pinned counts of class-mask pixels that may differ from the reference's stored mask, per fixture ("pin the count").
+# north_star asks for bit-exact masks; every EVAL-mode fixture is (0 pixels).  In TRAIN mode the batch statistics are summed in a
+# different fp32 order than the CPU reference's, logits move by ~2e-5 of 1e-3 allowed, and a pixel whose top two logits are closer
+# than that can flip: 6 of 524,288 on the headline training fixture, and the count is not run-to-run stable (float / f64 atomics in
+# the statistics), so the bound is 8.  A differing pixel must ALSO have a reference top-2 margin inside fp32 noise (below).
+MASK_DIFF_MAX = {"b5_256x13_train_bs8": 8}
+MASK_DIFF_DEFAULT = 4
+
+
 def _mask_report(mask_gpu: np.ndarray, mask_ref: np.ndarray, logits_ref: torch.Tensor, record_property, tag: str) -> str:
-    """Exact equality of the class masks is RECORDED (junit property + returned text for assertion messages) — and where it
-    does not hold, every differing pixel must be one whose reference top-2 margin is inside fp32 noise."""
+    """Exact equality of the class masks is RECORDED (junit property + returned text for assertion messages) - and where it
+    does not hold, the number of differing pixels is bounded by the pinned count of the fixture AND every differing pixel must be
+    one whose reference top-2 margin is inside fp32 noise."""
     diff = mask_gpu != mask_ref
     n = int(diff.sum())
-    msg = f"{tag}: class mask bit-exact vs the reference: {n == 0} ({n} of {mask_ref.size} pixels differ)"
+    bound = MASK_DIFF_MAX.get(tag, MASK_DIFF_DEFAULT)
+    msg = f"{tag}: class mask bit-exact vs the reference: {n == 0} ({n} of {mask_ref.size} pixels differ; pinned bound {bound})"
     record_property(f"mask_exact:{tag}", n == 0)
     record_property(f"mask_diff_pixels:{tag}", n)
     print(msg)
+    assert n <= bound, msg
     if n:
         top2 = logits_ref.topk(2, dim=1).values
         margin = (top2[:, 0] - top2[:, 1]).numpy()
-        assert diff.mean() < 1e-4 and margin[diff].max() < 1e-4 * max(1.0, float(logits_ref.abs().max())), \
+        assert margin[diff].max() < 1e-4 * max(1.0, float(logits_ref.abs().max())), \
             msg + f"; largest reference margin at a differing pixel {margin[diff].max():.3e}"
     return msg
 

@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--H", type=int, default=64)
     ap.add_argument("--pro", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rep", type=int, default=20)
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--nostats", action="store_true")
+    ap.add_argument("--beta", action="store_true", help="conv: accumulate into Y (a data gradient on top of an existing one)")
     ap.add_argument("--scratch", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS check: the chip holds a higher clock on trivial data)")
     ap.add_argument("--N", type=int, default=0, help="conv1: tokens per image (H=1, W=N) instead of an HxH map")
@@ -79,23 +81,40 @@ def main():
         prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st,
                  SCRATCH=scr, B=B, C1=C,
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
-                 W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=0, YC=M, NREP=D.stats_replicas(M),
+                 W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(a.beta), YC=M, NREP=D.stats_replicas(M),
                  **({"_flags": D.FLAG_BF16, "WTB": ar.alloc("w16", (KP * T * MP // 2,))} if a.bf16 else {}))
         flops = 2.0 * M * C * T * B * H * Wd
     buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * (0.0 if a.zeros else 0.5)).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)
     packed = prog.pack()
     st_ = torch.cuda.current_stream().cuda_stream
+    import numpy as np
+    R = a.rep                       # the stage R times in ONE program: back-to-back launches from the C loop (a Python call per launch
+    rep = np.concatenate([packed] * R)   # costs ~10 us of host time and hid every kernel shorter than that)
     for _ in range(3):
-        _lib.run(packed, bases, st_)
+        _lib.run(rep, bases, st_)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(a.iters):
-        _lib.run(packed, bases, st_)
+        _lib.run(rep, bases, st_)
+    e1.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.iters
-    print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s")
+    dt = e0.elapsed_time(e1) * 1e-3 / (a.iters * R)
+    ms_ev, var = _lib.profile_variants(packed, bases, st_)     # HIP-event time of the stage alone + the kernel family it took
+    fam = ("generic", "producer/consumer", "bf16", "dma-ring")[int(var[-1])]
+    print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s   [{fam}; events: {float(ms_ev[-1]) * 1e3:.1f} us]")
     L = _lib.lib()
+    if hasattr(L, "s2k_debug_dma_counters") and fam == "dma-ring":     # tuning build: in-kernel stamps of the LDS-DMA ring kernel
+        import ctypes
+        out = (ctypes.c_ulonglong * 8)()
+        L.s2k_debug_dma_counters(out, 1)
+        _lib.run(packed, bases, st_)
+        torch.cuda.synchronize()
+        L.s2k_debug_dma_counters(out, 1)
+        n = max(out[6], 1)
+        print(f"   per wave ({n} waves, {out[7] / n:.1f} stages): life {out[0] / n:.0f} cyc = set-up {out[1] / n:.0f} + wait/barrier {out[2] / n:.0f} "
+              f"+ issue {out[3] / n:.0f} + reads/MFMA {out[4] / n:.0f} + epilogue {out[5] / n:.0f}  (100 MHz ticks x clock ratio)")
     if hasattr(L, "s2k_debug_wg_counters"):        # tuning build: in-kernel stamps of the producer / consumer wgrad
         import ctypes
         out = (ctypes.c_ulonglong * 8)()
