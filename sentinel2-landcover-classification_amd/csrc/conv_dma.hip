@@ -397,6 +397,12 @@ int launch_conv_dma(ConvP& p, hipStream_t st) {
     if (p.mode != S2K_MODE_CONV || p.KH != 1 || p.KW != 1 || p.S != 1 || p.C2 != 0 || p.gate1 || p.pro1 != S2K_PRO_NONE || p.x1_bf16) return 1;
     if ((p.HW & 3) || p.HO != p.H || p.WO != p.W) return 1;
     if (p.M < 40) return 1;                                   // thin layers at full resolution: the wide-pixel tiles of igemm.hip
+    // Where this kernel is used (rocprofv3 kernel durations against the kernels it replaces, profiles/r04_dma_ab.md): the 8x8 and
+    // 16x16 maps' deep or wide layers - 128 x 768 (25 vs 34 us with the split-K tail), 768 x 176 (32 vs 37), 1056 x 176 (49 vs 52),
+    // 768 x 128 (26 vs 28), 304 x 1824 (41 vs 44), 512 x 2048 (59 vs 63).  On the larger maps the short reductions (240 x 40 at
+    // 64x64, 384 x 64 at 32x32, 40 x 240) tie or lose by 5 - 20 %: they are bound by the serial epilogue of a write-heavy tile,
+    // which one workgroup per CU cannot hide, so they stay on the generic kernel (two workgroups per CU).  S2K_CONV_DMA=2: everything.
+    if (enabled != 2 && !p.force_dma && !(p.Ntot <= 8192 && (p.Ctot >= 512 || p.M >= 768))) return 1;
     const int nchunks = cdiv(p.Ctot, 16);
     // tile: BM = 64 * WM rows x BN = 64 * WN pixels.  Cost of a candidate = rounds of 256 workgroups x tile area (the matrix-core
     // time of the slowest CU), padding included; K is cut (<= 8 ways, >= 4 chunks per cut) only when the items do not fill the chip.

@@ -739,6 +739,7 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
     p.scratch = ref_ptr<float>(c, op.t[S2K_CONV_T_SCRATCH]);
     p.wtb = (op.flags & S2K_FLAG_BF16) ? ref_ptr<const void>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
+    p.force_dma = (op.flags & S2K_FLAG_DMA) ? 1 : 0;
     static const int cv_exp = tune_int("S2K_CV_EXP", 0);
     p.exp = cv_exp;
     const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb};
@@ -799,6 +800,12 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     if (p.x1_bf16) {   // planned only where conv_bf16.hip takes the stage (plan/bf16.py); the f32 kernels would read the halves as floats
         set_error("conv: X1_BF16 on a stage the bf16 1x1 kernel does not take (FLAG_BF16 missing or shape not in its list)");
         return S2K_EINVAL;
+    }
+    if (p.force_dma) {
+        const int rc = launch_conv_dma(p, st);
+        if (rc != 1) return rc;
+        p.n_tiles = p.n_mtiles = 0;
+        p.splits = 1;
     }
     {   // the prologue-light, MFMA-bound shapes run on the producer / consumer kernels (igemm_pc.hip); 1 = not one of theirs
         const int rc = launch_conv_pc(p, st);

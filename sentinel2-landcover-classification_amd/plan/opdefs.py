@@ -40,6 +40,8 @@ FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream
 # epilogue; csrc/conv_bf16.hip, wgrad_bf16.hip) when the shape is one of the bf16 kernels'; CONV then reads the bf16 weight
 # copy WTB that WEIGHT_PACK wrote (BF16_BASE).  Without the flag every stage computes in exact f32 (the parity path).
 FLAG_BF16 = 4
+FLAG_DMA = 8        # CONV: take the LDS-DMA ring kernel (csrc/conv_dma.hip) for every shape it supports, not only where its launcher's
+                    # measured routing rule sends a stage (tests cover all of its tiles this way; plans leave the choice to the launcher)
 
 # BN_FINALIZE folded into the first consumer of its {scale, shift} (a 5 us launch per BatchNorm otherwise: 126 per U-Net step):
 # the consumer's BNV becomes an OUTPUT computed from FSTATS (NREP replicas of {sum, sumsq}[C], FCOUNT elements per channel) with

@@ -159,6 +159,8 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
         extra["SCRATCH"] = c.t("scratch", (8 * B * YC * Ho * Wo,), "nan")
     if want_variant is not None:
         extra["want_variant"] = want_variant
+        if want_variant == 3:
+            extra["_flags"] = D.FLAG_DMA           # every tile of the LDS-DMA ring kernel, not only the shapes its routing rule takes
     if bf16:
         # An activated value within an ulp of a bf16 rounding boundary may round to the other neighbour on the GPU (its SiLU is
         # v_exp + v_rcp, its BatchNorm affine one fma): one operand then differs by 2^-8 relative.  Over a long reduction a few
@@ -321,7 +323,7 @@ def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
     (32, 40, 16, 16, 240, False, True, 0, False, False),     # short reduction (K = 40 = two stages + a half stage), 256 x 128 tiles, statistics
     (8, 24, 32, 32, 144, False, True, 0, False, False),      # K = 24 (one stage + a half stage), M = 144 on 192-row tiles
     (32, 176, 16, 16, 1056, False, True, 0, False, True),    # the 16x16 expand conv: 192 x 64 tiles in three whole rounds, no split (K = 176 < 8 chunks x 4)
-    (32, 1824, 8, 8, 304, False, False, 1, False, True),     # deep data gradient over 2,048 pixels: 320-row tiles are refused with an accumulate -> narrower tile, K cut, prefetched old values
+    (32, 1824, 8, 8, 304, False, False, 1, False, True),     # deep data gradient over 2,048 pixels: 320 x 64 tiles, K cut 8 ways, the accumulate is applied by the reduce tail
     (32, 1824, 8, 8, 304, False, True, 0, False, True),      # the same layer forward-shaped: 320 x 64 tiles, K cut 8 ways (balanced partition), statistics in the reduce tail
     (32, 3072, 8, 8, 512, True, False, 0, False, True),      # 256-row tiles x 2, K cut, bias applied by the reduce tail
     (5, 100, 10, 10, 72, True, True, 0, False, False),       # HW = 100: tiles straddle images, ragged last tile, K tail of 4 channels
@@ -329,6 +331,8 @@ def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
     (2, 768, 1, 200, 768, True, False, 0, True, True),       # ViT proj Linear: residual stream, few tokens -> K cut
     (6, 17, 4, 4, 48, False, True, 0, False, False),         # 4x4 maps (16 pixels per image), K = 17
     (2, 64, 64, 64, 40, False, False, 1, False, False),      # M = 40 on a 64-row tile, accumulate
+    (16, 768, 16, 16, 128, False, False, 1, False, False),   # 128 x 768 data gradient, accumulate prefetched during the last stage (32-channel stages)
+    (8, 256, 64, 64, 256, False, True, 0, False, False),     # a shape the producer / consumer kernel would take: many items per workgroup
 ])
 def test_conv1x1_dma_ring(B, C1, H, W, M, bias, stats, beta, res, scratch):
     """prologue-free 1x1 contractions that the producer / consumer kernel leaves: the LDS-DMA ring kernel (csrc/conv_dma.hip)"""
