@@ -39,6 +39,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (the ~5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 GUIDE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of the 8 TB/s spec)
+BUCKET_MB = None           # --bucket-mb (None: ddp.DEFAULT_BUCKET_MB)
 MAE_DP_LIMIT_S = float(os.environ.get("S2K_MAE_DP_LIMIT_S", "240"))   # watchdog of the N > 1 Prithvi leg (an extra key must never cost the headline line)
 # SURVEY §8d, whole-step denominators (fp32): the layer-wise roofline T = sum over layers of max(FLOP / peak, bytes / BW) of
 # efficientnet-unet-b5 13x256x256 is 0.464 ms per tile (pure MFMA 0.418, pure HBM 0.140) = 2,154 tiles/s per GPU; the Prithvi
@@ -352,11 +353,16 @@ def launch_ranks(n: int, argv: list[str], script: str | None = None) -> int:
         # rank 0's stdout is filtered (below): its one JSON line IS this program's output; the other ranks print nothing there
         procs.append(subprocess.Popen([sys.executable, script or str(Path(__file__).resolve())] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    worst = 0
-    try:
+    # rank 0's stdout is relayed by a reader THREAD while the main loop polls every rank: a rank k > 0 that dies early (out of
+    # memory, import error, RCCL init failure) leaves rank 0 inside init_process_group or a collective, its stdout open - a parent
+    # that first reads rank 0 to EOF would sit there until rank 0's own distributed timeout.  First non-zero exit: the
+    # other ranks are ended (exact PIDs, ours) and that code is returned; S2K_LAUNCH_DEADLINE_S (default 1500) bounds the whole run.
+    import threading
+
+    def relay(pipe):
         # libraries chat on stdout too (gloo: "[Gloo] Rank 0 is connected to ..."): only the result line goes to this program's
         # stdout, everything else rank 0 printed there is passed on through stderr
-        for ln in procs[0].stdout:
+        for ln in pipe:
             is_result = False
             if ln.lstrip().startswith("{"):
                 try:
@@ -365,13 +371,42 @@ def launch_ranks(n: int, argv: list[str], script: str | None = None) -> int:
                     pass
             (sys.stdout if is_result else sys.stderr).write(ln)
             (sys.stdout if is_result else sys.stderr).flush()
-        for p in procs:
-            rc = p.wait()
-            worst = rc if abs(rc) > abs(worst) else worst
-            if rc != 0:         # a dead rank leaves the others waiting in a collective: end them (exact PIDs, ours)
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
+
+    reader = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("S2K_LAUNCH_DEADLINE_S", "1500"))
+    worst = 0
+
+    def end_all():
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + 10.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print(f"bench.py: rank {r} exited with code {c}: ending the other ranks", file=sys.stderr, flush=True)
+                worst = c
+                end_all()
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                print("bench.py: ranks still running at the launch deadline (S2K_LAUNCH_DEADLINE_S): ending them", file=sys.stderr, flush=True)
+                worst = 124
+                end_all()
+                break
+            time.sleep(0.05)
+        reader.join(timeout=5.0)
     except BaseException:
         for q in procs:
             if q.poll() is None:
@@ -419,6 +454,7 @@ def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms:
     dt = time_steps(alone, iters, dist, dev) / iters
     bus = 2.0 * (world - 1) / world * nbytes / dt / 1e9
     return {"buckets": len(buckets), "bytes": nbytes, "bucket_bytes": [4 * (hi - lo) for lo, hi in buckets],
+            "bucket_mb_planned": round(float(getattr(ddp, "bucket_mb", 0.0)), 3),      # ddp.DEFAULT_BUCKET_MB / --bucket-mb: the planner's bucket size
             "ms_exposed": round(step_ms - noop_ms, 3), "ms_step_with_reducer": round(step_ms, 3), "ms_step_noop_hook": round(noop_ms, 3),
             "ms_alone": round(dt * 1e3, 3), "bus_gbps": round(bus, 1), "overlap_fraction": round(max(0.0, 1.0 - max(step_ms - noop_ms, 0.0) / (dt * 1e3)), 3),
             "backend": dist.get_backend(), "op": "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
@@ -597,9 +633,12 @@ def main() -> None:
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra key `bf16_mixed` (N = 1 only)")
     ap.add_argument("--mae-batch", type=int, default=64, help="per-GPU batch of the data-parallel Prithvi leg (N > 1 only)")
     ap.add_argument("--mae-steps", type=int, default=5, help="timed steps of the data-parallel Prithvi leg (N > 1 only)")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size of the data-parallel reducer (default: ddp.DEFAULT_BUCKET_MB = 32)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"],
                     help="arithmetic of the HEADLINE run (default f32, the parity path; bf16-mixed is otherwise reported as the extra key `bf16_mixed`)")
     args = ap.parse_args()
+    global BUCKET_MB
+    BUCKET_MB = args.bucket_mb
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # called as the driver calls it (`python bench.py --gpus N ...`): become the launcher; no GPU call before or after
@@ -643,7 +682,7 @@ def main() -> None:
     if world > 1:
         from s2lc_amd.ddp import FlatGradReducer
 
-        ddp = FlatGradReducer(model, dist)
+        ddp = FlatGradReducer(model, dist, bucket_mb=BUCKET_MB)
         ddp.broadcast_parameters(0)
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
@@ -792,16 +831,33 @@ def main() -> None:
         # an extra key must never cost the headline line: a watchdog prints the line without the key and ends the rank if the leg hangs
         import threading
 
+        # ONE place prints the result line, whichever thread gets there first (the timer thread could fire while the main
+        # thread was printing - two JSON lines; `line` was mutated without a lock)
+        out_lock = threading.Lock()
+        state = {"printed": False}
+
+        def print_line(mae_value):
+            with out_lock:
+                if state["printed"]:
+                    return False
+                state["printed"] = True
+                if rank == 0:
+                    line["prithvi_mae"] = mae_value
+                    print(json.dumps(line), flush=True)
+                return True
+
         def give_up():
-            if rank == 0:
-                line["prithvi_mae"] = {"error": f"the data-parallel Prithvi leg did not finish within {MAE_DP_LIMIT_S} s"}
-                print(json.dumps(line), flush=True)
-            print(f"bench.py: rank {rank}: data-parallel Prithvi leg timed out", file=sys.stderr, flush=True)
-            os._exit(0)
+            # the headline measurement is complete and valid: the line goes out with the error in place of the extra key, and the rank
+            # ends with 0 (a non-zero code would make the launcher discard a good headline because an EXTRA leg hung); the hang itself
+            # is on stderr and in the JSON
+            if print_line({"error": f"the data-parallel Prithvi leg did not finish within {MAE_DP_LIMIT_S} s"}):
+                print(f"bench.py: rank {rank}: data-parallel Prithvi leg timed out", file=sys.stderr, flush=True)
+                os._exit(0)
         dog = threading.Timer(MAE_DP_LIMIT_S, give_up)
         dog.daemon = True
         dist.barrier()          # (the other ranks waited here while rank 0 profiled)
         dog.start()
+        ok = 1
         try:
             del model, opt
             torch.cuda.empty_cache()
@@ -809,9 +865,28 @@ def main() -> None:
         except Exception as e:  # noqa: BLE001
             print(f"bench.py: rank {rank}: prithvi_mae (data-parallel) failed: {e!r}", file=sys.stderr, flush=True)
             mae = {"error": repr(e)[:300]}
+            ok = 0
+        # did EVERY rank finish the leg?  A rank whose leg raised has left its peers inside the leg's all-reduces: the agreement below
+        # (still under the watchdog - it is a collective too) then never completes on the failed rank, the watchdog prints its line
+        # and ends it; ranks that do agree on a failure skip the final barrier instead of hanging in it
+        all_ok = False
+        try:
+            t = torch.tensor([ok], device=dev, dtype=torch.int32) if dist.get_backend() == "nccl" else torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            all_ok = bool(int(t.item()))
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: agreement after the Prithvi leg failed: {e!r}", file=sys.stderr, flush=True)
         dog.cancel()
-        if rank == 0:
-            line["prithvi_mae"] = mae
+        if not all_ok and "error" not in (mae if isinstance(mae, dict) else {}):
+            mae = {"error": "the data-parallel Prithvi leg failed on another rank"}
+        print_line(mae)
+        if all_ok:
+            dist.barrier()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        return
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

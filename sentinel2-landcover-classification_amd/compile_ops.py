@@ -82,7 +82,7 @@ def _(x, anchor, handle, ncls, want_bwd, want_dx):
 @torch.library.custom_op("s2lc::unet_bwd", mutates_args=())
 def unet_bwd(dout: torch.Tensor, x: torch.Tensor, out: torch.Tensor, handle: int, want_dx: bool) -> tuple[torch.Tensor, torch.Tensor]:
     from . import _lib
-    from .engine import _stream
+    from .engine import _stream, run_backward
 
     module = _module(handle)
     st = _STATE.pop((handle, out.data_ptr()), None)
@@ -101,14 +101,8 @@ def unet_bwd(dout: torch.Tensor, x: torch.Tensor, out: torch.Tensor, handle: int
     grads.zero_()
     dx = torch.empty_like(x) if want_dx else x.new_empty((0,))
     bases = eng.bases(module, x.contiguous(), None, dout=dout, noise=noise, grads=grads, space=lease.space, dx=dx if want_dx else None)
-    hook = getattr(module, "_bwd_segment_hook", None)
     with torch.cuda.device(x.device):
-        if hook is None:
-            _lib.run(eng.bwd, bases, _stream(x.device))
-        else:
-            for (a, b, lo, hi) in eng.bwd_marks:
-                _lib.run(eng.bwd, bases, _stream(x.device), a, b)
-                hook(lo, hi, grads)
+        run_backward(module, eng.bwd_marks, len(eng.bwd), lambda a, b: _lib.run(eng.bwd, bases, _stream(x.device), a, b), grads, accumulate)
     lease.release()
     if accumulate:
         module._grad_buffer().add_(grads)

@@ -13,12 +13,32 @@ per-rank (the reference never enables SyncBatchNorm).
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
+
+# Bucket size (floats of the flat gradient buffer per all-reduce).  SURVEY.md 8e's arithmetic for the b5 U-Net: 40.3 M parameters =
+# 161 MB of gradients per step; a GPU has 7 xGMI links of ~153 GB/s, and RCCL's all-reduce over the fully connected mesh moves
+# 2 (N - 1) / N x bytes per GPU, so at the ~300 GB/s bus bandwidth a ring of 8 reaches the whole buffer costs ~0.95 ms of a 21 ms
+# backward - what matters is not bandwidth but (a) the fixed cost per collective (30 - 50 us each over 8 ranks: dozens of 25 MB
+# DDP-style buckets from hooks would cost more in launches than in bytes; 5 buckets cost 0.2 ms) and (b) the size of the LAST
+# bucket, which is the only one nothing hides: buckets close from the END of the flat buffer (the decoder, whose gradients are
+# final first) towards its start, so the last bucket holds the stem and the first encoder blocks - a few hundred KB in this
+# network whatever the nominal size.  32 MB (8 M floats) gives 5 buckets for the b5 U-Net and 13 for Prithvi-100M; the planner
+# takes any value (`FlatGradReducer(..., bucket_mb=...)`), bench.py reports the sizes that resulted in `allreduce.bucket_bytes`.
+DEFAULT_BUCKET_MB = 32.0
 
 
 class FlatGradReducer:
-    def __init__(self, module, dist, process_group=None):
+    def __init__(self, module, dist, process_group=None, bucket_mb: float | None = None):
         self.module, self.dist, self.group = module, dist, process_group
+        self.bucket_mb = float(DEFAULT_BUCKET_MB if bucket_mb is None else bucket_mb)
+        if self.bucket_mb <= 0:
+            raise ValueError("bucket_mb must be positive")
+        if bucket_mb is not None or not hasattr(module, "_bucket_floats"):
+            module._bucket_floats = max(1, int(self.bucket_mb * (1 << 20)) // 4)     # read by the planners (plan/unet_plan.py, vit_plan.py)
+        else:
+            self.bucket_mb = module._bucket_floats * 4 / (1 << 20)                      # set on the module beforehand
         self.world = dist.get_world_size(process_group)
         self.on_gpu = module._flat_params.is_cuda
         self.stream = torch.cuda.Stream(device=module._flat_params.device) if self.on_gpu else None
@@ -64,6 +84,19 @@ class FlatGradReducer:
         self.pending.clear()
         if self.on_gpu:
             torch.cuda.current_stream(self.module._flat_params.device).wait_stream(self.stream)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (torch DDP's `no_sync`): backwards inside the context add LOCAL gradients to the flat buffer and
+        start no collective; the first backward outside it adds its own and `finish()` then all-reduces the accumulated sum once
+        (one collective over the trainable range - the bucket overlap is given up for that step, the bytes are the same)."""
+        mod = self.module
+        prev = getattr(mod, "_no_sync", False)
+        mod._no_sync = True
+        try:
+            yield
+        finally:
+            mod._no_sync = prev
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Start from identical weights / BatchNorm buffers on every rank (DDP does this at construction)."""

@@ -159,18 +159,9 @@ class _UnetFunction(torch.autograd.Function):
         grads.zero_()
         dx = torch.empty_like(x) if eng.want_dx else None      # gradient w.r.t. the input (planned only when x.requires_grad)
         bases = eng.bases(module, x, None, dout=dout, noise=ctx.noise, grads=grads, space=lease.space, dx=dx)
-        hook = getattr(module, "_bwd_segment_hook", None)
         st = _stream(x.device)
         with torch.cuda.device(x.device):
-            if hook is None:
-                _lib.run(eng.bwd, bases, st)
-            else:
-                if accumulate:
-                    raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
-                _note_bucket_reduction(module)
-                for (a, b, lo, hi) in eng.bwd_marks:
-                    _lib.run(eng.bwd, bases, st, a, b)
-                    hook(lo, hi, grads)
+            run_backward(module, eng.bwd_marks, len(eng.bwd), lambda a, b: _lib.run(eng.bwd, bases, st, a, b), grads, accumulate)
         lease.release()     # stream-ordered: the next forward that takes this workspace is enqueued behind this backward
         if accumulate:
             module._grad_buffer().add_(grads)
@@ -191,6 +182,37 @@ def _note_bucket_reduction(module) -> None:
         raise RuntimeError("one backward mixes the fused forward with separately called methods under a data-parallel reducer: "
                            "call ddp.finish() between them, or use one of the two paths per step")
     module._bucket_reduced = True
+
+
+def run_backward(module, marks, n_ops: int, run_range, grads: torch.Tensor, accumulate: bool, lo_min: int = 0) -> None:
+    """Enqueue a whole-network backward program, with or without the data-parallel reducer (shared by the eager autograd nodes of
+    engine.py / vit_engine.py and the torch.compile custom ops, so their checks cannot drift apart).
+
+      no reducer, or inside `FlatGradReducer.no_sync()`   the program runs in one go; under no_sync the module is marked: its flat
+                                                          buffer holds LOCAL gradients that a later backward / finish() reduces
+      reducer, fresh gradients                            segment by segment, each final suffix bucket handed to the hook
+      reducer, accumulating onto live gradients           (gradient accumulation: the last micro-batch of a no_sync sequence) the
+                                                          program runs in one go into the scratch buffer, the caller adds it to the
+                                                          flat buffer, and finish() reduces the SUM in one collective - torch DDP's
+                                                          semantics: one reduction of the accumulated gradients per optimiser step
+    `run_range(a, b)` enqueues stages [a, b); `marks` = (a, b, lo, hi) backward segments (plan.bwd_param_marks)."""
+    hook = getattr(module, "_bwd_segment_hook", None)
+    if hook is None or getattr(module, "_no_sync", False):
+        if hook is not None:
+            module._method_grads_unreduced = True      # local gradients: reduced as a whole by finish()
+        run_range(0, n_ops)
+        return
+    if accumulate or getattr(module, "_method_grads_unreduced", False):
+        if getattr(module, "_bucket_reduced", False):
+            raise RuntimeError("a second backward accumulates onto gradients that were already all-reduced bucket by bucket in this "
+                               "step: run every micro-batch but the last inside `with reducer.no_sync():` (as with torch DDP)")
+        module._method_grads_unreduced = True
+        run_range(0, n_ops)
+        return
+    _note_bucket_reduction(module)
+    for (a, b, lo, hi) in marks:
+        run_range(a, b)
+        hook(max(lo, lo_min), hi, grads)
 
 
 def run_unet(module, x: torch.Tensor) -> torch.Tensor:

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import Workspace, WorkspacePool, _note_bucket_reduction
+from .engine import Workspace, WorkspacePool, run_backward
 
 _TORCH_DT = {"f32": torch.float32, "i64": torch.int64, "i32": torch.int32}
 
@@ -132,7 +132,6 @@ def vit_backward_raw(module, eng, lease, noise, out, x, gouts: dict):
     grads.zero_()
     dx = torch.empty_like(x) if plan.want_dx else None
     bases = eng.bases(module, x, out, noise, dout=dout, grads=grads, space=lease.space, dx=dx, dout_need=dout_need)
-    hook = getattr(module, "_bwd_segment_hook", None)
     st = _stream(x.device)
 
     def run_range(a, b):        # stages [a, b) of the backward program minus the skipped ranges
@@ -145,16 +144,7 @@ def vit_backward_raw(module, eng, lease, noise, out, x, gouts: dict):
             _lib.run(eng.bwd, bases, st, a, b)
 
     with torch.cuda.device(x.device):
-        if hook is None:
-            run_range(0, len(eng.bwd))
-        else:
-            if accumulate:
-                raise RuntimeError("gradient accumulation together with the data-parallel reducer is not supported")
-            _note_bucket_reduction(module)
-            lo_min = eng.plan.trainable_lo
-            for (a, b, lo, hi) in eng.bwd_marks:
-                run_range(a, b)
-                hook(max(lo, lo_min), hi, grads)
+        run_backward(module, eng.bwd_marks, len(eng.bwd), run_range, grads, accumulate, lo_min=eng.plan.trainable_lo)
     lease.release()
     if accumulate:
         module._grad_buffer().add_(grads)

@@ -53,6 +53,7 @@ def build_case(case: str, seed: int):
 def run_shard(model, case, x, y, noise, loss_fn, lo, hi, dev):
     """forward + backward of samples [lo, hi) of the global batch; returns the loss."""
     xs = x[lo:hi].to(dev)
+    case = case.replace("_accum", "")
     if case.startswith("unet"):
         model.train(case == "unet_train")
         model.drop_connect_noise = noise[:, lo:hi].contiguous() if case == "unet_train" else None
@@ -102,7 +103,14 @@ def main():
 
         model._bwd_segment_hook = hook
         per = x.shape[0] // world
-        loss = run_shard(model, case, x, y, noise, loss_fn, rank * per, (rank + 1) * per, dev)
+        if case.endswith("_accum"):
+            # gradient accumulation as with torch DDP: every micro-batch but the last inside no_sync(), ONE reduction of the sum
+            half = per // 2
+            with red.no_sync():
+                run_shard(model, case, x, y, noise, loss_fn, rank * per, rank * per + half, dev)
+            loss = run_shard(model, case, x, y, noise, loss_fn, rank * per + half, (rank + 1) * per, dev)
+        else:
+            loss = run_shard(model, case, x, y, noise, loss_fn, rank * per, (rank + 1) * per, dev)
         red.finish()
         torch.cuda.synchronize()
         torch.save(dict(rank=rank, backend=dist.get_backend(), grads=model._grad_buffer().detach().cpu(), w0=w0, loss=float(loss), calls=calls,

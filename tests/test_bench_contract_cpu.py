@@ -93,3 +93,30 @@ def test_launcher_starts_one_process_per_rank_and_returns_the_worst_exit_code(tm
     assert lines == ['{"metric": "m", "rank": 0}']              # rank 0's result line only: ONE JSON line on stdout
     assert "[Gloo] chatter from rank 0" in cap.err and "rank 1" not in cap.err
     assert bench.launch_ranks(3, ["7"], script=str(script)) == 7
+
+
+def test_launcher_ends_the_other_ranks_when_one_dies_early(tmp_path, capfd):
+    """a rank k > 0 that dies while rank 0 sits in a collective (here: sleeps with its stdout open) must not hang the
+    launcher until rank 0's own distributed timeout - the launcher polls every rank, ends the survivors and returns the code."""
+    import time
+
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "if r == 1:\n"
+                      "    sys.exit(9)\n"                      # dies at once (import error, out of memory, RCCL init failure ...)
+                      "print('rank', r, 'waiting in a collective', flush=True)\n"
+                      "time.sleep(120)\n")
+    t0 = time.monotonic()
+    assert bench.launch_ranks(3, [], script=str(script)) == 9
+    assert time.monotonic() - t0 < 30.0
+    assert "rank 1 exited with code 9" in capfd.readouterr().err
+
+
+def test_launcher_deadline(tmp_path, capfd, monkeypatch):
+    """every rank hangs: the overall deadline ends the run with a non-zero code"""
+    script = tmp_path / "rank.py"
+    script.write_text("import time\ntime.sleep(120)\n")
+    monkeypatch.setenv("S2K_LAUNCH_DEADLINE_S", "2")
+    assert bench.launch_ranks(2, [], script=str(script)) == 124
+    assert "launch deadline" in capfd.readouterr().err

@@ -106,3 +106,44 @@ def test_flat_grad_reducer_averages_like_ddp_gloo(tmp_path):
         assert torch.allclose(reduced, mean, rtol=1e-6, atol=1e-7)
         assert torch.allclose(reduced2, mean2, rtol=1e-6, atol=1e-7)
     assert torch.equal(out[0][3], out[1][3])  # identical weights after the broadcast
+
+
+def test_run_backward_modes_without_a_gpu():
+    """engine.run_backward, the one place that decides how a backward program meets the reducer (eager nodes and compiled ops):
+    no reducer -> one run; reducer -> segments + hook; no_sync -> one run, marked for finish(); accumulate -> one run, marked;
+    accumulate onto bucket-reduced gradients -> refused."""
+    from s2lc_amd.engine import run_backward
+
+    class M:
+        pass
+
+    marks = [(0, 2, 8, 16), (2, 5, 0, 8)]
+    m, ran = M(), []
+    run_backward(m, marks, 5, lambda a, b: ran.append((a, b)), None, accumulate=False)
+    assert ran == [(0, 5)] and not getattr(m, "_bucket_reduced", False)
+    m, ran, hooked = M(), [], []
+    m._bwd_segment_hook = lambda lo, hi, g: hooked.append((lo, hi))
+    run_backward(m, marks, 5, lambda a, b: ran.append((a, b)), None, accumulate=False, lo_min=4)
+    assert ran == [(0, 2), (2, 5)] and hooked == [(8, 16), (4, 8)] and m._bucket_reduced
+    m, ran, hooked = M(), [], []
+    m._bwd_segment_hook = lambda lo, hi, g: hooked.append((lo, hi))
+    m._no_sync = True
+    run_backward(m, marks, 5, lambda a, b: ran.append((a, b)), None, accumulate=False)
+    assert ran == [(0, 5)] and hooked == [] and m._method_grads_unreduced
+    m._no_sync = False
+    run_backward(m, marks, 5, lambda a, b: ran.append((a, b)), None, accumulate=True)      # the last micro-batch
+    assert ran == [(0, 5), (0, 5)] and hooked == [] and m._method_grads_unreduced
+    m2 = M()
+    m2._bwd_segment_hook = lambda lo, hi, g: None
+    m2._bucket_reduced = True
+    with pytest.raises(RuntimeError, match="no_sync"):
+        run_backward(m2, marks, 5, lambda a, b: None, None, accumulate=True)
+
+
+def test_reducer_bucket_size_is_a_planner_parameter():
+    """FlatGradReducer(bucket_mb=...) reaches the planner: smaller buckets -> more backward segments, same coverage"""
+    from s2lc_amd.plan.unet_plan import plan_unet
+
+    m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[.25] * 4))
+    n = [len(plan_unet(m.spec, 2, 64, 64, True, m._layout, bucket_floats=int(mb * (1 << 20)) // 4).bwd_param_marks) for mb in (32.0, 4.0, 1.0)]
+    assert n[0] <= n[1] <= n[2] and n[2] > n[0]
