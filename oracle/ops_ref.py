@@ -115,7 +115,7 @@ def op_weight_pack(m: Mem, o):
     tab = m.view(o["TABLE"], (o["N_ENTRIES"], 12), "i32")
     for src_off, dst_off, M, K, T, s_m, s_k, s_t, flip, MP, KP, _ in tab.tolist():
         src = m.view(m.addr(o["SRC"], src_off), (M, K, T), strides=(s_m, s_k, s_t))
-        if flip:
+        if flip & 1:        # (bit 1: a quad copy of the entry is wanted - a layout for csrc/conv_q4.hip, no arithmetic: not modelled)
             src = src.flip(2)
         dst = m.view(m.addr(o["DST"], dst_off), (KP, T, MP))
         dst.zero_()

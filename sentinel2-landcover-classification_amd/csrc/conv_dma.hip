@@ -28,41 +28,11 @@
 #include <algorithm>
 
 #include "common.h"
+#define DMA_DBG_SYM g_dma_dbg
+#include "dma.h"
 #include "igemm.h"
 
 namespace s2k {
-
-#if defined(S2K_TUNING) && defined(S2K_DMA_STAMPS)
-// stamp builds (-DS2K_TUNING -DS2K_DMA_STAMPS; the flush is thousands of same-address atomics: ~50 us per launch, so kernel
-// durations of such a build mean nothing): in-kernel stamps (s_memtime), summed over waves: {wave lifetime, set-up, wait + barrier, DMA issue, LDS reads + MFMAs,
-// epilogue, waves, stages}
-__device__ unsigned long long g_dma_dbg[8];
-#define DMA_STAMP() __builtin_amdgcn_s_memtime()
-#define DMA_DBG_ADD(i, v) do { dbg_acc[i] += (unsigned long long)(v); } while (0)
-#define DMA_DBG_DECL() unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define DMA_DBG_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) if (dbg_acc[i_]) atomicAdd(&g_dma_dbg[i_], dbg_acc[i_]); } while (0)
-#else
-#define DMA_STAMP() 0ull
-#define DMA_DBG_ADD(i, v) do { } while (0)
-#define DMA_DBG_DECL() do { } while (0)
-#define DMA_DBG_FLUSH() do { } while (0)
-#endif
-
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// One 1-KiB LDS-DMA piece: every lane moves 16 bytes from its own source offset to lds_dst + 16 * lane (lds_dst wave-uniform).
-// The builtin is named in the DEVICE pass only: with it in a kernel body the host pass of hipcc (ROCm 7.2) drops that kernel's
-// launch stub without a diagnostic (undefined symbol at load time).
-typedef __attribute__((address_space(3))) void lds_void;
-__device__ __forceinline__ void dma16(rsrc_t r, float* lds_dst, uint32_t voff, uint32_t soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
-#else
-    (void)r; (void)lds_dst; (void)voff; (void)soff;
-#endif
-}
 
 // PRE: the stage has a bias, a residual or accumulates into Y (separate instantiation: the prefetched values double the
 // accumulator registers, so only tiles of <= 5 accumulator tiles per wave carry it)
@@ -82,7 +52,7 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const ConvP p) {
     float* ct = smem + NST * ST_FL + (threadIdx.x >> 6) * CT_FL;       // this wave's image
 
 #ifdef S2K_TUNING
-    const int exp_flags = p.exp;       // S2K_CV_EXP ablations: 1 = no epilogue, 2 = no MFMAs, 4 = no DMA (results are garbage), 8 = no stores
+    const int exp_flags = p.exp;       // S2K_CV_EXP ablations: 1 = no epilogue, 2 = no MFMAs, 4 = no DMA, 8 = no stores, 16 = MFMA operands from registers (results are garbage)
 #else
     constexpr int exp_flags = 0;
 #endif
@@ -257,6 +227,13 @@ __global__ void __launch_bounds__(256) conv_dma_kernel(const ConvP p) {
             if (exp_flags & 2) continue;
             {
                 auto lds_ops = [&](const float* Ah, const float* Bh, int s, float (&a)[WM], float (&b)[WN]) {
+                    if (exp_flags & 16) {      // ablation: operands from registers (what the bare MFMA stream of this loop costs)
+#pragma unroll
+                        for (int rm = 0; rm < WM; ++rm) a[rm] = __builtin_bit_cast(float, (int)(s + rm + lane));
+#pragma unroll
+                        for (int rn = 0; rn < WN; ++rn) b[rn] = __builtin_bit_cast(float, (int)(s - rn + lane));
+                        return;
+                    }
 #pragma unroll
                     for (int rm = 0; rm < WM; ++rm) a[rm] = Ah[(2 * s) * BM + rm * 32];
 #pragma unroll

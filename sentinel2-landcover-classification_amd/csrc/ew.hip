@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(NTHREADS) weight_pack_kernel(const int* table,
         if ((int64_t)table[mid * 12 + 11] <= e0) lo = mid; else hi = mid - 1;
     }
     const int* r = table + lo * 12;
-    const int M = r[2], K = r[3], T = r[4], s_m = r[5], s_k = r[6], s_t = r[7], flip = r[8], MP = r[9];
+    const int M = r[2], K = r[3], T = r[4], s_m = r[5], s_k = r[6], s_t = r[7], flip = r[8] & 1, MP = r[9];     // (bit 1 of r[8]: quad copy wanted)
     const int u = (int)((e0 - r[11]) >> 12);
     const int mbs = MP >> 6;
     const int kk0 = (u / mbs) * 64, m0 = (u % mbs) * 64;
@@ -180,6 +180,33 @@ __global__ void __launch_bounds__(NTHREADS) weight_pack_bf16_kernel(const int* t
     dst16[(r[1] >> 3) + v] = w;                                   // ushort offset r[1] of the bf16 region = unit r[1] / 8
 }
 
+// f32 plans: a second copy of every 1x1 entry (T = 1) in the "quad" layout of csrc/conv_q4.hip, [KP/8][MP][8] with the eight input
+// channels of a group in the order (k & 1) * 4 + (k >> 1): the A operands of four consecutive MFMA k-steps (k = 2 s + lane / 32)
+// are then 16 contiguous bytes of LDS.  Reads the f32 pack the kernel above has just written (L2-hot, lanes along m), two 16-byte
+// stores per thread.
+__global__ void __launch_bounds__(NTHREADS) weight_pack_q4_kernel(const int* table, int n_entries, const float* packed, float* mirror) {
+    const int64_t e0 = (int64_t)blockIdx.x * (NTHREADS * 8);       // first f32 element of this block's units
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)table[mid * 12 + 11] <= e0) lo = mid; else hi = mid - 1;
+    }
+    const int* r = table + lo * 12;
+    if (r[4] != 1 || !(r[8] & 2)) return;                          // only the 1x1 entries a FLAG_Q4 stage reads (plan: mark_q4)
+    const int MP = r[9];
+    const int64_t v = ((e0 - r[11]) >> 3) + threadIdx.x;           // unit inside the entry: kg * MP + m
+    const int m = (int)(v % MP);
+    const int64_t kg = v / MP;
+    const float* sp = packed + r[1];
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = sp[(kg * 8 + q) * MP + m];
+    f32x4 w0 = {x[0], x[2], x[4], x[6]}, w1 = {x[1], x[3], x[5], x[7]};
+    f32x4* dp = reinterpret_cast<f32x4*>(mirror + r[1] + v * 8);
+    dp[0] = w0;
+    dp[1] = w1;
+}
+
 int launch_weight_pack(const S2kOp& op, const Ctx& c) {
     const int* table = ref_ptr<const int>(c, op.t[S2K_WEIGHT_PACK_T_TABLE]);
     const float* src = ref_ptr<const float>(c, op.t[S2K_WEIGHT_PACK_T_SRC]);
@@ -196,6 +223,12 @@ int launch_weight_pack(const S2kOp& op, const Ctx& c) {
         if (b16 & 15) { set_error("weight_pack: BF16_BASE must be a multiple of 16 bytes"); return S2K_EINVAL; }
         hipLaunchKernelGGL(weight_pack_bf16_kernel, dim3((unsigned)(total / (NTHREADS * 8))), dim3(NTHREADS), 0, c.stream, table, n,
                            dst, reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + b16));
+    }
+    const int64_t q4 = op.n[S2K_WEIGHT_PACK_N_Q4_BASE];
+    if (q4 > 0) {
+        if (q4 & 15) { set_error("weight_pack: Q4_BASE must be a multiple of 16 bytes"); return S2K_EINVAL; }
+        hipLaunchKernelGGL(weight_pack_q4_kernel, dim3((unsigned)(total / (NTHREADS * 8))), dim3(NTHREADS), 0, c.stream, table, n,
+                           dst, reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + q4));
     }
     return S2K_OK;
 }

@@ -14,6 +14,7 @@ struct ConvP {
     int force_dma;       // S2K_FLAG_DMA: the LDS-DMA ring kernel for every shape it supports (tests), not only where its routing rule sends a stage
     int exp;             // tuning builds only (S2K_CV_EXP): 1 = no epilogue (nothing stored), 2 = no MFMA loop
     const void* wtb;     // bf16 copy of the packed weights ([KP/8][T][MP][8], WEIGHT_PACK BF16_BASE) when the stage carries S2K_FLAG_BF16, else null
+    const float* wtq;    // f32 quad copy of the packed weights ([KP/8][MP][8], WEIGHT_PACK Q4_BASE) when the stage carries S2K_FLAG_Q4, else null
     float* y;
     float* scratch;      // split-K partial tiles [splits][Y layout] (deep, short-N layers), or null
     int splits, chunks_per_split;
@@ -39,6 +40,8 @@ void launch_splitk_reduce(const ConvP& p, hipStream_t st);
 int launch_conv_pc(ConvP& p, hipStream_t st);
 // conv_dma.hip: prologue-free 1x1 contractions on the LDS-DMA ring kernel; same return convention
 int launch_conv_dma(ConvP& p, hipStream_t st);
+// conv_q4.hip: prologue-free 1x1 contractions with the quad weight copy (p.wtq set); same return convention
+int launch_conv_q4(ConvP& p, hipStream_t st);
 // conv_bf16.hip (bf16-mixed plans only: p.wtb set): same return convention
 int launch_conv_bf16(ConvP& p, hipStream_t st);
 

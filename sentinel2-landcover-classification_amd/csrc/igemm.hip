@@ -739,10 +739,11 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.res = ref_ptr<const float>(c, op.t[S2K_CONV_T_RES]);
     p.scratch = ref_ptr<float>(c, op.t[S2K_CONV_T_SCRATCH]);
     p.wtb = (op.flags & S2K_FLAG_BF16) ? ref_ptr<const void>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
+    p.wtq = (!(op.flags & S2K_FLAG_BF16) && (op.flags & S2K_FLAG_Q4)) ? ref_ptr<const float>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
     p.force_dma = (op.flags & S2K_FLAG_DMA) ? 1 : 0;
     static const int cv_exp = tune_int("S2K_CV_EXP", 0);
     p.exp = cv_exp;
-    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb};
+    const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb, p.wtq};
     for (const void* q : ptrs)
         if (q == reinterpret_cast<const void*>(1)) { set_error("conv: tensor references a null base"); return S2K_EFAULT; }
     const int32_t* d = op.d;
@@ -801,7 +802,13 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
         set_error("conv: X1_BF16 on a stage the bf16 1x1 kernel does not take (FLAG_BF16 missing or shape not in its list)");
         return S2K_EINVAL;
     }
-    if (p.force_dma) {
+    if (p.wtq) {   // prologue-free 1x1 contractions with the quad weight copy: conv_q4.hip where its launcher's measured routing rule says
+                   // so (S2K_FLAG_DMA beside S2K_FLAG_Q4: every shape it supports - tests); 1 = not one of its shapes
+        const int rc = launch_conv_q4(p, st);
+        if (rc != 1) return rc;
+        p.n_tiles = p.n_mtiles = 0;
+        p.splits = 1;
+    } else if (p.force_dma) {
         const int rc = launch_conv_dma(p, st);
         if (rc != 1) return rc;
         p.n_tiles = p.n_mtiles = 0;

@@ -185,4 +185,107 @@ extern "C" int s2k_measure_mfma_lds(void* scratch, int reads, int waves_per_simd
     hipEventDestroy(e1);
     return S2K_OK;
 }
+
+// ---- what does one k-step of the conv kernels' MFMA loop cost (round 4)? ------------------------------------------------------------
+// A wave owns WM x WN accumulator tiles; per k-step it needs WM A operands and WN B operands and issues WM * WN MFMAs.
+// MODE 0: operands constant in registers; 1: operands produced by a VALU instruction per k-step; 2: operands from LDS, read DEPTH
+// k-steps ahead (register sets rotate), interleaved with the MFMAs as in conv_pc_kernel / conv_dma_kernel.  One wave per SIMD.
+namespace s2k {
+template <int WM, int WN, int MODE, int DEPTH>
+__global__ void __launch_bounds__(256) mfma_kstep_kernel(float* sink, unsigned long long* stamps, int iters) {
+    __shared__ float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int lane = threadIdx.x & 63;
+    const float* Aa = lds + (lane >> 5) * 256 + (lane & 31);
+    const float* Bb = lds + 8192 + (lane >> 5) * 128 + (lane & 31);
+    float a[DEPTH + 1][WM], b[DEPTH + 1][WN];
+#pragma unroll
+    for (int d = 0; d <= DEPTH; ++d) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[d][i] = 1.0f + 0.001f * (float)(lane + i + d);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[d][j] = 0.5f - 0.002f * (float)(lane + j + d);
+    }
+    auto fetch = [&](int s, float (&aa)[WM], float (&bb)[WN]) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) aa[i] = aa[i] * 1.0001f;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bb[j] = bb[j] * 0.9999f;
+        } else if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) aa[i] = Aa[(s & 15) * 512 + i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bb[j] = Bb[(s & 15) * 256 + j * 32];
+        }
+    };
+    auto mfmas = [&](const float (&aa)[WM], const float (&bb)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[i], bb[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+    };
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        // DEPTH + 1 k-steps per trip; set d is consumed while the set DEPTH steps later is being fetched
+#pragma unroll
+        for (int d = 0; d <= DEPTH; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(it * (DEPTH + 1) + d, a[(d + DEPTH) % (DEPTH + 1)], b[(d + DEPTH) % (DEPTH + 1)]);
+            mfmas(a[d], b[d]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 12345.678f) sink[0] = sum;
+    if (threadIdx.x == 0 && blockIdx.x == 0) stamps[0] = c1 - c0;
+}
+}  // namespace s2k
+
+// cycles per MFMA of the k-step loop (one wave per SIMD, every CU busy); wm x wn in {1x1, 2x1, 3x1, 2x2, 4x2}, mode 0..2, depth 1..3
+extern "C" int s2k_measure_mfma_kstep(void* scratch, int wm, int wn, int mode, int depth, double* cycles_per_mfma, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    const int blocks = prop.multiProcessorCount;
+    float* sink = static_cast<float*>(scratch);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + 4096);
+    const int iters = 2000;
+    bool ok = false;
+#define KSTEP(WMv, WNv, Mv, Dv) if (wm == WMv && wn == WNv && mode == Mv && depth == Dv) { ok = true; \
+        hipLaunchKernelGGL((mfma_kstep_kernel<WMv, WNv, Mv, Dv>), dim3(blocks), dim3(256), 0, st, sink, stamps, 100); \
+        hipLaunchKernelGGL((mfma_kstep_kernel<WMv, WNv, Mv, Dv>), dim3(blocks), dim3(256), 0, st, sink, stamps, iters); }
+#define KSTEP_T(WMv, WNv) KSTEP(WMv, WNv, 0, 1) KSTEP(WMv, WNv, 1, 1) KSTEP(WMv, WNv, 2, 1) KSTEP(WMv, WNv, 2, 2) KSTEP(WMv, WNv, 2, 3)
+    KSTEP_T(1, 1) KSTEP_T(2, 1) KSTEP_T(3, 1) KSTEP_T(2, 2) KSTEP_T(4, 2)
+#undef KSTEP_T
+#undef KSTEP
+    if (!ok) { set_error("measure_mfma_kstep: configuration not instantiated"); return S2K_EINVAL; }
+    if (hipStreamSynchronize(st) != hipSuccess) return S2K_EHIP;
+    unsigned long long h = 0;
+    (void)hipMemcpy(&h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    *cycles_per_mfma = (double)h / ((double)iters * (depth + 1) * wm * wn);
+    return S2K_OK;
+}
 #endif

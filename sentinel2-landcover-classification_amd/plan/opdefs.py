@@ -40,6 +40,8 @@ FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream
 # epilogue; csrc/conv_bf16.hip, wgrad_bf16.hip) when the shape is one of the bf16 kernels'; CONV then reads the bf16 weight
 # copy WTB that WEIGHT_PACK wrote (BF16_BASE).  Without the flag every stage computes in exact f32 (the parity path).
 FLAG_BF16 = 4
+FLAG_Q4 = 16        # CONV (f32 plans): WTB holds the f32 "quad" copy of WT that WEIGHT_PACK wrote (Q4_BASE): [KP / 8][MP][8] with the eight
+                    # channels of a group in the order (k & 1) * 4 + (k >> 1) - the A-operand layout of csrc/conv_q4.hip
 FLAG_DMA = 8        # CONV: take the LDS-DMA ring kernel (csrc/conv_dma.hip) for every shape it supports, not only where its launcher's
                     # measured routing rule sends a stage (tests cover all of its tiles this way; plans leave the choice to the launcher)
 
@@ -61,7 +63,9 @@ OPS: dict[str, tuple[list[str], list[str], list[str], list[str]]] = {
     # conv kernel copies A tiles with aligned 16-byte loads and needs no bounds checks.  Runs once per step.
     # BF16_BASE > 0 (bf16-mixed plans): additionally DST_bytes[BF16_BASE + 2*dst_off ...] receives every entry as bf16 in the
     # fragment order of the bf16 MFMA kernels, [KP/8][T][MP][8]: element ((kc/8 * T + tap) * MP + m) * 8 + kc % 8
-    "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL", "BF16_BASE"], ["N_ENTRIES"], []),
+    # Q4_BASE > 0 (f32 plans): additionally DST_bytes[Q4_BASE + 4*dst_off ...] receives every 1x1 entry (T = 1) in the quad layout
+    # [KP/8][MP][8]: element ((kc >> 3) * MP + m) * 8 + (kc & 1) * 4 + ((kc >> 1) & 3)   (csrc/conv_q4.hip; FLAG_Q4 stages read it as WTB)
+    "WEIGHT_PACK": (["TABLE", "SRC", "DST"], ["TOTAL", "BF16_BASE", "Q4_BASE"], ["N_ENTRIES"], []),
     # Implicit-GEMM convolution on f32 MFMA (fwd conv / convT fwd / conv dgrad / convT dgrad):
     #   Y[b][m][yo][xo] (+)= BIAS[m] + sum_{c,ky,kx} Wv[m][c][ky][kx] * Xpro[b][c][yo*S+ky-PT][xo*S+kx-PL]
     # with Wv[m][c][tap] = WT[m*W_SM + c*W_SK + (FLIP ? T-1-tap : tap)*W_ST] (the HIP kernel requires the

@@ -782,13 +782,21 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
     into bucketed segments (+ WGRAD_FINALIZE per bucket) and put the WEIGHT_PACK stages in front."""
     table = p.const_table
 
+    q4 = {"base": 0, "packs_end": 0}
+
     def pack_op(prog: Program, rows):
         if not rows:
             return
         total = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9]
+        extra = {"Q4_BASE": q4["base"]} if q4["base"] and any(r[8] & 2 for r in rows) else {}
         prog.ops.insert(0, ("WEIGHT_PACK", dict(TABLE=table(rows, 12), SRC=TRef(D.BASE["PARAMS"], 0, (layout.n_params,)),
-                                                DST=TRef(D.BASE["WPACK"], 0, (p.wpack.mark() // 4,)), TOTAL=total,
-                                                N_ENTRIES=len(rows))))
+                                                DST=TRef(D.BASE["WPACK"], 0, (q4["packs_end"] // 4,)), TOTAL=total,
+                                                N_ENTRIES=len(rows), **extra)))
+
+    def attach_q4():       # (once every CONV stage exists and before the pack tables are built)
+        q4["packs_end"] = p.wpack.mark()
+        if not getattr(p, "bf16", False):
+            q4["base"] = mark_q4(p, p.bwd if p.want_bwd else None)
 
     def attach_splitk_scratch():
         """One shared scratch region (stages run in stream order) for the 1x1 convs with few output pixels and a long
@@ -854,10 +862,13 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
                 f["_flags"] = D.FLAG_SIDE if finalize_on_side else D.FLAG_JOIN
         side_stream_hazards(p.bwd)
         n_before = len(p.bwd.ops)
+        attach_q4()
         pack_op(p.bwd, p.pack_rows["bwd"])
         if len(p.bwd.ops) > n_before:   # WEIGHT_PACK went in front
             segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]
         bwd = p.bwd
+    else:
+        attach_q4()
     pack_op(p.fwd, p.pack_rows["fwd"])
     attach_splitk_scratch()
     if getattr(p, "bf16", False):
@@ -902,6 +913,43 @@ def side_stream_hazards(prog: Program) -> int:
                     added += 1
                     break
     return added
+
+
+def q4_conv_ok(f: dict) -> bool:
+    """the stages csrc/conv_q4.hip takes: prologue-free 1x1 contractions over pixel quads (launch_conv_q4's shape list) where its
+    measured routing rule sends them - the large maps' short reductions / thin layers and the deepest 8x8 layers"""
+    if not (f["KH"] == 1 and f["KW"] == 1 and f["STRIDE"] == 1 and f["MODE"] == D.MODE_CONV and f["C2"] == 0 and f["PRO1"] == D.PRO_NONE
+            and f.get("GATE1") is None and (f["H"] * f["W"]) % 4 == 0 and f["M"] >= 24 and not f.get("X1_BF16", 0)):
+        return False
+    n, m, c = f["B"] * f["H"] * f["W"], f["M"], f["C1"]
+    return (n >= 32768 and m >= 40 and c < 256) or (n <= 8192 and m <= 512 and c >= 2048)
+
+
+def mark_q4(p: "_P", bwd) -> int:
+    """f32 plans, BEFORE the WEIGHT_PACK stages are emitted: the prologue-free 1x1 convs / Linears / data gradients that csrc/conv_q4.hip
+    takes carry FLAG_Q4 and read, as WTB, a second f32 copy of their weight in that kernel's quad layout, which WEIGHT_PACK writes
+    into a mirror region behind the packs (Q4_BASE; only the table rows marked here - flip bit 1 - are copied).  The arithmetic is
+    unchanged (same f32 values, same k order): the emulator keeps reading WT.  Returns Q4_BASE (0: no such stage)."""
+    if tune("S2K_Q4", "1") != "1":
+        return 0
+    base = (p.wpack.mark() + 255) // 256 * 256
+    offs = set()
+    for prog in (p.fwd, bwd):
+        if prog is None:
+            continue
+        for kind, f in prog.ops:
+            if kind == "CONV" and isinstance(f.get("WT"), TRef) and f["WT"].base == D.BASE["WPACK"] and f.get("WTB") is None and q4_conv_ok(f):
+                f["_flags"] = f.get("_flags", 0) | D.FLAG_Q4
+                f["WTB"] = TRef(D.BASE["WPACK"], base + f["WT"].off, f["WT"].shape, "f32", "q4:" + f["WT"].name)
+                offs.add(f["WT"].off // 4)
+    if not offs:
+        return 0
+    for rows in p.pack_rows.values():
+        for row in rows:
+            if row[1] in offs and row[4] == 1:
+                row[8] |= 2
+    p.wpack.top = 2 * base + 256
+    return base
 
 
 def mark_bf16(p: "_P", bwd) -> None:

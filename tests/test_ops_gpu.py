@@ -52,15 +52,19 @@ class Case:
         invstd = torch.rand(C, generator=self.gen) + 0.7
         return self.t(name, (4, C), torch.stack([scale, shift, mean, invstd]))
 
-    def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0, bf16=False):
+    def pack(self, wt, M, K, T, s_m, s_k, s_t, flip, src_elem_off=0, bf16=False, q4=False):
         """WEIGHT_PACK record for one weight tensor living in this arena; returns (pre-op, packed ref, MP) and, with bf16, the
         reference of the bf16 copy as a fourth element."""
         MP, KP = (M + 127) // 128 * 128, (K + 63) // 64 * 64
         dst = self.t(f"packed{len(self.items)}", (KP * T, MP), "nan")
-        row = [wt.off // 4 + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip, MP, KP, 0]
+        row = [wt.off // 4 + src_elem_off, dst.off // 4, M, K, T, s_m, s_k, s_t, flip | (2 if q4 else 0), MP, KP, 0]
         tab = self.t(f"packtab{len(self.items)}", (1, 12), torch.tensor([row]), "i32")
         zero = self.arena.alloc("zero", (1,))  # offsets in the table are relative to SRC / DST = arena start
         fields = dict(TABLE=tab, SRC=zero.at(-(zero.off // 4)), DST=zero.at(-(zero.off // 4)), TOTAL=KP * T * MP, N_ENTRIES=1)
+        if q4:      # the f32 quad copy of a 1x1 entry lives at DST bytes + Q4_BASE + 4 * dst_off
+            dstq = self.t(f"packedq_{len(self.items)}", (KP * T, MP), "nan")
+            fields["Q4_BASE"] = dstq.off - dst.off
+            return ("WEIGHT_PACK", fields), dst, MP, dstq
         if not bf16:
             return ("WEIGHT_PACK", fields), dst, MP
         # the bf16 copy of an entry lives at DST bytes + BF16_BASE + 2 * dst_off (plan: a mirror region behind the f32 packs)
@@ -170,6 +174,10 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
             tol = max(tol, 1e-3)
         pre, wp, MP, wp16 = c.pack(wt, M, Ct, T, sm, sk, st, flip, bf16=True)
         extra.update(WTB=wp16, _flags=D.FLAG_BF16, want_variant=2)
+    elif want_variant == 4:
+        # f32 quad copy of the weights (WEIGHT_PACK Q4_BASE), read by csrc/conv_q4.hip as WTB
+        pre, wp, MP, wpq = c.pack(wt, M, Ct, T, sm, sk, st, flip, q4=True)
+        extra.update(WTB=wpq, _flags=D.FLAG_Q4 | D.FLAG_DMA)      # (+ FLAG_DMA: every supported shape, not only the launcher's routing rule)
     else:
         pre, wp, MP = c.pack(wt, M, Ct, T, sm, sk, st, flip)
     c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
@@ -337,6 +345,29 @@ def test_conv1x1_producer_consumer(B, C1, H, W, M, pro, bias, stats, beta):
 def test_conv1x1_dma_ring(B, C1, H, W, M, bias, stats, beta, res, scratch):
     """prologue-free 1x1 contractions that the producer / consumer kernel leaves: the LDS-DMA ring kernel (csrc/conv_dma.hip)"""
     _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, 0, 0, False, bias=bias, stats=stats, beta=beta, res=res, scratch=scratch, want_variant=3)
+
+
+@pytest.mark.parametrize("B,C1,H,W,M,bias,stats,beta,res,scratch", [
+    (32, 40, 16, 16, 240, False, True, 0, False, False),     # K = 40 (two stages + a k-group of 8), 256 x 128 tile, statistics
+    (8, 24, 32, 32, 144, False, True, 0, False, False),      # K = 24, M = 144
+    (32, 176, 16, 16, 1056, False, True, 0, False, True),    # the 16x16 expand conv
+    (32, 1824, 8, 8, 304, False, False, 1, False, True),     # deep data gradient over 2,048 pixels: K cut, accumulate in the reduce tail
+    (32, 1824, 8, 8, 304, False, True, 0, False, True),      # forward-shaped, statistics in the reduce tail
+    (32, 3072, 8, 8, 512, True, False, 0, False, True),      # bias applied by the reduce tail
+    (5, 100, 10, 10, 72, True, True, 0, False, False),       # HW = 100: tiles straddle images, ragged last tile, K tail of 4 channels, bias (prefetched) + statistics
+    (3, 52, 1, 52, 96, True, False, 1, True, False),         # a Linear over 52-token rows (H = 1): bias + residual + accumulate, all prefetched
+    (2, 768, 1, 200, 768, True, False, 0, True, True),       # ViT proj Linear: residual stream
+    (6, 17, 4, 4, 48, False, True, 0, False, False),         # 4x4 maps (16 pixels per image), K = 17
+    (2, 64, 64, 64, 40, False, False, 1, False, False),      # M = 40, accumulate
+    (16, 768, 16, 16, 128, False, False, 1, False, False),   # 128 x 768 data gradient, accumulate prefetched
+    (8, 256, 64, 64, 256, False, True, 0, False, False),     # many items per workgroup
+    (64, 768, 1, 52, 2304, True, False, 0, False, False),    # the MAE encoder's qkv Linear: 3,328 tokens
+    (3, 33, 12, 12, 24, False, True, 0, False, False),       # M = 24 (smallest), K = 33
+])
+def test_conv1x1_quad(B, C1, H, W, M, bias, stats, beta, res, scratch):
+    """prologue-free 1x1 contractions on the quad-layout kernel (csrc/conv_q4.hip): the weights' quad copy from WEIGHT_PACK, pixel-quad
+    B operands, 16-byte stores straight from the accumulators"""
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, 0, 0, False, bias=bias, stats=stats, beta=beta, res=res, scratch=scratch, want_variant=4)
 
 
 @pytest.mark.parametrize("B,C1,C2,H,W,M,pro,beta", [

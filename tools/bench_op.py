@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--nostats", action="store_true")
+    ap.add_argument("--q4", action="store_true", help="conv: FLAG_Q4 + the quad weight copy (csrc/conv_q4.hip)")
+    ap.add_argument("--dma", action="store_true", help="conv: FLAG_DMA (the LDS-DMA ring kernel wherever it supports the shape)")
+    ap.add_argument("--bias", action="store_true")
     ap.add_argument("--beta", action="store_true", help="conv: accumulate into Y (a data gradient on top of an existing one)")
     ap.add_argument("--scratch", action="store_true")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS check: the chip holds a higher clock on trivial data)")
@@ -78,11 +81,12 @@ def main():
         scr = ar.alloc("scr", (8 * B * M * H * Wd,)) if a.scratch else None
         MP, KP = (M + 127) // 128 * 128, (C + 63) // 64 * 64
         W = ar.alloc("w", (KP * T, MP)); st = ar.alloc("st", (D.stats_replicas(M), 2, M), "f64")
-        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=None, Y=Y, STATS=None if a.nostats else st,
+        flg = (D.FLAG_BF16 if a.bf16 else 0) | (D.FLAG_DMA if a.dma else 0) | ((D.FLAG_Q4 | D.FLAG_DMA) if a.q4 else 0)
+        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=ar.alloc("bias", (M,)) if a.bias else None, Y=Y, STATS=None if a.nostats else st,
                  SCRATCH=scr, B=B, C1=C,
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(a.beta), YC=M, NREP=D.stats_replicas(M),
-                 **({"_flags": D.FLAG_BF16, "WTB": ar.alloc("w16", (KP * T * MP // 2,))} if a.bf16 else {}))
+                 _flags=flg, **({"WTB": ar.alloc("w16", (KP * T * MP // 2,))} if a.bf16 else ({"WTB": ar.alloc("wq", (KP * T, MP))} if a.q4 else {})))
         flops = 2.0 * M * C * T * B * H * Wd
     buf = (torch.randn((ar.top + 4096) // 4, device="cuda") * (0.0 if a.zeros else 0.5)).view(torch.uint8)
     bases = _lib.Bases().set("WS", buf)
@@ -102,16 +106,17 @@ def main():
     torch.cuda.synchronize()
     dt = e0.elapsed_time(e1) * 1e-3 / (a.iters * R)
     ms_ev, var = _lib.profile_variants(packed, bases, st_)     # HIP-event time of the stage alone + the kernel family it took
-    fam = ("generic", "producer/consumer", "bf16", "dma-ring")[int(var[-1])]
+    fam = ("generic", "producer/consumer", "bf16", "dma-ring", "quad")[int(var[-1])]
     print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s   [{fam}; events: {float(ms_ev[-1]) * 1e3:.1f} us]")
     L = _lib.lib()
-    if hasattr(L, "s2k_debug_dma_counters") and fam == "dma-ring":     # tuning build: in-kernel stamps of the LDS-DMA ring kernel
+    if hasattr(L, "s2k_debug_dma_counters") and fam in ("dma-ring", "quad"):     # tuning build: in-kernel stamps of the LDS-DMA ring kernel
         import ctypes
         out = (ctypes.c_ulonglong * 8)()
-        L.s2k_debug_dma_counters(out, 1)
+        read = L.s2k_debug_q4_counters if fam == "quad" else L.s2k_debug_dma_counters
+        read(out, 1)
         _lib.run(packed, bases, st_)
         torch.cuda.synchronize()
-        L.s2k_debug_dma_counters(out, 1)
+        read(out, 1)
         n = max(out[6], 1)
         print(f"   per wave ({n} waves, {out[7] / n:.1f} stages): life {out[0] / n:.0f} cyc = set-up {out[1] / n:.0f} + wait/barrier {out[2] / n:.0f} "
               f"+ issue {out[3] / n:.0f} + reads/MFMA {out[4] / n:.0f} + epilogue {out[5] / n:.0f}  (100 MHz ticks x clock ratio)")

@@ -52,14 +52,14 @@ def main():
                 fl = 2.0 * g["M"] * (g["C1"] + g["C2"]) * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
                 gate = int(rec["t"][D.slot("CONV", "GATE1")[1]]) >= 0
                 desc = (f"M={g['M']:5d} C={g['C1']}+{g['C2']} k{g['KH']} s{g['STRIDE']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PRO1']}{g['PRO2']}"
-                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16')[var[i]]}")
+                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16', 'DMA', 'Q4')[var[i]]}")
                 by = 4.0 * (g["B"] * (g["C1"] + g["C2"]) * g["H"] * g["W"] + g["B"] * g["M"] * g["HO"] * g["WO"])
             elif kind == "WGRAD":
                 g = {k: int(d[D.slot("WGRAD", k)[1]]) for k in ("B", "M", "C", "KH", "HO", "WO", "MODE", "PROP", "PROQ")}
                 fl = 2.0 * g["M"] * g["C"] * g["KH"] ** 2 * g["B"] * g["HO"] * g["WO"]
                 gate = int(rec["t"][D.slot("WGRAD", "GATEP")[1]]) >= 0 or int(rec["t"][D.slot("WGRAD", "GATEQ")[1]]) >= 0
                 desc = (f"M={g['M']:5d} C={g['C']} k{g['KH']} {g['HO']}x{g['WO']} mode{g['MODE']} pro{g['PROP']}{g['PROQ']}"
-                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16')[var[i]]}")
+                        f"{' gate' if gate else ''} {('generic', 'PC', 'BF16', 'DMA', 'Q4')[var[i]]}")
                 by = 4.0 * g["B"] * g["HO"] * g["WO"] * (g["M"] + g["C"])
             else:
                 fl, desc, by = 0.0, " ".join(str(int(v)) for v in d[:11]), 0.0
