@@ -27,7 +27,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.v = None
         self._plist = None
         self._resumed_without_first = False      # a state dict written before per-parameter steps existed: every active parameter began at step 1
-        self._first = {}            # parameter index -> global step at which it first held a gradient (torch keeps state['step'] per parameter)
+        self._legacy_first = None                # "first_step" of a round-3 state dict (load_state_dict)
+        self._updates = {}          # parameter index -> number of steps in which it was UPDATED (torch keeps state['step'] per parameter
+                                    # and advances it only when the parameter holds a gradient: freeze / unfreeze / refreeze schedules)
         super().__init__([p for p in module.parameters()], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
     def add_param_group(self, param_group) -> None:
@@ -58,7 +60,11 @@ class FlatAdam(torch.optim.Optimizer):
                     ranges.append((start, end, cur))
                     start = None
                 continue
-            local = self.step_count - self._first.setdefault(i, 1 if self._resumed_without_first else self.step_count) + 1
+            if self._legacy_first is not None:      # state written before the per-parameter update count existed (see load_state_dict)
+                first = self._legacy_first.get(i, 1 if self._resumed_without_first else self.step_count)
+                self._updates.setdefault(i, self.step_count - first)
+            local = self._updates.get(i, 0) + 1
+            self._updates[i] = local
             if start is not None and local != cur:
                 ranges.append((start, end, cur))
                 start = None
@@ -68,6 +74,7 @@ class FlatAdam(torch.optim.Optimizer):
         if start is not None:
             ranges.append((start, end, cur))
         self._resumed_without_first = False
+        self._legacy_first = None
         return ranges
 
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -103,7 +110,7 @@ class FlatAdam(torch.optim.Optimizer):
     # -- checkpointing -------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
-        return {"state": {"step": self.step_count, "first_step": dict(self._first),
+        return {"state": {"step": self.step_count, "updates": dict(self._updates),
                           "exp_avg": None if self.m is None else self.m.detach().clone(),
                           "exp_avg_sq": None if self.v is None else self.v.detach().clone()},
                 "param_groups": groups, "layout_floats": int(self.module._flat_params.numel())}
@@ -113,8 +120,15 @@ class FlatAdam(torch.optim.Optimizer):
             raise ValueError("optimizer state belongs to a module with a different flat parameter layout")
         st = state["state"]
         self.step_count = int(st["step"])
-        self._first = {int(k): int(v) for k, v in st.get("first_step", {}).items()}
-        self._resumed_without_first = "first_step" not in st
+        # "updates": per-parameter count of steps taken (torch's state['step']).  Older checkpoints carry "first_step" (the global step
+        # at which a parameter first held a gradient: exact unless it was frozen again in between) or nothing (every parameter that
+        # holds a gradient at the first resumed step is assumed to have been updated in every step so far)
+        self._updates = {int(k): int(v) for k, v in st.get("updates", {}).items()}
+        self._legacy_first = None
+        self._resumed_without_first = False
+        if "updates" not in st:
+            self._legacy_first = {int(k): int(v) for k, v in st.get("first_step", {}).items()}
+            self._resumed_without_first = "first_step" not in st
         dev = self.module._flat_params.device
         self.m = None if st["exp_avg"] is None else st["exp_avg"].to(device=dev, dtype=torch.float32).clone()
         self.v = None if st["exp_avg_sq"] is None else st["exp_avg_sq"].to(device=dev, dtype=torch.float32).clone()

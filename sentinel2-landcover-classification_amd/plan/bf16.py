@@ -1,8 +1,14 @@
 """Which stages of a bf16-MIXED plan carry FLAG_BF16: the shape lists of csrc/conv_bf16.hip (launch_conv_bf16) and
 csrc/wgrad_bf16.hip (launch_wgrad_bf16), restated for the planner.  A flagged stage rounds its two MFMA operands to bf16 (f32
-accumulate); everything else of the plan computes in exact f32.  The native launchers fall back to the f32 kernels for a shape
-they do not take, so a mismatch between the two lists costs speed, never correctness; tests/test_bf16_mixed_gpu.py checks on
-real plans that every flagged stage ran on the bf16 kernels (s2k_program_profile_variants)."""
+accumulate); everything else of the plan computes in exact f32.  For a flagged stage whose operands are all f32 the native launchers
+fall back to the f32 kernels when they decline a shape (speed, not correctness).  That is NOT so once an operand is STORED as bf16
+(CONV.X1_BF16 / WGRAD.P_BF16, plan/unet_plan._dy_bf16_ok): only the bf16 kernels can read such a tensor, so a stage the native
+launcher declines - its shape list, but also its internal guards (the 2 GiB buffer-range check of wgrad_bf16.hip, the LDS / shape
+fall-backs of conv_bf16.hip's launch_b16) - FAILS the step with S2K_EINVAL rather than computing on garbage.  The planner
+therefore only stores dY as bf16 where these lists accept every reader; tests/test_bf16_mixed_gpu.py checks on real plans that
+every flagged stage ran on the bf16 kernels (s2k_program_profile_variants), and the method-path / encoder-only planners
+(plan_mae_encoder / _decoder / _loss, plan_random_masking, encoder_plan) do not implement the mode: they plan exact f32 whatever
+`precision` says (the fused forward is the path the mode is for)."""
 from __future__ import annotations
 
 from . import opdefs as D

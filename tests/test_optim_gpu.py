@@ -24,8 +24,9 @@ def test_unfrozen_parameters_start_their_own_bias_correction():
     g = torch.Generator(device=DEV).manual_seed(1)
     model._grad_buffer()
     model._publish_grads(model._no_grad_params)
-    for step in range(5):
-        unfreeze = step >= 3                     # the encoder joins at the fourth step
+    for step in range(7):
+        unfreeze = step in (3, 4, 6)             # the encoder joins at the fourth step, is frozen AGAIN at the sixth and rejoins at the
+                                                 # seventh: torch's state['step'] counts the steps a parameter was updated in
         for (n, p), r, fz in zip(model.named_parameters(), ref, frozen):
             if n in model._no_grad_params:
                 p.grad, r.grad = None, None
@@ -51,6 +52,9 @@ def test_unfrozen_parameters_start_their_own_bias_correction():
         assert e < 2e-6, (n, e)
     print(f"FlatAdam vs torch.optim.Adam after freeze -> unfreeze: worst relative difference {worst:.2e}")
     st = opt.state_dict()
-    assert st["state"]["step"] == 5 and len(set(st["state"]["first_step"].values())) == 2      # two cohorts of parameters
+    assert st["state"]["step"] == 7 and set(st["state"]["updates"].values()) == {7, 3}         # two cohorts of parameters: 7 and 3 updates
+    opt2 = FlatAdam(model, lr=1e-2, weight_decay=0.05)
+    opt2.load_state_dict(st)
+    assert opt2._updates == opt._updates and opt2.step_count == 7
     with pytest.raises(ValueError, match="one parameter group"):
         opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(1, device=DEV))]})
