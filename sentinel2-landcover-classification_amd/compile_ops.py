@@ -23,6 +23,18 @@ import torch
 
 _MODULES: "weakref.WeakValueDictionary[int, torch.nn.Module]" = weakref.WeakValueDictionary()
 _STATE: dict = {}          # (handle, data_ptr of the forward's output) -> (engine, lease, noise): consumed by the backward op
+MAX_PENDING = 4            # forwards of ONE module whose backward has not run yet (each pins a whole activation arena: 12.5 GB at b5 bs 32)
+
+
+def _park(handle: int, key, state) -> None:
+    """Keep a forward's workspace lease for its backward op.  Forwards whose backward never runs (inference under grad mode) are
+    bounded PER MODULE: beyond MAX_PENDING the module's own oldest pending forward is released - never another module's, whose
+    backward may still come (a global cap of 64 pinned up to 64 arenas and could evict a live forward of another module)."""
+    _STATE[key] = state
+    mine = [k for k in _STATE if k[0] == handle]
+    while len(mine) > MAX_PENDING:
+        old = _STATE.pop(mine.pop(0))
+        old[1].release()
 
 
 def register(module) -> int:
@@ -63,10 +75,7 @@ def unet_fwd(x: torch.Tensor, anchor: torch.Tensor, handle: int, ncls: int, want
     lease = eng.spaces.lease()
     _lib.run(eng.fwd, eng.bases(module, x, out, noise=noise, space=lease.space), _stream(x.device))
     if want_bwd:
-        _STATE[(handle, out.data_ptr())] = (eng, lease, noise)
-        if len(_STATE) > 64:           # forwards whose backward never ran (inference under grad mode): drop the oldest
-            _, old_lease, _ = _STATE.pop(next(iter(_STATE)))
-            old_lease.release()
+        _park(handle, (handle, out.data_ptr()), (eng, lease, noise))
     else:
         lease.release()
     return out
@@ -160,10 +169,7 @@ def _vit_fwd(handle: int, x: torch.Tensor, mask_ratio, trainable: bool, want_dx:
     _lib.run(eng.fwd, eng.bases(module, x, out, noise, space=lease.space), _stream(x.device))
     views = {k: v.clone() for k, v in eng.views(out).items()}      # separate storages: custom-op outputs must not alias each other
     if want_grad:
-        _STATE[(handle, views[primary].data_ptr())] = (eng, lease, noise, out)
-        if len(_STATE) > 64:
-            old = _STATE.pop(next(iter(_STATE)))
-            old[1].release()
+        _park(handle, (handle, views[primary].data_ptr()), (eng, lease, noise, out))
     else:
         lease.release()
     return views

@@ -62,6 +62,15 @@ class FlatParamsMixin:
         self._compile_anchor = torch.zeros((), dtype=torch.float32, device=dev, requires_grad=True)
         self._compile_handle = compile_ops.register(self)
 
+    def __setstate__(self, state):
+        """copy.deepcopy / pickle: the copy is a module of its own - its compiled forward must find IT (the handle is id-based and
+        would resolve to the original module, or to nothing), and it plans its own engines."""
+        super().__setstate__(state)
+        from . import compile_ops
+
+        self._engines = {}
+        self._compile_handle = compile_ops.register(self)
+
     # -- arithmetic ---------------------------------------------------------------------------
     @property
     def precision(self) -> str:

@@ -192,3 +192,20 @@ def test_unet_classifier_bias_follows_the_class_distribution():
     g = load("class_bias_prior.npz")
     m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.5, 0.3, 0.15, 0.05]))
     assert np.array_equal(m.out_conv1x1.bias.detach().cpu().numpy(), g["nonuniform4_conv.bias"])
+
+
+def test_copied_module_gets_its_own_compile_handle():
+    """`_compile_handle` is id-based; a deepcopy (or unpickled copy) must register itself, or its compiled forward would
+    run the ORIGINAL module's weights (or fail once the original is gone)."""
+    import copy
+
+    from s2lc_amd import compile_ops
+    from s2lc_amd.modules.efficientnet_unet import EfficientNetConfig, EfficientnetUnet
+
+    m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[0.25] * 4))
+    c = copy.deepcopy(m)
+    assert c._compile_handle != m._compile_handle
+    assert compile_ops._module(c._compile_handle) is c and compile_ops._module(m._compile_handle) is m
+    assert c._engines == {} and c._flat_params.data_ptr() != m._flat_params.data_ptr()
+    sd_m, sd_c = m.state_dict(), c.state_dict()
+    assert list(sd_m) == list(sd_c) and all(torch.equal(sd_m[k], sd_c[k]) for k in sd_m)
