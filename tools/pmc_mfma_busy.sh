@@ -18,7 +18,7 @@ for f in glob.glob("$out/p/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("s2k::", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
-want = ["conv_pc_kernel", "wgrad_pc_kernel", "conv_igemm_kernel", "wgrad_kernel", "conv_bf16_kernel", "wgrad_bf16_kernel", "attn_fwd_lds_kernel"]
+want = ["conv_pc_kernel", "wgrad_pc_kernel", "conv_igemm_kernel", "wgrad_kernel", "conv_dma_kernel", "conv_q4_kernel", "conv_bf16_kernel", "wgrad_bf16_kernel", "attn_fwd_lds_kernel"]
 lines = ["# $tag: matrix-core busy counters of the MFMA kernels, headline step ($*)", "",
          "source: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE",
          "-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-prithvi $*  (tools/pmc_mfma_busy.sh; all dispatches of a kernel summed)", "",
