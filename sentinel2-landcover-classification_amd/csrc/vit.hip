@@ -4,6 +4,8 @@
 // im2col of PatchEmbed (:84-127), the MAE reconstruction loss (:333-350), the layout change at the API
 // boundary and the Dropout2d keep-gate of the FCN head (prithvi_segmentation.py:106).
 // Lanes always run along the contiguous token / pixel axis (coalesced 256-B wave rows).
+#include <initializer_list>
+
 #include "common.h"
 
 namespace s2k {
@@ -37,7 +39,278 @@ struct LnP {
     float* dsum;            // backward: DSUM[c] += sum of the new DX values (a bias gradient), or null
     int B, C, HW, tiles_per_b, accum;
     float eps;
+    int dbg;                       // tuning build: S2K_LN_DBG bit 0 skips the all-channel sums, bit 1 the normalising pass, bit 2 the parameter sums
+    int qw, rw, pgroups, csplit;   // row kernels: 16-byte columns per position group, rows per wave, groups, channel splits
 };
+
+// ---- row kernels (HW % 4 == 0): short token rows, e.g. the MAE encoder's [768][52] samples ------------------------------
+// The tile kernels above put 64 POSITIONS on the lanes of a workgroup that owns all C channels: 64 workgroups for 64 samples of
+// 52 tokens, a quarter of the chip, each pulling 208-byte row pieces.  Here the lanes of a wave hold RW whole rows side by side
+// (lane = row slot x 16-byte column: contiguous bytes when one position group covers the row) and a sample is shared by
+// PGROUPS x CSPLIT workgroups: position groups are independent; a channel split recomputes the per-position sums over ALL
+// channels (the sample's other workgroups sit on the same XCD - workgroup id mod 8 - so those reads are L2 hits) and then
+// normalises only its own channel range.  No workgroup waits for another.
+constexpr int LNR_NW = 16;
+constexpr int LNR_U = 4;      // rows in flight per lane and tensor when normalising
+constexpr int LNR_US = 8;     // ... when summing over all channels
+
+struct LnRowsWg {
+    int b, pg, cs, r, q, col;
+    bool on;
+};
+__device__ __forceinline__ bool ln_rows_wg(const LnP& p, LnRowsWg& g) {
+    const int lane = threadIdx.x & 63;
+    const int group = p.pgroups * p.csplit;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int sub = k % group;
+    g.b = (k / group) * 8 + xcd;
+    g.pg = sub / p.csplit;
+    g.cs = sub - g.pg * p.csplit;
+    g.r = lane / p.qw;
+    g.q = lane - g.r * p.qw;
+    g.col = g.pg * p.qw + g.q;
+    g.on = g.r < p.rw && g.col < (p.HW >> 2);
+    return g.b < p.B;
+}
+
+__global__ void __launch_bounds__(64 * LNR_NW) chan_ln_fwd_rows_kernel(const LnP p) {
+    __shared__ double red[LNR_NW][64][4];
+    __shared__ double tot[64][8];
+    LnRowsWg g;
+    if (!ln_rows_wg(p, g)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpi = LNR_NW * p.rw;
+    const int64_t base = (int64_t)g.b * p.C * p.HW + (g.on ? g.col * 4 : 0);
+    const int row0 = wave * p.rw + (g.on ? g.r : 0);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    // every channel split sums over ALL rows, starting at its own range and wrapping: the splits of a sample then pull different
+    // quarters from HBM at any moment and find the rest in L2
+    const int crot = (p.C + rpi * LNR_US - 1) / (rpi * LNR_US) * (rpi * LNR_US);
+    const int rot = g.cs * ((p.C + p.csplit - 1) / p.csplit);
+    for (int i0 = row0; i0 - row0 < p.C && !(p.dbg & 1); i0 += rpi * LNR_US) {           // uniform trip count
+        float4 v[LNR_US];
+        int cc[LNR_US];
+#pragma unroll
+        for (int u = 0; u < LNR_US; ++u) {
+            int c = rot + i0 + rpi * u;
+            cc[u] = c >= crot ? c - crot : c;
+            v[u] = *reinterpret_cast<const float4*>(p.x + base + (int64_t)min(cc[u], p.C - 1) * p.HW);
+        }
+#pragma unroll
+        for (int u = 0; u < LNR_US; ++u) {
+            const bool ok = g.on && cc[u] < p.C;
+            const float a[4] = {ok ? v[u].x : 0.0f, ok ? v[u].y : 0.0f, ok ? v[u].z : 0.0f, ok ? v[u].w : 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += a[j]; sq[j] += (double)a[j] * a[j]; }
+        }
+    }
+    // the wave's row slots first (a shuffle tree over r), then the waves through LDS
+    for (int off = 1; off < p.rw; off <<= 1) {
+        const bool take = (g.r & (2 * off - 1)) == 0 && g.r + off < p.rw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double a = __shfl_down(s[j], off * p.qw), b = __shfl_down(sq[j], off * p.qw);
+            s[j] += take ? a : 0.0;
+            sq[j] += take ? b : 0.0;
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // sums, then sums of squares, through the same 32 KB
+        if (half) __syncthreads();
+        if (lane < p.qw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave][lane][j] = half ? sq[j] : s[j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < p.qw * 4) {
+            const int q2 = threadIdx.x >> 2, v = threadIdx.x & 3;
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < LNR_NW; ++w) a += red[w][q2][v];
+            tot[q2][half * 4 + v] = a;
+        }
+    }
+    __syncthreads();
+    float mf[4], rstd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double mean = tot[g.on ? g.q : 0][j] / p.C;
+        double var = tot[g.on ? g.q : 0][4 + j] / p.C - mean * mean;
+        if (var < 0.0) var = 0.0;
+        rstd[j] = (float)(1.0 / sqrt(var + (double)p.eps));
+        mf[j] = (float)mean;
+    }
+    if (g.on && g.cs == 0 && wave == 0 && g.r == 0) {
+        float4* mr = reinterpret_cast<float4*>(p.mr + ((int64_t)g.b * p.HW + g.col * 4) * 2);
+        mr[0] = make_float4(mf[0], rstd[0], mf[1], rstd[1]);
+        mr[1] = make_float4(mf[2], rstd[2], mf[3], rstd[3]);
+    }
+    const int rows_cs = (p.C + p.csplit - 1) / p.csplit;
+    const int c_lo = g.cs * rows_cs, c_hi = min(p.C, c_lo + rows_cs);
+    for (int c0 = c_lo + row0; c0 - row0 < c_hi && !(p.dbg & 2); c0 += rpi * LNR_U) {
+        float4 v[LNR_U];
+#pragma unroll
+        for (int u = 0; u < LNR_U; ++u) v[u] = *reinterpret_cast<const float4*>(p.x + base + (int64_t)min(c0 + rpi * u, p.C - 1) * p.HW);
+#pragma unroll
+        for (int u = 0; u < LNR_U; ++u) {
+            const int c = c0 + rpi * u;
+            if (g.on && c < c_hi) {
+                const float ga = p.gamma[c], be = p.beta[c];
+                *reinterpret_cast<float4*>(p.y + base + (int64_t)c * p.HW) =
+                    make_float4(fmaf((v[u].x - mf[0]) * rstd[0], ga, be), fmaf((v[u].y - mf[1]) * rstd[1], ga, be),
+                                fmaf((v[u].z - mf[2]) * rstd[2], ga, be), fmaf((v[u].w - mf[3]) * rstd[3], ga, be));
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * LNR_NW) chan_ln_bwd_rows_kernel(const LnP p) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float(*red)[64][8] = reinterpret_cast<float(*)[64][8]>(lsm);                    // [LNR_NW][64][8]
+    float(*tot)[8] = reinterpret_cast<float(*)[8]>(lsm + LNR_NW * 64 * 8);           // [64][8]
+    float* part = lsm + LNR_NW * 64 * 8 + 64 * 8;                                    // [rows of this channel split][3]
+    LnRowsWg g;
+    if (!ln_rows_wg(p, g)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool want_p = p.dgamma != nullptr && !(p.dbg & 4), want_d = p.dsum != nullptr && !(p.dbg & 4);
+    const float* acc_src = p.dxin ? p.dxin : p.dx;
+    const int rpi = LNR_NW * p.rw;
+    const int rows_cs = (p.C + p.csplit - 1) / p.csplit;
+    const int c_lo = g.cs * rows_cs, c_hi = min(p.C, c_lo + rows_cs);
+    for (int i = threadIdx.x; i < rows_cs * 3; i += 64 * LNR_NW) part[i] = 0.0f;
+    const int64_t base = (int64_t)g.b * p.C * p.HW + (g.on ? g.col * 4 : 0);
+    const int row0 = wave * p.rw + (g.on ? g.r : 0);
+    float mean[4], rstd[4];
+    {
+        const float4* mr = reinterpret_cast<const float4*>(p.mr_in + ((int64_t)g.b * p.HW + (g.on ? g.col * 4 : 0)) * 2);
+        const float4 m0 = mr[0], m1 = mr[1];
+        mean[0] = m0.x; rstd[0] = m0.y; mean[1] = m0.z; rstd[1] = m0.w;
+        mean[2] = m1.x; rstd[2] = m1.y; mean[3] = m1.z; rstd[3] = m1.w;
+    }
+    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int crot = (p.C + rpi * LNR_US - 1) / (rpi * LNR_US) * (rpi * LNR_US);       // (see the forward kernel: rotated start per channel split)
+    for (int i0 = row0; i0 - row0 < p.C && !(p.dbg & 1); i0 += rpi * LNR_US) {
+        float4 dv[LNR_US], xv[LNR_US];
+        float ga[LNR_US];
+        int cc[LNR_US];
+#pragma unroll
+        for (int u = 0; u < LNR_US; ++u) {
+            int c = c_lo + i0 + rpi * u;
+            cc[u] = c >= crot ? c - crot : c;
+            c = min(cc[u], p.C - 1);
+            dv[u] = *reinterpret_cast<const float4*>(p.dy + base + (int64_t)c * p.HW);
+            xv[u] = *reinterpret_cast<const float4*>(p.x + base + (int64_t)c * p.HW);
+            ga[u] = p.gamma[c];
+        }
+#pragma unroll
+        for (int u = 0; u < LNR_US; ++u) {
+            const float gm = (g.on && cc[u] < p.C) ? ga[u] : 0.0f;
+            const float d[4] = {dv[u].x * gm, dv[u].y * gm, dv[u].z * gm, dv[u].w * gm};
+            const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s1[j] += d[j];
+                s2[j] = fmaf(d[j], (x[j] - mean[j]) * rstd[j], s2[j]);
+            }
+        }
+    }
+    for (int off = 1; off < p.rw; off <<= 1) {       // the wave's row slots (shuffle tree over r), then the waves through LDS
+        const bool take = (g.r & (2 * off - 1)) == 0 && g.r + off < p.rw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = __shfl_down(s1[j], off * p.qw), b = __shfl_down(s2[j], off * p.qw);
+            s1[j] += take ? a : 0.0f;
+            s2[j] += take ? b : 0.0f;
+        }
+    }
+    if (lane < p.qw) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[wave][lane][j] = s1[j]; red[wave][lane][4 + j] = s2[j]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.qw * 8) {
+        const int q2 = threadIdx.x >> 3, v = threadIdx.x & 7;
+        float a = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LNR_NW; ++w) a += red[w][q2][v];
+        tot[q2][v] = a;
+    }
+    __syncthreads();
+    const float invC = 1.0f / p.C;
+    float m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m1[j] = tot[g.on ? g.q : 0][j] * invC; m2[j] = tot[g.on ? g.q : 0][4 + j] * invC; }
+    for (int c0 = c_lo + row0; c0 - row0 < c_hi && !(p.dbg & 2); c0 += rpi * LNR_U) {
+        float4 dv[LNR_U], xv[LNR_U], ov[LNR_U];
+#pragma unroll
+        for (int u = 0; u < LNR_U; ++u) {
+            const int64_t off = base + (int64_t)min(c0 + rpi * u, p.C - 1) * p.HW;
+            dv[u] = *reinterpret_cast<const float4*>(p.dy + off);
+            xv[u] = *reinterpret_cast<const float4*>(p.x + off);
+            ov[u] = p.accum ? *reinterpret_cast<const float4*>(acc_src + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // kernel-uniform
+        }
+#pragma unroll
+        for (int u = 0; u < LNR_U; ++u) {
+            const int c = c0 + rpi * u;
+            if (g.on && c < c_hi) {
+                const float gm = p.gamma[c];
+                const float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+                const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                const float o[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+                float nv[4], sg = 0.0f, sb = 0.0f, sd = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (x[j] - mean[j]) * rstd[j];
+                    nv[j] = rstd[j] * (d[j] * gm - m1[j] - xh * m2[j]) + o[j];
+                    sg = fmaf(d[j], xh, sg);
+                    sb += d[j];
+                    sd += nv[j];
+                }
+                *reinterpret_cast<float4*>(p.dx + base + (int64_t)c * p.HW) = make_float4(nv[0], nv[1], nv[2], nv[3]);
+                float* pr = part + (c - c_lo) * 3;
+                if (want_p) { atomicAdd(pr, sg); atomicAdd(pr + 1, sb); }
+                if (want_d) atomicAdd(pr + 2, sd);
+            }
+        }
+    }
+    if (want_p || want_d) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < c_hi - c_lo; i += 64 * LNR_NW) {
+            if (want_p) {
+                atomicAdd(p.dgamma + c_lo + i, part[i * 3]);
+                atomicAdd(p.dbeta + c_lo + i, part[i * 3 + 1]);
+            }
+            if (want_d) atomicAdd(p.dsum + c_lo + i, part[i * 3 + 2]);
+        }
+    }
+}
+
+// geometry of the row kernels, or false when the tile kernels should run (rows not a multiple of 16 bytes, tiny or long rows)
+static bool ln_rows_geometry(LnP& p, std::initializer_list<const void*> ptrs) {
+    static const int enabled = tune_int("S2K_LN_ROWS", 1);
+    static const int dbg = tune_int("S2K_LN_DBG", 0);
+    p.dbg = dbg;
+    // worth it only where the tile kernels leave most of the chip idle: one 64-position tile per sample and few samples (measured,
+    // tools/exp_ln.sh, back-to-back launches: 64 x [768][52] backward 35 -> 24 us, forward 17 -> 12; 64 x [512][200] and
+    // 64 x [768][196]: forward equal, backward slower - the 3 C atomics of every workgroup are 64-byte memory transactions,
+    // 11 of the 24 us, and four times as many workgroups send them).  S2K_LN_ROWS=2 (tuning build) takes every supported shape.
+    if (!enabled || (p.HW & 3) || p.HW < 32 || p.HW > 1024 || p.C < 64 || (enabled != 2 && (p.HW > 64 || p.B >= 128))) return false;
+    for (const void* q : ptrs)
+        if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+    const int ncol = p.HW >> 2;
+    p.pgroups = cdiv(ncol, 64);
+    p.qw = cdiv(ncol, p.pgroups);
+    if (p.qw > 32 && p.B * p.pgroups < 256 && (ncol & 1) == 0) {     // long rows: two position groups rather than a channel split
+        p.pgroups *= 2;
+        p.qw = cdiv(ncol, p.pgroups);
+    }
+    p.rw = 64 / p.qw;
+    const int rpi = LNR_NW * p.rw;
+    int cs = cdiv(256, p.B * p.pgroups);
+    cs = std::max(1, std::min(cs, std::min(8, p.C / (rpi * 2))));   // at least two row iterations per split
+    p.csplit = cs;
+    return true;
+}
 
 __global__ void __launch_bounds__(64 * LN_NW) chan_ln_fwd_kernel(const LnP p) {
     __shared__ double red[LN_NW][64][2];
@@ -105,6 +378,11 @@ int launch_chan_ln_fwd(const S2kOp& op, const Ctx& c) {
     p.B = op.d[S2K_CHAN_LN_FWD_D_B]; p.C = op.d[S2K_CHAN_LN_FWD_D_C]; p.HW = op.d[S2K_CHAN_LN_FWD_D_HW];
     p.eps = op.f[S2K_CHAN_LN_FWD_F_EPS];
     if (!p.x || !p.gamma || !p.beta || !p.y || !p.mr || p.B <= 0 || p.C <= 0 || p.HW <= 0) { set_error("chan_ln_fwd: bad args"); return S2K_EINVAL; }
+    if (ln_rows_geometry(p, {p.x, p.y, p.mr})) {
+        const unsigned grid = 8u * (unsigned)(p.pgroups * p.csplit) * (unsigned)cdiv(p.B, 8);
+        hipLaunchKernelGGL(chan_ln_fwd_rows_kernel, dim3(grid), dim3(64 * LNR_NW), 0, c.stream, p);
+        return S2K_OK;
+    }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;
     hipLaunchKernelGGL(chan_ln_fwd_kernel, dim3((unsigned)std::min<int64_t>(tiles, 8192)), dim3(64 * LN_NW), 0, c.stream, p);
@@ -232,6 +510,14 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     p.accum = op.d[S2K_CHAN_LN_BWD_D_ACCUM];
     if (!p.dy || !p.x || !p.mr_in || !p.gamma || !p.dx || p.B <= 0 || p.C <= 0 || p.HW <= 0 || (!p.dgamma != !p.dbeta)) {
         set_error("chan_ln_bwd: bad args"); return S2K_EINVAL;
+    }
+    if (ln_rows_geometry(p, {p.x, p.dy, p.dx, p.mr_in, p.dxin})) {
+        const unsigned grid = 8u * (unsigned)(p.pgroups * p.csplit) * (unsigned)cdiv(p.B, 8);
+        const size_t lds_rows = ((size_t)LNR_NW * 64 * 8 + 64 * 8 + 3 * (size_t)cdiv(p.C, p.csplit)) * sizeof(float);
+        if (lds_rows <= 64 * 1024) {
+            hipLaunchKernelGGL(chan_ln_bwd_rows_kernel, dim3(grid), dim3(64 * LNR_NW), lds_rows, c.stream, p);
+            return S2K_OK;
+        }
     }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;

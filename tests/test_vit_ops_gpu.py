@@ -14,7 +14,12 @@ from tests.test_ops_gpu import Case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,C,HW,eps", [(2, 32, 50, 1e-5), (2, 768, 197, 1e-5), (1, 96, 28 * 28, 1e-6), (3, 16, 64, 1e-6), (1, 5, 3, 1e-5)])
+# HW % 4 == 0 with C >= 64 runs the row kernels (a sample shared by position groups x channel splits), the rest the tile kernels
+LN_ROW_SHAPES = [(3, 768, 52), (2, 512, 200), (9, 130, 36), (17, 64, 32), (1, 1000, 1024), (2, 96, 196), (64, 768, 52)]
+
+
+@pytest.mark.parametrize("B,C,HW,eps", [(2, 32, 50, 1e-5), (2, 768, 197, 1e-5), (1, 96, 28 * 28, 1e-6), (3, 16, 64, 1e-6), (1, 5, 3, 1e-5)]
+                         + [(*s, 1e-6) for s in LN_ROW_SHAPES])
 def test_chan_ln_fwd(B, C, HW, eps):
     c = Case(1)
     x = c.t("x", (B, C, HW), scale=2.0)
@@ -23,9 +28,11 @@ def test_chan_ln_fwd(B, C, HW, eps):
     c.run("CHAN_LN_FWD", ["y", "mr"], tol=2e-5, X=x, GAMMA=g, BETA=b, Y=y, MR=mr, B=B, C=C, HW=HW, EPS=eps)
 
 
-@pytest.mark.parametrize("B,C,HW,accum,params", [(2, 32, 50, 0, True), (2, 768, 197, 1, True), (1, 96, 28 * 28, 1, False),
-                                                 (3, 16, 64, 0, True), (1, 5, 3, 0, True), (5, 100, 52, 1, True)])
-def test_chan_ln_bwd(B, C, HW, accum, params):
+@pytest.mark.parametrize("B,C,HW,accum,params,extra", [(2, 32, 50, 0, True, ""), (2, 768, 197, 1, True, ""), (1, 96, 28 * 28, 1, False, ""),
+                                                       (3, 16, 64, 0, True, ""), (1, 5, 3, 0, True, ""), (5, 100, 52, 1, True, ""),
+                                                       (2, 768, 197, 1, True, "dxin+dsum"), (3, 40, 50, 0, False, "dsum")]
+                         + [(*s, i % 2, i % 3 != 0, ["", "dxin", "dsum", "dxin+dsum"][i % 4]) for i, s in enumerate(LN_ROW_SHAPES)])
+def test_chan_ln_bwd(B, C, HW, accum, params, extra):
     c = Case(2)
     xd = torch.randn(B, C, HW, generator=c.gen) * 2
     mean = xd.mean(1)
@@ -37,8 +44,10 @@ def test_chan_ln_bwd(B, C, HW, accum, params):
     dx = c.t("dx", (B, C, HW), "randn" if accum else "nan")
     dg = c.t("dgamma", (C,), "randn") if params else None
     db = c.t("dbeta", (C,), "randn") if params else None
-    c.run("CHAN_LN_BWD", ["dx"] + (["dgamma", "dbeta"] if params else []), tol=1e-4, DY=dy, X=x, MR=mr, GAMMA=g, DX=dx, DGAMMA=dg,
-          DBETA=db, B=B, C=C, HW=HW, ACCUM=accum)
+    dxin = c.t("dxin", (B, C, HW), "randn") if "dxin" in extra else None     # out-of-place accumulate: DX = DXIN + ...
+    dsum = c.t("dsum", (C,), "randn") if "dsum" in extra else None           # DSUM[c] += sum of the new DX values
+    c.run("CHAN_LN_BWD", ["dx"] + (["dgamma", "dbeta"] if params else []) + (["dsum"] if dsum is not None else []), tol=1e-4, DY=dy, X=x, MR=mr,
+          GAMMA=g, DX=dx, DGAMMA=dg, DBETA=db, DXIN=dxin, DSUM=dsum, B=B, C=C, HW=HW, ACCUM=1 if dxin is not None else accum)
 
 
 @pytest.mark.parametrize("act", [D.ACT_GELU, D.ACT_SILU, D.ACT_RELU])

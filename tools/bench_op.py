@@ -16,7 +16,7 @@ from s2lc_amd.plan.program import Arena, Program  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["wgrad3", "wgrad1", "conv3", "conv1", "dwfwd", "dwwgrad", "dwdgrad", "copy"])
+    ap.add_argument("what", choices=["wgrad3", "wgrad1", "conv3", "conv1", "dwfwd", "dwwgrad", "dwdgrad", "copy", "lnfwd", "lnbwd"])
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--M", type=int, default=128)
     ap.add_argument("--C", type=int, default=128)
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--S", type=int, default=1)
     ap.add_argument("--nostats", action="store_true")
+    ap.add_argument("--gate", action="store_true", help="conv: SE gate [B][C] on X1 (with --pro 2: the MBConv project conv's prologue)")
     ap.add_argument("--q4", action="store_true", help="conv: FLAG_Q4 + the quad weight copy (csrc/conv_q4.hip)")
     ap.add_argument("--dma", action="store_true", help="conv: FLAG_DMA (the LDS-DMA ring kernel wherever it supports the shape)")
     ap.add_argument("--bias", action="store_true")
@@ -49,7 +50,18 @@ def main():
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
         print(f"copy {x.numel() * 8 / 1e6:.0f} MB: {dt * 1e3:.3f} ms  {x.numel() * 8 / dt / 1e12:.2f} TB/s")
         return
-    if a.what.startswith("dw"):
+    if a.what.startswith("ln"):          # channel LayerNorm on [B][C][N] (--N tokens per sample)
+        N = a.N or H * H
+        X = ar.alloc("x", (B, C, N)); Y = ar.alloc("y", (B, C, N)); mr = ar.alloc("mr", (B, N, 2)); ga = ar.alloc("gamma", (C,)); be = ar.alloc("beta", (C,))
+        if a.what == "lnfwd":
+            prog.add("CHAN_LN_FWD", X=X, GAMMA=ga, BETA=be, Y=Y, MR=mr, B=B, C=C, HW=N, EPS=1e-6)
+            flops = 8.0 * B * C * N * 1000      # "TF/s" column = TB/s of read + write
+        else:
+            dy = ar.alloc("dy", (B, C, N)); dxin = ar.alloc("dxin", (B, C, N)) if a.beta else None
+            prog.add("CHAN_LN_BWD", DY=dy, X=X, MR=mr, GAMMA=ga, DX=Y, DGAMMA=None if a.nostats else ar.alloc("dg", (C,)),
+                     DBETA=None if a.nostats else ar.alloc("db", (C,)), DXIN=dxin, DSUM=ar.alloc("ds", (C,)) if a.bias else None, B=B, C=C, HW=N, ACCUM=int(a.beta))
+            flops = (16.0 if a.beta else 12.0) * B * C * N * 1000
+    elif a.what.startswith("dw"):
         K, S = a.K, a.S
         HO = (H + S - 1) // S
         pad = max((HO - 1) * S + K - H, 0)
@@ -82,7 +94,7 @@ def main():
         MP, KP = (M + 127) // 128 * 128, (C + 63) // 64 * 64
         W = ar.alloc("w", (KP * T, MP)); st = ar.alloc("st", (D.stats_replicas(M), 2, M), "f64")
         flg = (D.FLAG_BF16 if a.bf16 else 0) | (D.FLAG_DMA if a.dma else 0) | ((D.FLAG_Q4 | D.FLAG_DMA) if a.q4 else 0)
-        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=None, X2=None, BNV2=None, WT=W, BIAS=ar.alloc("bias", (M,)) if a.bias else None, Y=Y, STATS=None if a.nostats else st,
+        prog.add("CONV", X1=X, BNV1=bnv if a.pro else None, GATE1=ar.alloc("gate", (B, C)) if a.gate else None, X2=None, BNV2=None, WT=W, BIAS=ar.alloc("bias", (M,)) if a.bias else None, Y=Y, STATS=None if a.nostats else st,
                  SCRATCH=scr, B=B, C1=C,
                  C2=0, H=H, W=Wd, M=M, KH=k, KW=k, STRIDE=1, PAD_T=k // 2, PAD_L=k // 2, HO=H, WO=Wd, PRO1=a.pro, PRO2=0, MODE=0,
                  W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=int(a.beta), YC=M, NREP=D.stats_replicas(M),
@@ -106,7 +118,7 @@ def main():
     torch.cuda.synchronize()
     dt = e0.elapsed_time(e1) * 1e-3 / (a.iters * R)
     ms_ev, var = _lib.profile_variants(packed, bases, st_)     # HIP-event time of the stage alone + the kernel family it took
-    fam = ("generic", "producer/consumer", "bf16", "dma-ring", "quad")[int(var[-1])]
+    fam = ("generic", "producer/consumer", "bf16", "dma-ring", "quad")[int(var[-1])] if int(var[-1]) < 5 else "-"
     print(f"{a.what} B={B} M={M} C={C} H={H} pro={a.pro}: {dt * 1e3:.3f} ms  {flops / dt / 1e12:.1f} TF/s   [{fam}; events: {float(ms_ev[-1]) * 1e3:.1f} us]")
     L = _lib.lib()
     if hasattr(L, "s2k_debug_dma_counters") and fam in ("dma-ring", "quad"):     # tuning build: in-kernel stamps of the LDS-DMA ring kernel

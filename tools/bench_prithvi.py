@@ -97,11 +97,14 @@ def main():
             from s2lc_amd.plan import opdefs as D
             names = {v: k for k, v in D.KIND.items()}
             agg = collections.OrderedDict()
+            other = collections.OrderedDict()
             for tag, prog in (("fwd", eng.fwd), ("bwd", eng.bwd)):
                 ms = _lib.profile_ops(prog, bases, st)
                 for rec, t in zip(prog, ms):
                     kind = names[int(rec["kind"])]
                     if kind not in ("CONV", "WGRAD"):
+                        e = other.setdefault((tag, kind, tuple(int(v) for v in rec["d"][:6]), tuple(int(v) for v in rec["n"][:2])), [0, 0.0])
+                        e[0] += 1; e[1] += float(t)
                         continue
                     d = rec["d"]
                     g = lambda f: int(d[D.slot(kind, f)[1]])  # noqa: E731
@@ -116,6 +119,9 @@ def main():
             print("per-shape MFMA stages (sequential, no side stream):", file=sys.stderr)
             for key, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
                 print("  %s %-5s M=%5d C=%5d k%d N=%7d mode%d  x%-3d %7.3f ms  %6.1f TF/s" % (*key, n, t, fl / t / 1e9), file=sys.stderr)
+            print("other stages by (kind, d[:6], n[:2]):", file=sys.stderr)
+            for key, (n, t) in sorted(other.items(), key=lambda kv: -kv[1][1])[:40]:
+                print("  %s %-16s d=%s n=%s  x%-3d %7.3f ms  %7.1f us each" % (key[0], key[1], key[2], key[3], n, t, 1e3 * t / n), file=sys.stderr)
     print(json.dumps(res))
 
 
