@@ -236,12 +236,13 @@ def cpu_baseline(version, C, H, ncls, steps=5):
 
 
 def time_adam(opt, dev, iters=10) -> float:
-    """Milliseconds of one fused Adam step over the flat parameter buffer (HIP events on the current stream)."""
+    """Milliseconds of one fused Adam step over the flat parameter buffer (HIP events on the current stream).  Called on rank 0 alone:
+    in the sharded mode the kernels over the owned slices are timed without the parameter all-gather (a collective)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    opt.step()
+    opt.step(gather=False)
     e0.record()
     for _ in range(iters):
-        opt.step()
+        opt.step(gather=False)
     e1.record()
     torch.cuda.synchronize(dev)
     return e0.elapsed_time(e1) / iters
@@ -447,10 +448,14 @@ def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms:
     nbytes = 4 * sum(hi - lo for lo, hi in buckets)
     iters = 5
 
+    sharded = getattr(ddp, "mode", "allreduce") == "sharded"
+
     def alone():
         for lo, hi in buckets:
             ddp.on_segment(lo, hi, grads)
         ddp.finish()
+        if sharded:     # the second half of the collective: the parameters of every bucket gathered from their owners
+            ddp.all_gather_slices(model._flat_params)
     alone()
     dt = time_steps(alone, iters, dist, dev) / iters
     bus = 2.0 * (world - 1) / world * nbytes / dt / 1e9
@@ -458,7 +463,10 @@ def allreduce_report(model, ddp, dist, dev, world: int, step_ms: float, noop_ms:
             "bucket_mb_planned": round(float(getattr(ddp, "bucket_mb", 0.0)), 3),      # ddp.DEFAULT_BUCKET_MB / --bucket-mb: the planner's bucket size
             "ms_exposed": round(step_ms - noop_ms, 3), "ms_step_with_reducer": round(step_ms, 3), "ms_step_noop_hook": round(noop_ms, 3),
             "ms_alone": round(dt * 1e3, 3), "bus_gbps": round(bus, 1), "overlap_fraction": round(max(0.0, 1.0 - max(step_ms - noop_ms, 0.0) / (dt * 1e3)), 3),
-            "backend": dist.get_backend(), "op": "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
+            "backend": dist.get_backend(), "mode": "sharded" if sharded else "allreduce",
+            "op": ("reduce_scatter(SUM) per contiguous suffix bucket of the flat gradient buffer on a side stream, Adam on the owned slices, "
+                   "all_gather of the updated parameters per bucket (--sharded-adam)") if sharded else
+                  "all_reduce(SUM) per contiguous suffix bucket of the flat gradient buffer, side stream"}
 
 
 def prithvi_mae_dp_leg(dist, dev, rank: int, world: int, batch: int = 64, steps: int = 5, warmup: int = 2) -> dict:
@@ -634,6 +642,8 @@ def main() -> None:
     ap.add_argument("--no-bf16", action="store_true", help="skip the extra key `bf16_mixed` (N = 1 only)")
     ap.add_argument("--mae-batch", type=int, default=64, help="per-GPU batch of the data-parallel Prithvi leg (N > 1 only)")
     ap.add_argument("--mae-steps", type=int, default=5, help="timed steps of the data-parallel Prithvi leg (N > 1 only)")
+    ap.add_argument("--sharded-adam", action="store_true", help="N > 1: reduce-scatter the gradient buckets, Adam on the slices each rank owns, all-gather "
+                    "the parameters (ddp.FlatGradReducer(mode='sharded')) instead of all-reduce + full Adam on every rank")
     ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size of the data-parallel reducer (default: ddp.DEFAULT_BUCKET_MB = 32)")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16-mixed"],
                     help="arithmetic of the HEADLINE run (default f32, the parity path; bf16-mixed is otherwise reported as the extra key `bf16_mixed`)")
@@ -677,14 +687,14 @@ def main() -> None:
     model = EfficientnetUnet(model_cfg)
     model.to(dev).train()
     model.precision = args.precision
-    opt = FlatAdam(model, lr=1.5e-6, weight_decay=0.05)  # BASE_CONFIG lr / weight_decay
     loss_fn = FocalLoss(torch.ones(ncls), 2.0, 0.0, ignore_index=0)
     ddp = None
     if world > 1:
         from s2lc_amd.ddp import FlatGradReducer
 
-        ddp = FlatGradReducer(model, dist, bucket_mb=BUCKET_MB)
+        ddp = FlatGradReducer(model, dist, bucket_mb=BUCKET_MB, mode="sharded" if args.sharded_adam else "allreduce")
         ddp.broadcast_parameters(0)
+    opt = FlatAdam(model, lr=1.5e-6, weight_decay=0.05, reducer=ddp)  # BASE_CONFIG lr / weight_decay
 
     g = torch.Generator(device=dev).manual_seed(42 + rank)
     B, C, H = args.batch, args.bands, args.size
@@ -721,6 +731,7 @@ def main() -> None:
         #     gradients off, ddp.py), the fair denominator of a weak-scaling efficiency.
         calls = []
         model._bwd_segment_hook = lambda lo, hi, grads: calls.append((lo, hi))
+        opt_reducer, opt.reducer = opt.reducer, None      # (sharded mode: no parameter all-gather either; every rank steps all of its own)
         n_extra = max(3, min(args.steps, 10))
         step()
         calls.clear()
@@ -730,6 +741,7 @@ def main() -> None:
         noop_ms = noop_dt / n_extra * 1e3
         same_plan = round(B * n_extra / noop_dt, 2)
         model._bwd_segment_hook = ddp.on_segment
+        opt.reducer = opt_reducer
         try:
             allreduce = allreduce_report(model, ddp, dist, dev, world, step_ms, noop_ms, buckets)
         except Exception as e:  # noqa: BLE001

@@ -353,7 +353,8 @@ static int launch_q4(ConvP& p, int n_ntiles, int splits, hipStream_t st) {
         hipDeviceProp_t pr;
         n_cu[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     });
-    const int grid = (int)std::min<int64_t>(items, n_cu[dev]);     // one workgroup per CU (see conv_dma.hip)
+    static const int per_cu = tune_int("S2K_Q4_PER_CU", 1);
+    const int grid = (int)std::min<int64_t>(items, (int64_t)n_cu[dev] * per_cu);     // one workgroup per CU (see conv_dma.hip)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
     if (splits > 1) launch_splitk_reduce(p, st);
     g_s2k_variant = 4;

@@ -7,6 +7,10 @@ parameter takes part in a step iff it `requires_grad` and holds a gradient (`p.g
 never-used parameters (`encoder.fc.*`), the fixed position tables and anything the user froze after
 construction are skipped entirely — no moment update, no weight decay.
 
+Data-parallel option (ddp.FlatGradReducer(mode="sharded")): `FlatAdam(module, reducer=red)` updates only the slices of the flat
+buffer this rank received reduced gradients for and all-gathers the updated parameters (see ddp.py); moments of the other ranks'
+slices stay zero here until `consolidate_state()` gathers them for a checkpoint.
+
 It IS a `torch.optim.Optimizer` (param_groups, state_dict / load_state_dict, add-on lr schedulers such
 as the reference's `get_lr_scheduler` wrap it unchanged); only `step` / `zero_grad` are replaced.
 """
@@ -18,10 +22,15 @@ from . import _lib
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, reducer=None):
         if not hasattr(module, "_flat_params"):
             raise TypeError("FlatAdam optimises a module that keeps its parameters in one flat buffer (flat.FlatParamsMixin)")
+        if reducer is not None and reducer.module is not module:
+            raise ValueError("the reducer belongs to another module")
         self.module = module
+        self.reducer = reducer if (reducer is not None and reducer.mode == "sharded") else None
+        self._consolidated = True       # sharded: the moments of every rank's slices are present on this rank
+        self._seg_layout = None         # sharded: the bucket list the moments are currently sliced by
         self.step_count = 0
         self.m = None
         self.v = None
@@ -83,7 +92,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.module._overwrite_next = True
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, gather: bool = True):
+        """gather=False (sharded mode, measurement only): update the owned slices without the collectives of a step - no parameter
+        all-gather, no re-slicing of the moments; the ranks' weights then differ until the next full step."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -100,15 +111,39 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = grp["betas"]
         st = torch.cuda.current_stream(p.device).cuda_stream
         L = _lib.lib()
+        red = self.reducer
+        if red is not None and gather:
+            layout = list(red.last_segments)
+            if self._seg_layout is not None and layout != self._seg_layout:
+                # the buckets changed (another plan, or an accumulated step reduced as one range): slices change owners, so every rank
+                # first needs the moments of the slices it is about to own - all ranks see the same change in the same step
+                self.consolidate_state()
+            self._seg_layout = layout
         with torch.cuda.device(p.device):
-            for a, b, local_step in self._ranges():
-                _lib.check(L.s2k_adam_step(p.data_ptr() + 4 * a, g.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
-                                           self.v.data_ptr() + 4 * a, b - a, float(grp["lr"]), float(b1), float(b2),
-                                           float(grp["eps"]), float(grp["weight_decay"]), local_step, st))
+            for a0, b0, local_step in self._ranges():
+                for a, b in (red.owned(a0, b0) if red is not None else ((a0, b0),)):
+                    _lib.check(L.s2k_adam_step(p.data_ptr() + 4 * a, g.data_ptr() + 4 * a, self.m.data_ptr() + 4 * a,
+                                               self.v.data_ptr() + 4 * a, b - a, float(grp["lr"]), float(b1), float(b2),
+                                               float(grp["eps"]), float(grp["weight_decay"]), local_step, st))
+            if red is not None:
+                if gather:
+                    red.all_gather_slices(p)        # every rank's updated slices to all ranks, bucket by bucket
+                self._consolidated = False
         return loss
+
+    def consolidate_state(self) -> None:
+        """sharded mode, a COLLECTIVE (call on every rank, e.g. before a checkpoint): gathers the Adam moments of all ranks' slices, after
+        which `state_dict()` is the same full state on every rank as the all-reduce mode would hold."""
+        if self.reducer is not None and not self._consolidated and self.m is not None and self._seg_layout is not None:
+            self.reducer.all_gather_slices(self.m, self._seg_layout)
+            self.reducer.all_gather_slices(self.v, self._seg_layout)
+        self._consolidated = True
 
     # -- checkpointing -------------------------------------------------------------------------------------
     def state_dict(self) -> dict:
+        if self.reducer is not None and not self._consolidated:
+            raise RuntimeError("FlatAdam in sharded mode holds only this rank's slices of the moments: call consolidate_state() on "
+                               "EVERY rank first (a collective), then state_dict() where the checkpoint is written")
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
         return {"state": {"step": self.step_count, "updates": dict(self._updates),
                           "exp_avg": None if self.m is None else self.m.detach().clone(),
@@ -120,6 +155,7 @@ class FlatAdam(torch.optim.Optimizer):
             raise ValueError("optimizer state belongs to a module with a different flat parameter layout")
         st = state["state"]
         self.step_count = int(st["step"])
+        self._consolidated, self._seg_layout = True, None       # a checkpoint holds the full moments
         # "updates": per-parameter count of steps taken (torch's state['step']).  Older checkpoints carry "first_step" (the global step
         # at which a parameter first held a gradient: exact unless it was frozen again in between) or nothing (every parameter that
         # holds a gradient at the first resumed step is assumed to have been updated in every step so far)

@@ -53,7 +53,7 @@ def build_case(case: str, seed: int):
 def run_shard(model, case, x, y, noise, loss_fn, lo, hi, dev):
     """forward + backward of samples [lo, hi) of the global batch; returns the loss."""
     xs = x[lo:hi].to(dev)
-    case = case.replace("_accum", "")
+    case = case.replace("_accum", "").replace("_sharded", "").replace("_adam", "")
     if case.startswith("unet"):
         model.train(case == "unet_train")
         model.drop_connect_noise = noise[:, lo:hi].contiguous() if case == "unet_train" else None
@@ -90,7 +90,7 @@ def main():
 
         model, x, y, noise, loss_fn = build_case(case, seed=5 + rank)      # different weights per rank: the broadcast must fix that
         model.to(dev)
-        red = FlatGradReducer(model, dist)
+        red = FlatGradReducer(model, dist, mode="sharded" if case.endswith("_sharded") else "allreduce")
         red.broadcast_parameters(0)
         torch.cuda.synchronize()
         w0 = model._flat_params.detach().cpu().clone()
@@ -103,6 +103,37 @@ def main():
 
         model._bwd_segment_hook = hook
         per = x.shape[0] // world
+        if case.endswith("_sharded") or case.endswith("_adam"):
+            # three optimiser steps: two with bucketed reduction, the third accumulated (reduced as one range by finish(): in the
+            # sharded mode the slices change owners there).  "_adam": all-reduce + full Adam on every rank; "_sharded": reduce-scatter,
+            # Adam on the owned slices, all-gather of the parameters - same weights and (consolidated) moments, bit for bit
+            from s2lc_amd.optim import FlatAdam
+
+            opt = FlatAdam(model, lr=1e-2, weight_decay=0.01, reducer=red)
+            half = per // 2
+            for step in range(3):
+                opt.zero_grad()
+                if step == 2:
+                    with red.no_sync():
+                        run_shard(model, case, x, y, noise, loss_fn, rank * per, rank * per + half, dev)
+                    loss = run_shard(model, case, x, y, noise, loss_fn, rank * per + half, (rank + 1) * per, dev)
+                else:
+                    loss = run_shard(model, case, x, y, noise, loss_fn, rank * per, (rank + 1) * per, dev)
+                red.finish()
+                opt.step()
+            refused = False
+            if case.endswith("_sharded"):
+                try:
+                    opt.state_dict()
+                except RuntimeError:
+                    refused = True
+            opt.consolidate_state()
+            sd = opt.state_dict()["state"]
+            torch.cuda.synchronize()
+            torch.save(dict(rank=rank, backend=dist.get_backend(), params=model._flat_params.detach().cpu(), m=sd["exp_avg"].cpu(), v=sd["exp_avg_sq"].cpu(),
+                            w0=w0, loss=float(loss), calls=calls, native=red._native_rs, refused=refused, segments=list(red.last_segments),
+                            grads=model._grad_buffer().detach().cpu(), bufs=model._flat_bufs.detach().cpu()), os.path.join(outdir, f"{case}.r{rank}.pt"))
+            return
         if case.endswith("_accum"):
             # gradient accumulation as with torch DDP: every micro-batch but the last inside no_sync(), ONE reduction of the sum
             half = per // 2

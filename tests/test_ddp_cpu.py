@@ -108,6 +108,70 @@ def test_flat_grad_reducer_averages_like_ddp_gloo(tmp_path):
     assert torch.equal(out[0][3], out[1][3])  # identical weights after the broadcast
 
 
+def _sharded_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from s2lc_amd.ddp import FlatGradReducer
+
+        torch.manual_seed(7)
+        m = EfficientnetUnet(EfficientNetConfig("b0", 4, 4, class_distribution=[.25] * 4))
+        red = FlatGradReducer(m, dist, mode="sharded")
+        grads = m._grad_buffer()
+        local = torch.randn(grads.shape, generator=torch.Generator().manual_seed(rank))
+        grads.copy_(local * m._grad_scale)
+        n = grads.numel()
+        cuts = [n, 2 * n // 3 // 64 * 64 + 40, n // 3 // 64 * 64, 0]       # one bucket boundary off the 64-float grid: leftovers
+        for hi, lo in zip(cuts, cuts[1:]):
+            red.on_segment(lo, hi, grads)
+        red.finish()
+        owned = red.owned(0, n)
+        # "parameters": every rank writes its rank id + 1 into what it owns, the all-gather must deliver everyone's slices
+        flat = torch.zeros(n)
+        for a, b in owned:
+            flat[a:b] = rank + 1.0
+        red.all_gather_slices(flat)
+        torch.save((rank, grads.clone(), local, owned, flat, list(red.last_segments), red._native_rs), os.path.join(outdir, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_reducer_slices_gloo(tmp_path):
+    """mode="sharded" (reduce-scatter per bucket): every rank holds the rank-mean of the gradients on the slices it owns, the slices of
+    a bucket tile it together with the replicated leftover, and all_gather_slices delivers every owner's values to every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    out = sorted((torch.load(tmp_path / f"s{r}.pt") for r in range(world)), key=lambda t: t[0])
+    mean = (out[0][2] + out[1][2]) / 2
+    n = mean.numel()
+    cover = torch.zeros(n)
+    for rank, grads, _, owned, flat, segs, native in out:
+        assert len(segs) == 3 and all(sl % 64 == 0 for _, _, sl in segs)
+        for a, b in owned:
+            assert torch.allclose(grads[a:b], mean[a:b], rtol=1e-6, atol=1e-7), (rank, a, b)
+            cover[a:b] += 1
+    leftovers = torch.zeros(n)
+    for lo, hi, sl in out[0][5]:
+        leftovers[lo + sl * world: hi] = 1
+    assert leftovers.sum() > 0, "the test must exercise a bucket with a leftover"
+    assert torch.equal(cover, 1 + leftovers * (world - 1)), "slices tile every bucket once; leftovers belong to every rank"
+    # after the all-gather: a slice carries its owner's id on every rank; leftovers each rank's own
+    for rank, _, _, _, flat, segs, _ in out:
+        for lo, hi, sl in segs:
+            for r in range(world):
+                assert (flat[lo + r * sl: lo + (r + 1) * sl] == r + 1.0).all()
+            assert (flat[lo + sl * world: hi] == rank + 1.0).all()
+    print(f"sharded reducer over gloo: native reduce-scatter {out[0][6]}")
+
+
 def test_run_backward_modes_without_a_gpu():
     """engine.run_backward, the one place that decides how a backward program meets the reducer (eager nodes and compiled ops):
     no reducer -> one run; reducer -> segments + hook; no_sync -> one run, marked for finish(); accumulate -> one run, marked;

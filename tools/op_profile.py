@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--kinds", default="CONV,WGRAD")
     ap.add_argument("--top", type=int, default=400)
     ap.add_argument("--precision", default="f32")
+    ap.add_argument("--order", action="store_true", help="program order instead of slowest first")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model = EfficientnetUnet(EfficientNetConfig(a.version, a.bands, 4, class_distribution=[.25] * 4)).to(dev).train()
@@ -64,7 +65,7 @@ def main():
             else:
                 fl, desc, by = 0.0, " ".join(str(int(v)) for v in d[:11]), 0.0
             rows.append((float(ms[i]), tag, i, kind, desc, fl, by))
-        rows.sort(reverse=True)
+        rows.sort(key=(lambda r: r[2]) if a.order else None, reverse=not a.order)
         tot = sum(r[0] for r in rows)
         print(f"== {tag}: {tot:.2f} ms in {len(rows)} stages of kinds {sorted(kinds)}")
         for t, tg, i, kind, desc, fl, by in rows[: a.top]:
