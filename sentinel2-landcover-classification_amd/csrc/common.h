@@ -21,7 +21,14 @@ constexpr int NTHREADS = 256;
 // v_exp_f32 + v_rcp_f32 (~1 ulp each): far inside the 1e-3 logits bar (measured 2e-5) and 3.6 % faster end to end than
 // expf + a true division.  Cost: the median fp32 gradient noise of a b0 train step (train-mode BatchNorm on 7x7 maps
 // amplifies every ulp) is 2.6x the fp32 oracle's own distance from float64 instead of 2.0x (tests/test_unet_gpu.py bars: 3x).
-__device__ __forceinline__ float silu_f(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+// -DS2K_EXACT_SILU (tools/exp_exact_silu.sh builds libs2k_exact.so with it; never the shipped library): expf + a true division, so
+// that what the fast form costs in parity terms is a measured table (profiles/r04_exact_silu.md), not a comment.
+#ifdef S2K_EXACT_SILU
+__device__ __forceinline__ float sigmoid_act(float u) { return 1.0f / (1.0f + expf(-u)); }
+#else
+__device__ __forceinline__ float sigmoid_act(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+#endif
+__device__ __forceinline__ float silu_f(float u) { return u * sigmoid_act(u); }
 
 // exact (erf) GELU, as nn.GELU() / F.gelu default (timm Mlp, prithvi_segmentation.py:58,62)
 __device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
@@ -60,7 +67,7 @@ __device__ __forceinline__ void dispatch_pro(int pro, F&& f) {
 // d act(u) / du for act in {none, silu, relu}
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (act == S2K_PRO_SILU) {
-        float s = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        float s = sigmoid_act(u);
         return s * (1.0f + u * (1.0f - s));
     }
     if (act == S2K_PRO_RELU) return u > 0.0f ? 1.0f : 0.0f;
