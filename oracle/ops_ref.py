@@ -170,7 +170,9 @@ def op_conv(m: Mem, o):
         st[0] += y.double().sum((0, 2, 3))
         st[1] += (y.double() ** 2).sum((0, 2, 3))
     if o.get("RES", -1) >= 0:
-        y = y + m.view(o["RES"], tuple(dst.shape), strides=tuple(dst.stride()))
+        res = m.view(o["RES"], tuple(dst.shape), strides=tuple(dst.stride()))
+        # FLAG_RES_GELU_GRAD: the backward of "GELU, then this Linear's transpose" in one stage - times gelu'(RES) instead of + RES
+        y = y * _act_grad(res, 4) if (o.get("_flags", 0) & 32) else y + res       # 32 = opdefs.FLAG_RES_GELU_GRAD
     if o["BETA"]:
         dst.add_(y)
     else:

@@ -75,6 +75,9 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     return 1.0f;
 }
 
+// CONV epilogue with RES: v + r, or v * act'(r) when the stage carries S2K_FLAG_RES_GELU_GRAD (res_mul = the activation; kernel-uniform)
+__device__ __forceinline__ float res_combine(float v, float r, int res_mul) { return res_mul ? v * act_grad(r, res_mul) : v + r; }
+
 // ---- bounds-checked buffer loads ----------------------------------------------------------------------
 // Operand tiles that hang over a tensor edge are fetched through a buffer descriptor sized to the tensor:
 // the hardware returns 0 for any offset beyond it, so the stagers keep ONE affine address stream (base +

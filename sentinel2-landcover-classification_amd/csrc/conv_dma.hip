@@ -370,7 +370,7 @@ static int launch_dma(ConvP& p, int n_ntiles, int splits, hipStream_t st) {
 // S2K_OK = launched, 1 = not one of this kernel's shapes, < 0 = error
 int launch_conv_dma(ConvP& p, hipStream_t st) {
     static const int enabled = tune_int("S2K_CONV_DMA", 1);
-    if (!enabled) return 1;
+    if (!enabled || p.res_mul) return 1;
     if (p.mode != S2K_MODE_CONV || p.KH != 1 || p.KW != 1 || p.S != 1 || p.C2 != 0 || p.gate1 || p.pro1 != S2K_PRO_NONE || p.x1_bf16) return 1;
     if ((p.HW & 3) || p.HO != p.H || p.WO != p.W) return 1;
     if (p.M < 40) return 1;                                   // thin layers at full resolution: the wide-pixel tiles of igemm.hip

@@ -364,7 +364,7 @@ static int launch_q4(ConvP& p, int n_ntiles, int splits, hipStream_t st) {
 // S2K_OK = launched, 1 = not one of this kernel's shapes, < 0 = error
 int launch_conv_q4(ConvP& p, hipStream_t st) {
     static const int enabled = tune_int("S2K_CONV_Q4", 1);
-    if (!enabled || !p.wtq) return 1;
+    if (!enabled || !p.wtq || p.res_mul) return 1;
     if (p.mode != S2K_MODE_CONV || p.KH != 1 || p.KW != 1 || p.S != 1 || p.C2 != 0 || p.gate1 || p.pro1 != S2K_PRO_NONE || p.x1_bf16) return 1;
     if ((p.HW & 3) || p.HO != p.H || p.WO != p.W) return 1;
     if (p.M < 24) return 1;

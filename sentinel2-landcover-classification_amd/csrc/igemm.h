@@ -11,6 +11,7 @@ struct ConvP {
     const float *x1, *bnv1, *gate1, *x2, *bnv2, *wt, *bias, *res;
     int x1_bf16;         // X1 is stored as bf16 (opdefs CONV.X1_BF16; only conv_bf16.hip's 1x1 kernel reads such a tensor)
     int tepi;            // conv_igemm_kernel: 1 = transposed (LDS) store of the output tile, set by its launcher
+    int res_mul;         // S2K_FLAG_RES_GELU_GRAD: the epilogue multiplies by act'(RES) (= S2K_PRO_GELU) instead of adding RES; else 0
     int force_dma;       // S2K_FLAG_DMA: the LDS-DMA ring kernel for every shape it supports (tests), not only where its routing rule sends a stage
     int exp;             // tuning builds only (S2K_CV_EXP): 1 = no epilogue (nothing stored), 2 = no MFMA loop
     const void* wtb;     // bf16 copy of the packed weights ([KP/8][T][MP][8], WEIGHT_PACK BF16_BASE) when the stage carries S2K_FLAG_BF16, else null

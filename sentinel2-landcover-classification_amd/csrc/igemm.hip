@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                     if (ok) {
                         if (p.bias) { const float bsv = p.bias[gm]; v[0] += bsv; v[1] += bsv; v[2] += bsv; v[3] += bsv; }
                         float* dst = p.y + gcol + (int64_t)gm * HWo;
-                        if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+                        if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] = res_combine(v[0], rv[0], p.res_mul); v[1] = res_combine(v[1], rv[1], p.res_mul); v[2] = res_combine(v[2], rv[2], p.res_mul); v[3] = res_combine(v[3], rv[3], p.res_mul); }
                         if (p.beta) { const f32x4 ov = *reinterpret_cast<const f32x4*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
                         *reinterpret_cast<f32x4*>(dst) = v;
                         s = (v[0] + v[1]) + (v[2] + v[3]);
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(NTHREADS, MINW) conv_igemm_kernel(const ConvP 
                 float v = acc[rm][rn][reg] + bs;
                 if (rok && cval[rn]) {
                     float* dst = p.y + ycol[rn] + (int64_t)gm * HWo;
-                    if (p.res) v += p.res[ycol[rn] + (int64_t)gm * HWo];
+                    if (p.res) v = res_combine(v, p.res[ycol[rn] + (int64_t)gm * HWo], p.res_mul);
                     if (p.beta) v += *dst;
                     *dst = v;
                     s += v;
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(NTHREADS) splitk_reduce_kernel(const ConvP p) 
     for (int i = lane; i < HWo; i += 64) {
         float v = bs;
         for (int k = 0; k < p.splits; ++k) v += p.scratch[(int64_t)k * p.y_elems + base + i];
-        if (p.res) v += p.res[base + i];
+        if (p.res) v = res_combine(v, p.res[base + i], p.res_mul);
         if (p.beta) v += p.y[base + i];
         p.y[base + i] = v;
         s += v;
@@ -741,6 +741,8 @@ int launch_conv(const S2kOp& op, const Ctx& c) {
     p.wtb = (op.flags & S2K_FLAG_BF16) ? ref_ptr<const void>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
     p.wtq = (!(op.flags & S2K_FLAG_BF16) && (op.flags & S2K_FLAG_Q4)) ? ref_ptr<const float>(c, op.t[S2K_CONV_T_WTB]) : nullptr;
     p.force_dma = (op.flags & S2K_FLAG_DMA) ? 1 : 0;
+    p.res_mul = (op.flags & S2K_FLAG_RES_GELU_GRAD) ? S2K_PRO_GELU : 0;
+    if (p.res_mul && (!p.res || (op.flags & S2K_FLAG_BF16))) { set_error("conv: S2K_FLAG_RES_GELU_GRAD needs RES and an f32 stage"); return S2K_EINVAL; }
     static const int cv_exp = tune_int("S2K_CV_EXP", 0);
     p.exp = cv_exp;
     const void* ptrs[] = {p.x1, p.bnv1, p.gate1, p.x2, p.bnv2, p.wt, p.bias, p.y, p.stats, p.res, p.scratch, p.wtb, p.wtq};

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
             if (ok) {
                 if (p.bias) { const float bsv = p.bias[gm]; v[0] += bsv; v[1] += bsv; v[2] += bsv; v[3] += bsv; }
                 float* dst = p.y + gcol + (int64_t)gm * HWo;
-                if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+                if (p.res) { const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + gcol + (int64_t)gm * HWo); v[0] = res_combine(v[0], rv[0], p.res_mul); v[1] = res_combine(v[1], rv[1], p.res_mul); v[2] = res_combine(v[2], rv[2], p.res_mul); v[3] = res_combine(v[3], rv[3], p.res_mul); }
                 if (p.beta) { const f32x4 ov = *reinterpret_cast<const f32x4*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
                 *reinterpret_cast<f32x4*>(dst) = v;
                 s = (v[0] + v[1]) + (v[2] + v[3]);
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(512) conv_pc_kernel(const ConvP p) {
                     float v = acc[rm][rn][reg] + bs;
                     if (rok && cval[rn]) {
                         float* dst = p.y + ycol[rn] + (int64_t)gm * HWo;
-                        if (p.res) v += p.res[ycol[rn] + (int64_t)gm * HWo];
+                        if (p.res) v = res_combine(v, p.res[ycol[rn] + (int64_t)gm * HWo], p.res_mul);
                         if (p.beta) v += *dst;
                         *dst = v;
                         s += v;

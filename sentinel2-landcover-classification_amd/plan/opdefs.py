@@ -42,6 +42,9 @@ FLAG_SIDE, FLAG_JOIN = 1, 2      # S2kOp.flags (see s2k_program_run: side-stream
 FLAG_BF16 = 4
 FLAG_Q4 = 16        # CONV (f32 plans): WTB holds the f32 "quad" copy of WT that WEIGHT_PACK wrote (Q4_BASE): [KP / 8][MP][8] with the eight
                     # channels of a group in the order (k & 1) * 4 + (k >> 1) - the A-operand layout of csrc/conv_q4.hip
+FLAG_RES_GELU_GRAD = 32   # CONV with RES: Y = (conv + bias) * gelu'(RES) instead of + RES - the backward of "GELU then Linear" in one stage
+                    # (fc2's data gradient times gelu'(fc1 output): timm Mlp, prithvi.py:162-183), f32 plans; the producer / consumer and
+                    # generic kernels implement it, the other CONV kernels decline such a stage
 FLAG_DMA = 8        # CONV: take the LDS-DMA ring kernel (csrc/conv_dma.hip) for every shape it supports, not only where its launcher's
                     # measured routing rule sends a stage (tests cover all of its tiles this way; plans leave the choice to the launcher)
 

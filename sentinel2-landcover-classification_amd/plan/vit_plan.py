@@ -21,6 +21,8 @@ bias and LayerNorm-parameter gradients summed over NS columns equal the sums ove
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 
 from . import opdefs as D
@@ -181,6 +183,12 @@ def seg_layout(s: SegSpec) -> ParamLayout:
     return L
 
 
+# fc2's data gradient multiplied by gelu'(fc1 output) in the CONV epilogue (FLAG_RES_GELU_GRAD) instead of a separate ACT_BWD pass.
+# Implemented and tested (op level: tests/test_ops_gpu.py::test_conv1x1_times_gelu_grad_of_res; plan level: test_vit_plan_cpu.py), OFF by
+# default: the MAE backward is bound by MFMA capacity - the side stream's weight gradients fill the chip while the main stream runs the
+# HBM-bound ACT_BWD, so removing that pass frees nothing, and the erf in the epilogue lengthens the MFMA kernel instead (alternating
+# runs on one box, tools/exp_gelu_fuse.sh: 1471.0 samples/s fused vs 1473.0 separate)
+FUSE_GELU_GRAD = os.environ.get("S2LC_FUSE_GELU_GRAD", "0") == "1"
 _ROW_ALIGN = 4      # floats; 8 while a bf16-mixed plan is being built (the bf16 weight-gradient kernel contracts pixel OCTETS)
 
 
@@ -229,9 +237,11 @@ class _V:
         return y
 
     def linear_bwd(self, wname: str, bname: str | None, x: TRef, dy: TRef, K: int, M: int, N: int, pro: int = D.PRO_NONE,
-                   dx: TRef | None = None, dx_beta: int = 0, bias_sum: bool = True) -> None:
+                   dx: TRef | None = None, dx_beta: int = 0, bias_sum: bool = True, dx_gelu_of: TRef | None = None) -> None:
         """weight / bias gradients (when trainable) and, if `dx` is given, the input gradient w.r.t. pro(x).
-        bias_sum=False: the bias gradient (the row sums of dy) is produced by the stage that wrote dy (CHAN_LN_BWD's DSUM)."""
+        bias_sum=False: the bias gradient (the row sums of dy) is produced by the stage that wrote dy (CHAN_LN_BWD's DSUM).
+        dx_gelu_of: x = gelu(that tensor) - the data-gradient stage multiplies by gelu'(it) in its epilogue (FLAG_RES_GELU_GRAD), so dx
+        is the gradient w.r.t. the tensor BEFORE the GELU (no separate ACT_BWD pass over dx)."""
         p, B = self.p, self.p.B
         if self.trainable(wname):
             # [M][K] scratch layout = the Linear weight's layout: accumulate straight into the gradient buffer (no finalize pass)
@@ -242,9 +252,12 @@ class _V:
                 p.bwd.add("CHANNEL_SUM", G=dy, OUT=p.pgrad(bname), B=B, C=M, HW=N)
         if dx is not None:
             wp, MP = p.pack_weight("bwd", wname, K, M, 1, 1, K, 1, 0)
-            p.bwd.add("CONV", X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=dx, STATS=None, RES=None,
+            if dx_gelu_of is not None and dx_beta:
+                raise ValueError("a data gradient through a GELU is written, not accumulated")
+            p.bwd.add("CONV", X1=dy, BNV1=None, GATE1=None, X2=None, BNV2=None, WT=wp, BIAS=None, Y=dx, STATS=None, RES=dx_gelu_of,
                       B=B, C1=M, C2=0, H=1, W=N, M=K, KH=1, KW=1, STRIDE=1, PAD_T=0, PAD_L=0, HO=1, WO=N, PRO1=D.PRO_NONE, PRO2=0,
-                      MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=dx_beta, YC=K, NREP=1)
+                      MODE=D.MODE_CONV, W_SM=1, W_SK=MP, W_ST=MP, FLIP=0, BETA=dx_beta, YC=K, NREP=1,
+                      **({"_flags": D.FLAG_RES_GELU_GRAD} if dx_gelu_of is not None else {}))
 
     def ln_fwd(self, prefix: str, x: TRef, C: int, N: int, eps: float):
         p, B = self.p, self.p.B
@@ -297,8 +310,11 @@ class _V:
         p, B = self.p, self.p.B
         pre, Dm, heads, hidden, N = r["prefix"], r["Dm"], r["heads"], r["hidden"], r["N"]
         g_f1 = p.alloc("g:f1:" + pre, (B, hidden, N))
-        self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1, bias_sum=False)
-        p.bwd.add("ACT_BWD", G=g_f1, X=r["f1"], COUNT=B * hidden * N, ACT=D.ACT_GELU)
+        if getattr(p, "bf16", False) or not FUSE_GELU_GRAD:       # the bf16 kernels' epilogues add RES only: GELU' as its own pass
+            self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1, bias_sum=False)
+            p.bwd.add("ACT_BWD", G=g_f1, X=r["f1"], COUNT=B * hidden * N, ACT=D.ACT_GELU)
+        else:            # fc2's data gradient comes out already multiplied by gelu'(fc1 output): one pass over [B][hidden][N] less
+            self.linear_bwd(pre + ".mlp.fc2.weight", pre + ".mlp.fc2.bias", r["a1"], g, hidden, Dm, N, dx=g_f1, bias_sum=False, dx_gelu_of=r["f1"])
         g_h = p.alloc("g:h:" + pre, (B, Dm, N))       # shared scratch for both LayerNorm output gradients
         self.linear_bwd(pre + ".mlp.fc1.weight", pre + ".mlp.fc1.bias", r["h2"], g_f1, Dm, hidden, N, dx=g_h)
         g_mid = p.alloc("g:mid:" + pre, (B, Dm, N))   # d loss / d (x + attention branch)

@@ -125,7 +125,7 @@ def test_mfma_lane_maps_exact():
 # CONV (implicit GEMM)
 # ---------------------------------------------------------------------------------------------------
 def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias, stats, beta=0, mode=0, flip=0,
-               strides=None, seed=0, tol=1e-4, yc=None, bf16=False, res=False, scratch=False, want_variant=None):
+               strides=None, seed=0, tol=1e-4, yc=None, bf16=False, res=False, scratch=False, want_variant=None, res_gelu=False):
     """bf16: the stage carries FLAG_BF16 + the bf16 weight copy, must run on the bf16 MFMA kernels (csrc/conv_bf16.hip) and is
     compared with the oracle on bf16-ROUNDED operands (f32 products and sums): what is left is f32 summation order, so the
     tolerance stays 1e-4 - rounding of the operands is arithmetic the oracle states too, not kernel error."""
@@ -158,13 +158,15 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     outs = ["y"] + (["stats"] if stats else [])
     extra = {}
     if res:
-        extra["RES"] = c.t("res", (B, YC, Ho, Wo))
+        extra["RES"] = c.t("res", (B, YC, Ho, Wo), scale=1.5)
+    if res_gelu:      # Y = (conv + bias) * gelu'(RES) instead of + RES
+        extra["_flags"] = D.FLAG_RES_GELU_GRAD
     if scratch:
         extra["SCRATCH"] = c.t("scratch", (8 * B * YC * Ho * Wo,), "nan")
     if want_variant is not None:
         extra["want_variant"] = want_variant
         if want_variant == 3:
-            extra["_flags"] = D.FLAG_DMA           # every tile of the LDS-DMA ring kernel, not only the shapes its routing rule takes
+            extra["_flags"] = extra.get("_flags", 0) | D.FLAG_DMA           # every tile of the LDS-DMA ring kernel, not only the shapes its routing rule takes
     if bf16:
         # An activated value within an ulp of a bf16 rounding boundary may round to the other neighbour on the GPU (its SiLU is
         # v_exp + v_rcp, its BatchNorm affine one fma): one operand then differs by 2^-8 relative.  Over a long reduction a few
@@ -183,6 +185,21 @@ def _conv_case(B, C1, C2, H, W, M, k, s, pt, pl, Ho, Wo, pro1, pro2, gate, bias,
     c.run("CONV", outs, tol, sum0=("stats",), pre=[pre], NREP=nrep, X1=x1, BNV1=bnv1, GATE1=g1, X2=x2, BNV2=bnv2, WT=wp,
           BIAS=bs, Y=y, STATS=st_ref, B=B, C1=C1, C2=C2, H=H, W=W, M=M, KH=k, KW=k, STRIDE=s, PAD_T=pt, PAD_L=pl, HO=Ho,
           WO=Wo, PRO1=pro1, PRO2=pro2, MODE=mode, W_SM=1, W_SK=T * MP, W_ST=MP, FLIP=0, BETA=beta, YC=YC, **extra)
+
+
+@pytest.mark.parametrize("B,C1,H,W,M,bias,beta,want", [
+    (64, 768, 1, 52, 3072, False, 0, 1),       # fc2's data gradient of the MAE encoder (tokens as a 1 x N map): producer / consumer kernel
+    (16, 512, 1, 200, 2048, True, 0, 1),
+    (3, 512, 1, 200, 2048, True, 0, None),     # few tokens: whatever the launcher picks
+    (2, 256, 7, 9, 96, False, 0, None),        # ragged pixels, HW % 4 != 0: scalar epilogues
+    (2, 48, 16, 16, 72, True, 1, 0),           # short reduction: the generic kernel, accumulate on top
+    (2, 1824, 8, 8, 304, False, 0, None),      # few pixels, deep reduction: whatever the launcher picks must honour the flag (split-K tail)
+])
+def test_conv1x1_times_gelu_grad_of_res(B, C1, H, W, M, bias, beta, want):
+    """S2K_FLAG_RES_GELU_GRAD: Y = (conv + bias) * gelu'(RES) - fc2's data gradient through the GELU in one stage (plan/vit_plan.py
+    block_bwd; timm Mlp via prithvi.py:162-183).  Kernels that do not implement it must decline the stage."""
+    _conv_case(B, C1, 0, H, W, M, 1, 1, 0, 0, H, W, 0, 0, False, bias=bias, stats=False, beta=beta, res=True, res_gelu=True,
+               scratch=(C1 >= 1024), want_variant=want, seed=B + M)
 
 
 @pytest.mark.parametrize("B,M,C,H,W", [(4, 240, 40, 16, 16), (3, 24, 48, 20, 28), (2, 40, 240, 64, 64), (5, 1056, 176, 8, 16), (2, 32, 16, 64, 64),

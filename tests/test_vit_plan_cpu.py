@@ -9,6 +9,7 @@ import torch
 import s2lc_amd  # noqa: F401
 from oracle import losses_ref
 from oracle import prithvi_ref as P
+from s2lc_amd.plan import opdefs as D
 from s2lc_amd.plan import vit_plan as V
 from tests.helpers import MAE_CASES, SEG_CASES, mae_inputs, rel_err, seg_inputs
 from tests.plan_harness import emulate, flat_from_state, fview, make_bases_vit, out_view
@@ -38,13 +39,20 @@ def _check_grads(plan, grads, sd64, tol, skip=()):
     return worst
 
 
-@pytest.mark.parametrize("tag,wide,norm_pix", [("small_bs2", True, False), ("small_t3_bs2", True, True), ("small_bs2", False, False)])
-def test_mae_programs_match_oracle(tag, wide, norm_pix):
+@pytest.mark.parametrize("tag,wide,norm_pix,fuse_gelu", [("small_bs2", True, False, False), ("small_t3_bs2", True, True, False), ("small_bs2", False, False, False),
+                                                        ("small_bs2", True, False, True), ("small_bs2", False, False, True)])
+def test_mae_programs_match_oracle(tag, wide, norm_pix, fuse_gelu, monkeypatch):
+    """fuse_gelu: fc2's data gradient times gelu'(fc1 output) in the CONV epilogue (FLAG_RES_GELU_GRAD; off by default, see
+    plan/vit_plan.py block_bwd) instead of a separate ACT_BWD stage - the same gradients."""
+    monkeypatch.setattr(V, "FUSE_GELU_GRAD", fuse_gelu)
     cfg, sd, x, noise, ratio = mae_inputs(tag)
     cfg.norm_pix_loss = norm_pix
     B = x.shape[0]
     spec = _mae_spec(cfg)
     plan = V.plan_mae(spec, B, ratio, True)
+    n_fused = sum(1 for k, f in plan.bwd.ops if k == "CONV" and f.get("_flags", 0) & D.FLAG_RES_GELU_GRAD)
+    n_act = sum(1 for k, f in plan.bwd.ops if k == "ACT_BWD")
+    assert (n_fused > 0 and n_act == 0) if fuse_gelu else (n_fused == 0 and n_act > 0)
     dt = torch.float64 if wide else torch.float32
     fp, fb = flat_from_state(plan.layout, sd)
     bases = make_bases_vit(plan, fp, fb, x, noise, wide)
