@@ -39,7 +39,7 @@ struct LnP {
     float* dsum;            // backward: DSUM[c] += sum of the new DX values (a bias gradient), or null
     int B, C, HW, tiles_per_b, accum;
     float eps;
-    int dbg;                       // tuning build: S2K_LN_DBG bit 0 skips the all-channel sums, bit 1 the normalising pass, bit 2 the parameter sums
+    int dbg;                       // tuning build: S2K_LN_DBG bit 0 skips the all-channel sums, bit 1 the normalising pass (timing only)
     int qw, rw, pgroups, csplit;   // row kernels: 16-byte columns per position group, rows per wave, groups, channel splits
 };
 
@@ -164,137 +164,19 @@ __global__ void __launch_bounds__(64 * LNR_NW) chan_ln_fwd_rows_kernel(const LnP
     }
 }
 
-__global__ void __launch_bounds__(64 * LNR_NW) chan_ln_bwd_rows_kernel(const LnP p) {
-    extern __shared__ __attribute__((aligned(16))) float lsm[];
-    float(*red)[64][8] = reinterpret_cast<float(*)[64][8]>(lsm);                    // [LNR_NW][64][8]
-    float(*tot)[8] = reinterpret_cast<float(*)[8]>(lsm + LNR_NW * 64 * 8);           // [64][8]
-    float* part = lsm + LNR_NW * 64 * 8 + 64 * 8;                                    // [rows of this channel split][3]
-    LnRowsWg g;
-    if (!ln_rows_wg(p, g)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool want_p = p.dgamma != nullptr && !(p.dbg & 4), want_d = p.dsum != nullptr && !(p.dbg & 4);
-    const float* acc_src = p.dxin ? p.dxin : p.dx;
-    const int rpi = LNR_NW * p.rw;
-    const int rows_cs = (p.C + p.csplit - 1) / p.csplit;
-    const int c_lo = g.cs * rows_cs, c_hi = min(p.C, c_lo + rows_cs);
-    for (int i = threadIdx.x; i < rows_cs * 3; i += 64 * LNR_NW) part[i] = 0.0f;
-    const int64_t base = (int64_t)g.b * p.C * p.HW + (g.on ? g.col * 4 : 0);
-    const int row0 = wave * p.rw + (g.on ? g.r : 0);
-    float mean[4], rstd[4];
-    {
-        const float4* mr = reinterpret_cast<const float4*>(p.mr_in + ((int64_t)g.b * p.HW + (g.on ? g.col * 4 : 0)) * 2);
-        const float4 m0 = mr[0], m1 = mr[1];
-        mean[0] = m0.x; rstd[0] = m0.y; mean[1] = m0.z; rstd[1] = m0.w;
-        mean[2] = m1.x; rstd[2] = m1.y; mean[3] = m1.z; rstd[3] = m1.w;
-    }
-    float s1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, s2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int crot = (p.C + rpi * LNR_US - 1) / (rpi * LNR_US) * (rpi * LNR_US);       // (see the forward kernel: rotated start per channel split)
-    for (int i0 = row0; i0 - row0 < p.C && !(p.dbg & 1); i0 += rpi * LNR_US) {
-        float4 dv[LNR_US], xv[LNR_US];
-        float ga[LNR_US];
-        int cc[LNR_US];
-#pragma unroll
-        for (int u = 0; u < LNR_US; ++u) {
-            int c = c_lo + i0 + rpi * u;
-            cc[u] = c >= crot ? c - crot : c;
-            c = min(cc[u], p.C - 1);
-            dv[u] = *reinterpret_cast<const float4*>(p.dy + base + (int64_t)c * p.HW);
-            xv[u] = *reinterpret_cast<const float4*>(p.x + base + (int64_t)c * p.HW);
-            ga[u] = p.gamma[c];
-        }
-#pragma unroll
-        for (int u = 0; u < LNR_US; ++u) {
-            const float gm = (g.on && cc[u] < p.C) ? ga[u] : 0.0f;
-            const float d[4] = {dv[u].x * gm, dv[u].y * gm, dv[u].z * gm, dv[u].w * gm};
-            const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s1[j] += d[j];
-                s2[j] = fmaf(d[j], (x[j] - mean[j]) * rstd[j], s2[j]);
-            }
-        }
-    }
-    for (int off = 1; off < p.rw; off <<= 1) {       // the wave's row slots (shuffle tree over r), then the waves through LDS
-        const bool take = (g.r & (2 * off - 1)) == 0 && g.r + off < p.rw;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = __shfl_down(s1[j], off * p.qw), b = __shfl_down(s2[j], off * p.qw);
-            s1[j] += take ? a : 0.0f;
-            s2[j] += take ? b : 0.0f;
-        }
-    }
-    if (lane < p.qw) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { red[wave][lane][j] = s1[j]; red[wave][lane][4 + j] = s2[j]; }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < p.qw * 8) {
-        const int q2 = threadIdx.x >> 3, v = threadIdx.x & 7;
-        float a = 0.0f;
-#pragma unroll
-        for (int w = 0; w < LNR_NW; ++w) a += red[w][q2][v];
-        tot[q2][v] = a;
-    }
-    __syncthreads();
-    const float invC = 1.0f / p.C;
-    float m1[4], m2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { m1[j] = tot[g.on ? g.q : 0][j] * invC; m2[j] = tot[g.on ? g.q : 0][4 + j] * invC; }
-    for (int c0 = c_lo + row0; c0 - row0 < c_hi && !(p.dbg & 2); c0 += rpi * LNR_U) {
-        float4 dv[LNR_U], xv[LNR_U], ov[LNR_U];
-#pragma unroll
-        for (int u = 0; u < LNR_U; ++u) {
-            const int64_t off = base + (int64_t)min(c0 + rpi * u, p.C - 1) * p.HW;
-            dv[u] = *reinterpret_cast<const float4*>(p.dy + off);
-            xv[u] = *reinterpret_cast<const float4*>(p.x + off);
-            ov[u] = p.accum ? *reinterpret_cast<const float4*>(acc_src + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // kernel-uniform
-        }
-#pragma unroll
-        for (int u = 0; u < LNR_U; ++u) {
-            const int c = c0 + rpi * u;
-            if (g.on && c < c_hi) {
-                const float gm = p.gamma[c];
-                const float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
-                const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-                const float o[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
-                float nv[4], sg = 0.0f, sb = 0.0f, sd = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = (x[j] - mean[j]) * rstd[j];
-                    nv[j] = rstd[j] * (d[j] * gm - m1[j] - xh * m2[j]) + o[j];
-                    sg = fmaf(d[j], xh, sg);
-                    sb += d[j];
-                    sd += nv[j];
-                }
-                *reinterpret_cast<float4*>(p.dx + base + (int64_t)c * p.HW) = make_float4(nv[0], nv[1], nv[2], nv[3]);
-                float* pr = part + (c - c_lo) * 3;
-                if (want_p) { atomicAdd(pr, sg); atomicAdd(pr + 1, sb); }
-                if (want_d) atomicAdd(pr + 2, sd);
-            }
-        }
-    }
-    if (want_p || want_d) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < c_hi - c_lo; i += 64 * LNR_NW) {
-            if (want_p) {
-                atomicAdd(p.dgamma + c_lo + i, part[i * 3]);
-                atomicAdd(p.dbeta + c_lo + i, part[i * 3 + 1]);
-            }
-            if (want_d) atomicAdd(p.dsum + c_lo + i, part[i * 3 + 2]);
-        }
-    }
-}
-
 // geometry of the row kernels, or false when the tile kernels should run (rows not a multiple of 16 bytes, tiny or long rows)
 static bool ln_rows_geometry(LnP& p, std::initializer_list<const void*> ptrs) {
-    static const int enabled = tune_int("S2K_LN_ROWS", 1);
+    static const int enabled = tune_int("S2K_LN_ROWS", 1);      // 0: tile kernel only; 4: every supported shape (tests, tools/exp_ln.sh)
+    // Used where the tile kernel leaves most of the chip idle - one 64-position tile per sample, few samples - and only in the FORWARD.
+    // Back-to-back launches (tools/exp_ln.sh): 64 x [768][52] 17 -> 12 us; 64 x [512][200] and 64 x [768][196]: equal.  A backward
+    // kernel of the same form existed in round 4 (35 -> 24 us alone, 11 of them the 3 C atomics of every workgroup, which are 64-byte
+    // memory transactions) and was removed: inside the MAE step it LOST (alternating runs, tools/exp_ln_step.sh: forward only
+    // 44.79 ms, neither 45.01, both 45.20) - the backward is bound by MFMA capacity, the side stream's weight gradients want the CUs
+    // that 256 x 1,024 LayerNorm threads occupied, while the tile kernel's 64 workgroups leave them three quarters of the chip.
     static const int dbg = tune_int("S2K_LN_DBG", 0);
     p.dbg = dbg;
-    // worth it only where the tile kernels leave most of the chip idle: one 64-position tile per sample and few samples (measured,
-    // tools/exp_ln.sh, back-to-back launches: 64 x [768][52] backward 35 -> 24 us, forward 17 -> 12; 64 x [512][200] and
-    // 64 x [768][196]: forward equal, backward slower - the 3 C atomics of every workgroup are 64-byte memory transactions,
-    // 11 of the 24 us, and four times as many workgroups send them).  S2K_LN_ROWS=2 (tuning build) takes every supported shape.
-    if (!enabled || (p.HW & 3) || p.HW < 32 || p.HW > 1024 || p.C < 64 || (enabled != 2 && (p.HW > 64 || p.B >= 128))) return false;
+    const bool all = enabled == 4;
+    if (!enabled || (p.HW & 3) || p.HW < 32 || p.HW > 1024 || p.C < 64 || (!all && (p.HW > 64 || p.B >= 128))) return false;
     for (const void* q : ptrs)
         if (reinterpret_cast<uintptr_t>(q) & 15) return false;
     const int ncol = p.HW >> 2;
@@ -510,14 +392,6 @@ int launch_chan_ln_bwd(const S2kOp& op, const Ctx& c) {
     p.accum = op.d[S2K_CHAN_LN_BWD_D_ACCUM];
     if (!p.dy || !p.x || !p.mr_in || !p.gamma || !p.dx || p.B <= 0 || p.C <= 0 || p.HW <= 0 || (!p.dgamma != !p.dbeta)) {
         set_error("chan_ln_bwd: bad args"); return S2K_EINVAL;
-    }
-    if (ln_rows_geometry(p, {p.x, p.dy, p.dx, p.mr_in, p.dxin})) {
-        const unsigned grid = 8u * (unsigned)(p.pgroups * p.csplit) * (unsigned)cdiv(p.B, 8);
-        const size_t lds_rows = ((size_t)LNR_NW * 64 * 8 + 64 * 8 + 3 * (size_t)cdiv(p.C, p.csplit)) * sizeof(float);
-        if (lds_rows <= 64 * 1024) {
-            hipLaunchKernelGGL(chan_ln_bwd_rows_kernel, dim3(grid), dim3(64 * LNR_NW), lds_rows, c.stream, p);
-            return S2K_OK;
-        }
     }
     p.tiles_per_b = cdiv(p.HW, 64);
     const int64_t tiles = (int64_t)p.B * p.tiles_per_b;

@@ -14,7 +14,7 @@ from tests.test_ops_gpu import Case
 pytestmark = pytest.mark.gpu
 
 
-# HW % 4 == 0 with C >= 64 runs the row kernels (a sample shared by position groups x channel splits), the rest the tile kernels
+# forward: HW % 4 == 0, HW <= 64, C >= 64 and B < 128 run the row kernel (a sample shared by channel splits), the rest the tile kernel
 LN_ROW_SHAPES = [(3, 768, 52), (2, 512, 200), (9, 130, 36), (17, 64, 32), (1, 1000, 1024), (2, 96, 196), (64, 768, 52)]
 
 
