@@ -50,8 +50,8 @@ PRITHVI_GFLOP_PER_SAMPLE = {"mae": 59.8, "seg_frozen": 804.0, "seg_unfrozen": 87
 
 KERNEL_OF = {("CONV", 0): "conv_igemm_kernel", ("CONV", 1): "conv_pc_kernel", ("WGRAD", 0): "wgrad_kernel", ("WGRAD", 1): "wgrad_pc_kernel",
              ("CONV", 2): "conv_bf16_kernel", ("WGRAD", 2): "wgrad_bf16_kernel",      # variant 2: bf16 MFMA operands (bf16-mixed plans only)
-             ("CONV", 3): "conv_dma_kernel",
-             ("CONV", 4): "conv_q4_kernel"}                                             # variant 4: the quad-layout 1x1 kernel (csrc/conv_q4.hip)                                            # variant 3: the LDS-DMA ring kernel (csrc/conv_dma.hip)
+             ("CONV", 3): "conv_dma_kernel",                                            # variant 3: the LDS-DMA ring kernel (csrc/conv_dma.hip)
+             ("CONV", 4): "conv_q4_kernel", ("WGRAD", 4): "wgrad_q4_kernel"}            # variant 4: the quad-read 1x1 kernels (csrc/conv_q4.hip, wgrad_q4.hip)
 
 
 def stage_work(rec, D):

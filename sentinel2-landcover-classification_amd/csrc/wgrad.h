@@ -23,6 +23,8 @@ struct WgradP {
 // wgrad_pc.hip: returns S2K_OK when it launched the stage, 1 when the shape is not one of its instantiations (the caller
 // then takes the generic kernel), or a negative error code
 int launch_wgrad_pc(WgradP& p, int mode, hipStream_t st);
+// wgrad_q4.hip (1x1 / Linear weight gradients with H * W % 4 == 0: quad operand reads): same return convention
+int launch_wgrad_q4(WgradP& p, int mode, hipStream_t st);
 // wgrad_bf16.hip (stages carrying S2K_FLAG_BF16 in bf16-mixed plans): same return convention
 int launch_wgrad_bf16(WgradP& p, int mode, hipStream_t st);
 

@@ -488,6 +488,10 @@ int launch_wgrad(const S2kOp& op, const Ctx& c) {
         set_error("wgrad: P_BF16 on a stage the bf16 1x1 kernel does not take (FLAG_BF16 missing or shape not in its list)");
         return S2K_EINVAL;
     }
+    {   // 1x1 / Linear weight gradients whose pixel rows are 16-byte multiples: the quad-read producer / consumer kernel (wgrad_q4.hip)
+        const int rc = launch_wgrad_q4(p, mode, st);
+        if (rc != 1) return rc;
+    }
     {   // the MFMA-bound shapes run on the producer / consumer kernels (wgrad_pc.hip); 1 = not one of theirs
         const int rc = launch_wgrad_pc(p, mode, st);
         if (rc != 1) return rc;
