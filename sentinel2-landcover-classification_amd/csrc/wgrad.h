@@ -17,6 +17,7 @@ struct WgradP {
     int NP;                      // pixels per chunk (PIX / GATHER)
     int R, XW, XWe, tiles_x, tiles_y, IR, IC, WS, CSQ, PSTR;
     int p_bf16;                  // P is stored as bf16 (opdefs WGRAD.P_BF16; only wgrad_bf16.hip's 1x1 kernel reads such a tensor)
+    int streamk;                 // wgrad_q4.hip: equal ranges of the (output tile, pixel tile) list per workgroup instead of pixel splits of one tile
     int exp;                     // tuning builds only (S2K_WG_EXP): 1 = stage the first tile only, 2 = no combine, 4 = no MFMA loop
 };
 

@@ -45,50 +45,65 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int mc = p.n_mtiles * p.n_ctiles;
     const int v = wg_xcd_remap(blockIdx.x, gridDim.x);
-    const int split = v / mc, tl = v - split * mc;
-    const int mt = tl % p.n_mtiles, ct = tl / p.n_mtiles;
-    const int m0 = mt * BM, c0 = ct * BC;
-    const int tile_begin = split * p.tiles_per_split;
-    const int tile_end = min(tile_begin + p.tiles_per_split, p.ntiles);
-    if (tile_begin >= tile_end) return;            // (whole workgroup)
+    // This workgroup's work: units [u0, u1) of the list of (output tile tl, 64-pixel tile) pairs, output-tile major.  Split form: the
+    // pixel tiles [split * tiles_per_split, ...) of ONE output tile.  Stream form (p.streamk: the launcher picks it where whole rounds
+    // of 256 workgroups fit badly - 144 output tiles of 52 pixel tiles cost 3 rounds x 13 units split five ways, 29.25 + 2 flushes
+    // here): the list is cut into gridDim.x equal ranges, which may cross into the next output tile(s); the accumulators are
+    // flushed (float atomics, as ever) at every crossing.
+    int u0, u1;
+    if (p.streamk) {
+        const int64_t total = (int64_t)mc * p.ntiles;
+        u0 = (int)(total * v / gridDim.x);
+        u1 = (int)(total * (v + 1) / gridDim.x);
+    } else {
+        const int split = v / mc, tl = v - split * mc;
+        const int tb = split * p.tiles_per_split;
+        u0 = tl * p.ntiles + tb;
+        u1 = tl * p.ntiles + min(tb + p.tiles_per_split, p.ntiles);
+    }
+    if (u0 >= u1) return;                          // (whole workgroup)
 
     if (producer) {
         // =================================================================================================================
         // PRODUCER thread: pixel quad q = tid & 15 of rows r + 16 i (r = tid >> 4) of both images
         // =================================================================================================================
         const int q = tid & 15, r = tid >> 4;
-        const int64_t ntot = (int64_t)p.B * p.HWp;
+        const uint32_t ntot = (uint32_t)p.B * (uint32_t)p.HWp;      // < 2^31 (launcher): 32-bit index arithmetic throughout - a 64-bit
+                                                                     // division is ~150 instructions, and a producer gets about one per MFMA
         const bool img_local = (p.HWp % NPJ) == 0;
         float psc[NMP], psh[NMP], qsc[NCP], qsh[NCP];
         uint32_t prow[NMP], qrow[NCP];              // byte offset of the (clamped) row inside an image
+        auto set_rows = [&](int tl) {               // the output tile's rows: once per segment
+            const int m0 = (tl % p.n_mtiles) * BM, c0 = (tl / p.n_mtiles) * BC;
 #pragma unroll
-        for (int i = 0; i < NMP; ++i) {
-            const int gm = min(m0 + r + 16 * i, p.M - 1);      // rows past M re-read the last one (they feed discarded outputs)
-            prow[i] = (uint32_t)gm * (uint32_t)p.HWp * 4u;
-            psc[i] = PROP != S2K_PRO_NONE ? p.bnvp[gm] : 1.0f;
-            psh[i] = PROP != S2K_PRO_NONE ? p.bnvp[p.M + gm] : 0.0f;
-        }
+            for (int i = 0; i < NMP; ++i) {
+                const int gm = min(m0 + r + 16 * i, p.M - 1);      // rows past M re-read the last one (they feed discarded outputs)
+                prow[i] = (uint32_t)gm * (uint32_t)p.HWp * 4u;
+                psc[i] = PROP != S2K_PRO_NONE ? p.bnvp[gm] : 1.0f;
+                psh[i] = PROP != S2K_PRO_NONE ? p.bnvp[p.M + gm] : 0.0f;
+            }
 #pragma unroll
-        for (int j = 0; j < NCP; ++j) {
-            const int gc = min(c0 + r + 16 * j, p.C - 1);
-            qrow[j] = (uint32_t)gc * (uint32_t)p.HWq * 4u;
-            qsc[j] = PROQ != S2K_PRO_NONE ? p.bnvq[gc] : 1.0f;
-            qsh[j] = PROQ != S2K_PRO_NONE ? p.bnvq[p.C + gc] : 0.0f;
-        }
+            for (int j = 0; j < NCP; ++j) {
+                const int gc = min(c0 + r + 16 * j, p.C - 1);
+                qrow[j] = (uint32_t)gc * (uint32_t)p.HWq * 4u;
+                qsc[j] = PROQ != S2K_PRO_NONE ? p.bnvq[gc] : 1.0f;
+                qsh[j] = PROQ != S2K_PRO_NONE ? p.bnvq[p.C + gc] : 0.0f;
+            }
+        };
         f32x4 preg[NMP], qreg[NCP];
         float bound = 0.0f;                          // of the tile held in preg / qreg
         auto fetch = [&](int tile) {
-            const int64_t n = (int64_t)tile * NPJ + 4 * q;
+            const uint32_t n = (uint32_t)tile * NPJ + 4u * q;
             const bool ok = n < ntot;                // HWp % 4 == 0: a quad is inside one image and entirely valid or not
-            const int64_t nn = ok ? n : 0;
-            const int b = (int)(nn / p.HWp);
-            const int pp = (int)(nn - (int64_t)b * p.HWp);
+            const uint32_t nn = ok ? n : 0u;
+            const uint32_t b = nn / (uint32_t)p.HWp;
+            const uint32_t pp = nn - b * (uint32_t)p.HWp;
             // descriptors based at the first image this pixel tile touches (uniform): offsets span the tile's images only
-            const int bt = (int)(((int64_t)tile * NPJ) / p.HWp);
-            const rsrc_t rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - bt) * p.M * p.HWp * 4);
-            const rsrc_t rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - bt) * p.C * p.HWq * 4);
-            const uint32_t pv = ok ? (uint32_t)((int64_t)(b - bt) * p.M * p.HWp + pp) * 4u : BUF_OOB;
-            const uint32_t qv = ok ? (uint32_t)((int64_t)(b - bt) * p.C * p.HWq + pp) * 4u : BUF_OOB;
+            const uint32_t bt = __builtin_amdgcn_readfirstlane(((uint32_t)tile * NPJ) / (uint32_t)p.HWp);
+            const rsrc_t rp = make_rsrc(p.p + (int64_t)bt * p.M * p.HWp, (int64_t)(img_local ? 1 : p.B - (int)bt) * p.M * p.HWp * 4);
+            const rsrc_t rq = make_rsrc(p.q + (int64_t)bt * p.C * p.HWq, (int64_t)(img_local ? 1 : p.B - (int)bt) * p.C * p.HWq * 4);
+            const uint32_t pv = ok ? ((b - bt) * (uint32_t)p.M * (uint32_t)p.HWp + pp) * 4u : BUF_OOB;       // (< 2 GiB: the launcher's span check)
+            const uint32_t qv = ok ? ((b - bt) * (uint32_t)p.C * (uint32_t)p.HWq + pp) * 4u : BUF_OOB;
 #pragma unroll
             for (int i = 0; i < NMP; ++i) preg[i] = bload4(rp, pv + prow[i]);     // BUF_OOB + a row offset (< 2^31) stays out of range: no select,
                                                                               // which hipcc would turn into a branch and a full wait per load
@@ -112,11 +127,17 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
                 *reinterpret_cast<f32x4*>(Qt + (r + 16 * j) * PS + 4 * q) = o;
             }
         };
-        fetch(tile_begin);
-        for (int tile = tile_begin; tile < tile_end; ++tile) {
-            float* Pt = smem + ((tile - tile_begin) & 1) * BUF;
+        int tl = u0 / p.ntiles, tile = u0 - tl * p.ntiles;
+        set_rows(tl);
+        fetch(tile);
+        for (int u = u0, it = 0; u < u1; ++it) {
+            float* Pt = smem + (it & 1) * BUF;
             commit(Pt, Pt + PIMG);
-            if (tile + 1 < tile_end) fetch(tile + 1);     // in flight while the consumers work on this tile
+            ++u;
+            if (u < u1 && !(p.exp & 1)) {              // the next unit is in flight while the consumers work on this one
+                if (++tile == p.ntiles) { tile = 0; ++tl; set_rows(tl); }     // (tuning builds, S2K_WG_EXP: 1 = stage the first unit only,
+                fetch(tile);                                                    //  4 = no MFMA loop)
+            }
             __syncthreads();
         }
         return;
@@ -128,18 +149,23 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
     __builtin_amdgcn_s_setprio(2);
     const int wm0 = (wave >> 1) * (WM * 32), wc0 = (wave & 1) * (WN * 32);
     f32x16 acc[1][WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) acc[0][i][j][rr] = 0.0f;
     const int a_off = (wm0 + l31) * PS + 4 * lh;                 // + rm * 32 * PS + 8 g
     const int b_off = PIMG + (wc0 + l31) * PS + 4 * lh;          // + rn * 32 * PS + 8 g
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        __syncthreads();                                         // buffer (k & 1) is full
-        const float* img = smem + ((tile - tile_begin) & 1) * BUF;
+    int it = 0;
+    for (int u = u0; u < u1;) {
+      const int tl = u / p.ntiles;
+      const int seg_end = min(u1, (tl + 1) * p.ntiles);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+#pragma unroll
+              for (int rr = 0; rr < 16; ++rr) acc[0][i][j][rr] = 0.0f;
+      for (; u < seg_end; ++u, ++it) {
+        __syncthreads();                                         // buffer (it & 1) is full
+        if (p.exp & 4) continue;
+        const float* img = smem + (it & 1) * BUF;
         const float* Pa = img + a_off;
         const float* Qb = img + b_off;
         auto lds_operands = [&](int g, f32x4 (&a)[WM], f32x4 (&b)[WN]) {      // g is a compile-time constant after unrolling
@@ -178,8 +204,10 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
             interleave();
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      // flush this output tile's sums (no LDS involved: the producers may already be staging the next segment's first unit)
+      wg_combine<1, WM, WN, 1>(p, acc, smem, 0, wave, lane, (tl % p.n_mtiles) * BM, (tl / p.n_mtiles) * BC, wm0, wc0);
     }
-    wg_combine<1, WM, WN, 1>(p, acc, smem, 0, wave, lane, m0, c0, wm0, wc0);
 }
 
 template <int WM, int WN, int PROP, int PROQ>
@@ -213,7 +241,20 @@ static int launch_q4w(WgradP& p, hipStream_t st) {
     }
     p.tiles_per_split = cdiv(p.ntiles, splits);
     splits = cdiv(p.ntiles, p.tiles_per_split);
-    hipLaunchKernelGGL(kern, dim3(mc * splits), dim3(512), lds, st, p);
+    // stream form: equal unit ranges over one round of workgroups; a range of n units crosses into 1 + (n - 1) / ntiles further output
+    // tiles at most, and every crossing (and the end) is a flush.  OFF in the shipped library: alone it is what the model says
+    // (768 x 3072 over 3,328 tokens 87 -> 105 TF/s, 2304 x 768 88 -> 102; all weight gradients of the MAE step 13.2 -> 12.0 ms), inside
+    // the step it LOSES (alternating runs, tools/exp_wq4_step.sh: 41.59 vs 41.42 ms) - these kernels run on the side stream beside the
+    // data gradients of the critical path, and 256 workgroups that hold their CU for the whole kernel leave those no gaps, whereas
+    // the pixel splits' short workgroups (and the idle CUs of their last round) do.  DESIGN.md lesson 22.
+    static const int streamk = tune_int("S2K_WG_STREAMK", 0);      // 0: never, 1: where the cost model prefers it, 2: always
+    const int64_t total = (int64_t)mc * p.ntiles;
+    const int grid_sk = (int)std::min<int64_t>(slots, total);
+    const double per_wg = (double)cdiv64(total, grid_sk);
+    const double cost_sk = per_wg + (WM * WN >= 4 ? 2.0 : 1.0) * (2.0 + (double)((int64_t)(per_wg - 1) / p.ntiles));
+    p.streamk = (streamk == 2 || (streamk == 1 && cost_sk < 0.95 * best)) ? 1 : 0;
+    if (total > 0x7fffffff) p.streamk = 0;
+    hipLaunchKernelGGL(kern, dim3(p.streamk ? grid_sk : mc * splits), dim3(512), lds, st, p);
     g_s2k_variant = 4;
     return S2K_OK;
 }
@@ -233,7 +274,7 @@ int launch_wgrad_q4(WgradP& p, int mode, hipStream_t st) {
     if (!enabled || p.gatep || p.gateq || p.p_bf16) return 1;
     if (mode != S2K_MODE_CONV || p.T != 1 || p.S != 1 || p.H != p.HO || p.W != p.WO) return 1;
     if (p.M <= 32 || p.C <= 32 || (p.HWp & 3) || p.HWq != p.HWp) return 1;
-    if ((int64_t)p.B * p.HWp < 1024) return 1;
+    if ((int64_t)p.B * p.HWp < 1024 || (int64_t)p.B * p.HWp > 0x7fffffffll) return 1;
     if ((reinterpret_cast<uintptr_t>(p.p) | reinterpret_cast<uintptr_t>(p.q)) & 15) return 1;
     // tile edge per side: 128 unless it pads the side by more than 12 % (as wgrad_pc.hip)
     auto edge = [](int n) { return (n > 64 && (double)cdiv(n, 128) * 128 / n <= 1.12) ? 128 : 64; };
