@@ -27,6 +27,27 @@ __device__ __forceinline__ float q4_pro(float v, float sc, float sh, float bound
     return __builtin_amdgcn_fmed3f(fmaf(v, sc, sh), 0.0f, bound);      // ReLU; bound = 0 for a pixel past the end (else +inf)
 }
 
+// BatchNorm + SiLU + SE gate of four pixels of one channel (the MBConv project conv's operand): two-wide vector arithmetic so that the
+// affine part, the 1 + e^-u and the final products are v_pk_* instructions - the producer's budget beside the MFMA stream is its
+// INSTRUCTION count.  `gate` is 0 for a quad past the end.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 q4_silu_gate(f32x4 v, float sc, float sh, float gate) {
+#ifdef S2K_EXACT_SILU
+    return f32x4{silu_f(fmaf(v[0], sc, sh)) * gate, silu_f(fmaf(v[1], sc, sh)) * gate, silu_f(fmaf(v[2], sc, sh)) * gate, silu_f(fmaf(v[3], sc, sh)) * gate};
+#endif
+    const f32x2 s2 = {sc, sc}, h2 = {sh, sh}, g2 = {gate, gate}, one = {1.0f, 1.0f};
+    f32x2 u0 = {v[0], v[1]}, u1 = {v[2], v[3]};
+    u0 = u0 * s2 + h2;
+    u1 = u1 * s2 + h2;
+    f32x2 e0 = {__expf(-u0[0]), __expf(-u0[1])}, e1 = {__expf(-u1[0]), __expf(-u1[1])};
+    e0 += one;
+    e1 += one;
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(e0[0]), __builtin_amdgcn_rcpf(e0[1])}, r1 = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+    u0 = u0 * g2 * r0;
+    u1 = u1 * g2 * r1;
+    return f32x4{u0[0], u0[1], u1[0], u1[1]};
+}
+
 template <int WM, int WN, int PROP, int PROQ>
 __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
     constexpr int NT = 256;
@@ -37,7 +58,7 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
     constexpr int NMP = BM / 16, NCP = BC / 16;    // rows per producer thread and tile (16 rows per pass: 16 quads x 16 rows = 256 threads)
     constexpr int PIMG = BM * PS, BUF = (BM + BC) * PS;
     static_assert(PROP == S2K_PRO_NONE || PROP == S2K_PRO_RELU, "P prologue");
-    static_assert(PROQ == S2K_PRO_NONE || PROQ == S2K_PRO_RELU, "Q prologue");
+    static_assert(PROQ == S2K_PRO_NONE || PROQ == S2K_PRO_RELU || PROQ == S2K_PRO_SILU, "Q prologue (SiLU: with the SE gate)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const bool producer = threadIdx.x >= NT;       // wave-uniform
@@ -73,6 +94,8 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
         const bool img_local = (p.HWp % NPJ) == 0;
         float psc[NMP], psh[NMP], qsc[NCP], qsh[NCP];
         uint32_t prow[NMP], qrow[NCP];              // byte offset of the (clamped) row inside an image
+        int qch[NCP];                               // the (clamped) channel: index of its SE gate
+        float qgate[NCP];                           // SiLU: gate[b][channel] of the tile held in qreg (0 for a quad past the end)
         auto set_rows = [&](int tl) {               // the output tile's rows: once per segment
             const int m0 = (tl % p.n_mtiles) * BM, c0 = (tl / p.n_mtiles) * BC;
 #pragma unroll
@@ -86,6 +109,7 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
             for (int j = 0; j < NCP; ++j) {
                 const int gc = min(c0 + r + 16 * j, p.C - 1);
                 qrow[j] = (uint32_t)gc * (uint32_t)p.HWq * 4u;
+                qch[j] = gc;
                 qsc[j] = PROQ != S2K_PRO_NONE ? p.bnvq[gc] : 1.0f;
                 qsh[j] = PROQ != S2K_PRO_NONE ? p.bnvq[p.C + gc] : 0.0f;
             }
@@ -109,6 +133,13 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
                                                                               // which hipcc would turn into a branch and a full wait per load
 #pragma unroll
             for (int j = 0; j < NCP; ++j) qreg[j] = bload4(rq, qv + qrow[j]);
+            if (PROQ == S2K_PRO_SILU) {
+#pragma unroll
+                for (int j = 0; j < NCP; ++j) {
+                    const float gv = p.gateq ? p.gateq[(int64_t)b * p.C + qch[j]] : 1.0f;     // (b = 0 for a quad past the end: a valid address)
+                    qgate[j] = ok ? gv : 0.0f;
+                }
+            }
             bound = ok ? __builtin_inff() : 0.0f;
         };
         auto commit = [&](float* Pt, float* Qt) {
@@ -122,8 +153,11 @@ __global__ void __launch_bounds__(512) wgrad_q4_kernel(const WgradP p) {
 #pragma unroll
             for (int j = 0; j < NCP; ++j) {
                 f32x4 o;
+                if (PROQ == S2K_PRO_SILU) o = q4_silu_gate(qreg[j], qsc[j], qsh[j], qgate[j]);
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = q4_pro<PROQ>(qreg[j][e], qsc[j], qsh[j], bound);
+                    for (int e = 0; e < 4; ++e) o[e] = q4_pro<(PROQ == S2K_PRO_SILU ? S2K_PRO_NONE : PROQ)>(qreg[j][e], qsc[j], qsh[j], bound);
+                }
                 *reinterpret_cast<f32x4*>(Qt + (r + 16 * j) * PS + 4 * q) = o;
             }
         };
@@ -265,6 +299,7 @@ static int launch_q4w_pro(WgradP& p, hipStream_t st) {
     if (pp == S2K_PRO_NONE && pq == S2K_PRO_NONE) return launch_q4w<WM, WN, S2K_PRO_NONE, S2K_PRO_NONE>(p, st);
     if (pp == S2K_PRO_NONE && pq == S2K_PRO_RELU) return launch_q4w<WM, WN, S2K_PRO_NONE, S2K_PRO_RELU>(p, st);
     if (pp == S2K_PRO_RELU && pq == S2K_PRO_NONE) return launch_q4w<WM, WN, S2K_PRO_RELU, S2K_PRO_NONE>(p, st);
+    if (pp == S2K_PRO_NONE && pq == S2K_PRO_SILU) return launch_q4w<WM, WN, S2K_PRO_NONE, S2K_PRO_SILU>(p, st);      // (+ the SE gate of Q)
     return 1;
 }
 
@@ -492,8 +527,9 @@ static int launch_wgrad_q4_spatial(WgradP& p, hipStream_t st) {
 
 // S2K_OK = launched, 1 = not one of this kernel's shapes (the caller goes on to wgrad_pc.hip / the generic kernels), < 0 = error
 int launch_wgrad_q4(WgradP& p, int mode, hipStream_t st) {
-    static const int enabled = tune_int("S2K_WG_Q4", 3);      // bit 0: 1x1, bit 1: 3x3
-    if (!enabled || p.gatep || p.gateq || p.p_bf16) return 1;
+    static const int enabled = tune_int("S2K_WG_Q4", 7);      // bit 0: 1x1, bit 1: 3x3, bit 2: 1x1 with the SiLU + SE-gate operand
+    if (!enabled || p.gatep || p.p_bf16) return 1;
+    if (p.gateq && (p.proq != S2K_PRO_SILU || p.T != 1 || !(enabled & 4))) return 1;      // the SE-gated operand of the project convs: 1x1, SiLU
     if (mode != S2K_MODE_CONV || p.S != 1 || p.H != p.HO || p.W != p.WO) return 1;
     if ((reinterpret_cast<uintptr_t>(p.p) | reinterpret_cast<uintptr_t>(p.q)) & 15) return 1;
     if (p.T == 9) return (enabled & 2) ? launch_wgrad_q4_spatial(p, st) : 1;
