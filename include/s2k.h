@@ -82,8 +82,7 @@ int s2k_program_profile_ops(const S2kOp* ops, int begin, int end, void* const* b
 /* same, plus which kernel the stage's launcher picked: variant_per_op[i] = 0 for the stage's generic kernel
  * (conv_igemm_kernel, wgrad_kernel, ...), 1 for the producer/consumer kernel (conv_pc_kernel / wgrad_pc_kernel), 2 for the
  * bf16 MFMA kernels (conv_bf16_kernel / wgrad_bf16_kernel; S2K_FLAG_BF16 stages), 3 for the LDS-DMA ring kernel
- * (conv_dma_kernel), 4 for the quad-read kernels (conv_q4_kernel: S2K_FLAG_Q4 stages; wgrad_q4_kernel / wgrad_q4s_kernel: picked by
- * the launcher).
+ * (conv_dma_kernel), 4 for the quad-read kernels (conv_q4_kernel: S2K_FLAG_Q4 stages; wgrad_q4_kernel: picked by the launcher).
  * bench.py uses it to attribute time and algorithmic FLOPs to the kernel names a rocprofv3 trace shows. */
 int s2k_program_profile_variants(const S2kOp* ops, int begin, int end, void* const* bases, int n_bases, void* stream,
                                  float* ms_per_op, int* variant_per_op);

@@ -26,8 +26,10 @@
 
 namespace s2k {
 
-#ifdef S2K_TUNING
-__device__ unsigned long long g_wg_dbg[8];      // tuning builds: {consumer barrier-wait cycles, compute cycles, tiles, producer wait, producer work}
+// In-kernel stamps: only in the stamps build (-DS2K_TUNING -DS2K_DMA_STAMPS, libs2k_stamps.so).  They used to be part of every tuning
+// build and made wgrad_pc_kernel 5 - 8 % slower there than in the shipped library, which skewed every A/B run against it.
+#if defined(S2K_TUNING) && defined(S2K_DMA_STAMPS)
+__device__ unsigned long long g_wg_dbg[8];      // {consumer barrier-wait cycles, compute cycles, tiles, producer wait, producer work}
 #define WG_STAMP() __builtin_amdgcn_s_memtime()
 #define WG_DBG_ADD(i, v) do { dbg_acc[i] += (unsigned long long)(v); } while (0)
 #define WG_DBG_DECL() unsigned long long dbg_acc[5] = {0, 0, 0, 0, 0}
@@ -379,7 +381,7 @@ static int launch_pc_pix(WgradP& p, hipStream_t st) {
     return 1;      // SiLU / GELU prologues cost a producer too many instructions per tile: generic kernels
 }
 
-#ifdef S2K_TUNING
+#if defined(S2K_TUNING) && defined(S2K_DMA_STAMPS)
 extern "C" int s2k_debug_wg_counters(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_dbg), sizeof(g_wg_dbg)) != hipSuccess) return S2K_EHIP;
     if (reset) {

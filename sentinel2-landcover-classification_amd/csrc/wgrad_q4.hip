@@ -303,236 +303,19 @@ static int launch_q4w_pro(WgradP& p, hipStream_t st) {
     return 1;
 }
 
-// ---- 3x3 stride-1 convs (the U-Net decoder's double convs): the same quad reads over a halo tile --------------------------------------
-// A tile = R rows x XW columns = 64 output pixels (XW a power of two >= 8, so a lane's four consecutive pixels and a group's eight stay
-// inside one tile row); nine accumulator tiles (one per tap) per consumer wave as in wgrad_pc_kernel.  P = dY is the [m][pixel] image
-// of the 1x1 kernel.  Q is staged channel-major as [c][R + 2 rows][XW + 8 columns] with image column x0 - 4 in column 0, so that every
-// 16-byte group of a row is aligned in HBM and in LDS.  For output pixels x .. x + 3 and tap column dx the lane needs input columns
-// x + dx - 1 .. x + dx + 2: elements dx + 3 .. dx + 6 of the 12-column window [x - 4, x + 8) - ONE aligned ds_read_b128 (columns
-// x .. x + 3) plus the two dwords beside it serve the three taps of a row, and which register feeds which MFMA is decided at compile
-// time.  Per pixel group: 1 read of P + 9 of Q for 36 MFMAs (wgrad_pc_kernel: 10 reads for 9).
-template <int R, int XW, int PROQ>
-__global__ void __launch_bounds__(512) wgrad_q4s_kernel(const WgradP p) {
-    constexpr int NT = 256, BM = 64, BC = 64, T = 9;
-    constexpr int PS = 64 + 4;                     // P row stride (floats)
-    constexpr int IR = R + 2, WSQ = XW + 8;        // halo tile of one channel
-    constexpr int QCH = IR * WSQ;
-    constexpr int PSQ = QCH + ((4 - QCH % 32) + 32) % 32;      // channel stride = 4 mod 32 banks: 8 consecutive channels cover all banks
-    constexpr int QPR = WSQ / 4, QPC = IR * QPR;   // 16-byte groups per halo row / per channel
-    constexpr int NQ = BC * QPC, NQT = (NQ + NT - 1) / NT;      // ... per tile / per producer thread
-    constexpr int NMP = BM / 16;
-    constexpr int PIMG = BM * PS, BUF = PIMG + BC * PSQ;
-    constexpr int NG = 8;
-    static_assert(R * XW == 64 && XW % 8 == 0 && (XW & (XW - 1)) == 0, "tile geometry");
-    static_assert(PROQ == S2K_PRO_NONE || PROQ == S2K_PRO_RELU, "Q prologue");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const bool producer = threadIdx.x >= NT;
-    const int tid = threadIdx.x & (NT - 1);
-    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int mc = p.n_mtiles * p.n_ctiles;
-    const int v = wg_xcd_remap(blockIdx.x, gridDim.x);
-    const int split = v / mc, tl = v - split * mc;
-    const int mt = tl % p.n_mtiles, ct = tl / p.n_mtiles;
-    const int m0 = mt * BM, c0 = ct * BC;
-    const int tile_begin = split * p.tiles_per_split;
-    const int tile_end = min(tile_begin + p.tiles_per_split, p.ntiles);
-    if (tile_begin >= tile_end) return;            // (whole workgroup)
-
-    if (producer) {
-        // P: pixel quad q = tid & 15 of rows r + 16 i; Q: 16-byte groups tid + 256 i of the [channel][halo row][column group] list
-        const int q = tid & 15, r = tid >> 4;
-        const int prr = (4 * q) / XW, pxx = (4 * q) % XW;      // the quad's place in the tile
-        uint32_t prow[NMP];
-#pragma unroll
-        for (int i = 0; i < NMP; ++i) prow[i] = (uint32_t)min(m0 + r + 16 * i, p.M - 1) * (uint32_t)p.HWp * 4u;
-        uint32_t qchan[NQT];        // byte offset of the (clamped) channel plane
-        int qlds[NQT];              // float offset inside the Q image, or -1
-        int qdy[NQT], qdx[NQT];     // the group's first element relative to the tile origin
-        float qsc[NQT], qsh[NQT];
-#pragma unroll
-        for (int i = 0; i < NQT; ++i) {
-            const int idx = tid + NT * i;
-            const bool on = idx < NQ;
-            const int c = on ? idx / QPC : 0, qi = on ? idx - c * QPC : 0;
-            const int row = qi / QPR, cg = qi - row * QPR;
-            const int gc = min(c0 + c, p.C - 1);
-            qchan[i] = (uint32_t)gc * (uint32_t)p.HWq * 4u;
-            qlds[i] = on ? c * PSQ + row * WSQ + 4 * cg : -1;
-            qdy[i] = row - p.PT;
-            qdx[i] = 4 * cg - 4 + (1 - p.PL);          // column 0 of the halo row = x0 - 4 for PL = 1
-            qsc[i] = PROQ != S2K_PRO_NONE ? p.bnvq[gc] : 1.0f;
-            qsh[i] = PROQ != S2K_PRO_NONE ? p.bnvq[p.C + gc] : 0.0f;
-        }
-        f32x4 preg[NMP], qreg[NQT];
-        unsigned qin = 0;           // bit i: group i of the tile held in qreg lies inside the image
-        auto fetch = [&](int tile) {
-            const int tx = tile % p.tiles_x;
-            const int ty = (tile / p.tiles_x) % p.tiles_y;
-            const int b = tile / (p.tiles_x * p.tiles_y);
-            const int y0 = ty * R, x0 = tx * XW;
-            const rsrc_t rp = make_rsrc(p.p + (int64_t)b * p.M * p.HWp, (int64_t)p.M * p.HWp * 4);
-            const rsrc_t rq = make_rsrc(p.q + (int64_t)b * p.C * p.HWq, (int64_t)p.C * p.HWq * 4);
-            const bool pok = y0 + prr < p.HO && x0 + pxx < p.WO;              // (WO % 4 == 0: the whole quad)
-            const uint32_t pv = pok ? (uint32_t)((y0 + prr) * p.WO + x0 + pxx) * 4u : BUF_OOB;
-#pragma unroll
-            for (int i = 0; i < NMP; ++i) preg[i] = bload4(rp, pv + prow[i]);
-            qin = 0;
-#pragma unroll
-            for (int i = 0; i < NQT; ++i) {
-                const int iy = y0 + qdy[i], ix = x0 + qdx[i];
-                const bool ok = qlds[i] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;    // (W % 4 == 0, ix % 4 == 0: the whole group)
-                const uint32_t qv = ok ? (uint32_t)(iy * p.W + ix) * 4u : BUF_OOB;
-                qreg[i] = bload4(rq, qv + qchan[i]);
-                qin |= ok ? (1u << i) : 0u;
-            }
-        };
-        auto commit = [&](float* Pt, float* Qt) {
-#pragma unroll
-            for (int i = 0; i < NMP; ++i) *reinterpret_cast<f32x4*>(Pt + (r + 16 * i) * PS + 4 * q) = preg[i];
-#pragma unroll
-            for (int i = 0; i < NQT; ++i) {
-                const float bound = ((qin >> i) & 1u) ? __builtin_inff() : 0.0f;          // the reference pads ACTIVATED maps with zeros
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = q4_pro<PROQ>(qreg[i][e], qsc[i], qsh[i], bound);
-                if (qlds[i] >= 0) *reinterpret_cast<f32x4*>(Qt + qlds[i]) = o;
-            }
-        };
-        fetch(tile_begin);
-        for (int tile = tile_begin; tile < tile_end; ++tile) {
-            float* Pt = smem + ((tile - tile_begin) & 1) * BUF;
-            commit(Pt, Pt + PIMG);
-            if (tile + 1 < tile_end && !(p.exp & 1)) fetch(tile + 1);
-            __syncthreads();
-        }
-        return;
-    }
-
-    // CONSUMER
-    __builtin_amdgcn_s_setprio(2);
-    const int wm0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
-    f32x16 acc[T][1][1];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc[t][0][0][rr] = 0.0f;
-    const int a_off = (wm0 + l31) * PS + 4 * lh;
-    const int b_off = PIMG + (wc0 + l31) * PSQ + 4 * lh;
-
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        __syncthreads();
-        if (p.exp & 4) continue;
-        const float* img = smem + ((tile - tile_begin) & 1) * BUF;
-        const float* Pa = img + a_off;
-        const float* Qb = img + b_off;
-        // step s = g * 3 + dy (compile-time after unrolling): the lane's pixels 8 g + 4 lh .. + 3 sit in tile row (8 g) / XW at columns
-        // (8 g) % XW + 4 lh ..; halo row + dy; halo column = image column + 4
-        auto lds_q = [&](int s, float (&w)[6]) {
-            const int g = s / 3, dy = s % 3;
-            const float* row = Qb + ((8 * g) / XW + dy) * WSQ + (8 * g) % XW;
-            w[0] = row[3];
-            const f32x4 mid = *reinterpret_cast<const f32x4*>(row + 4);
-            w[1] = mid[0]; w[2] = mid[1]; w[3] = mid[2]; w[4] = mid[3];
-            w[5] = row[8];
-        };
-        auto mfmas = [&](int s, const f32x4& a, const float (&w)[6]) {
-            const int dy = s % 3;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    acc[dy * 3 + dx][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], w[k + dx], acc[dy * 3 + dx][0][0], 0, 0, 0);
-        };
-        auto interleave = [&]() {      // the next step's reads (3 of Q, every third step 1 of P) spread over this step's 12 MFMAs
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        };
-        f32x4 pa[2];
-        float w0[6], w1[6];
-        pa[0] = *reinterpret_cast<const f32x4*>(Pa);
-        lds_q(0, w0);
-#pragma unroll
-        for (int s = 0; s < 3 * NG; s += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            if ((s + 1) % 3 == 0) pa[((s + 1) / 3) & 1] = *reinterpret_cast<const f32x4*>(Pa + 8 * ((s + 1) / 3));
-            lds_q(s + 1, w1);
-            mfmas(s, pa[(s / 3) & 1], w0);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < 3 * NG) {
-                if ((s + 2) % 3 == 0) pa[((s + 2) / 3) & 1] = *reinterpret_cast<const f32x4*>(Pa + 8 * ((s + 2) / 3));
-                lds_q(s + 2, w0);
-            }
-            mfmas(s + 1, pa[((s + 1) / 3) & 1], w1);
-            interleave();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    wg_combine<T, 1, 1, 1>(p, acc, smem, 0, wave, lane, m0, c0, wm0, wc0);
-}
-
-template <int R, int XW, int PROQ>
-static int launch_q4s(WgradP& p, hipStream_t st) {
-    constexpr int IR = R + 2, WSQ = XW + 8, QCH = IR * WSQ, PSQ = QCH + ((4 - QCH % 32) + 32) % 32;
-    constexpr size_t lds = (size_t)2 * (64 * 68 + 64 * PSQ) * sizeof(float);
-    static_assert(lds <= 160 * 1024, "LDS image");
-    p.n_mtiles = cdiv(p.M, 64);
-    p.n_ctiles = cdiv(p.C, 64);
-    p.R = R; p.XW = XW; p.XWe = XW;
-    p.tiles_x = cdiv(p.WO, XW);
-    p.tiles_y = cdiv(p.HO, R);
-    p.ntiles = p.B * p.tiles_x * p.tiles_y;
-    p.NP = 0;
-    p.streamk = 0;
-    if (std::max((int64_t)p.M * p.HWp, (int64_t)p.C * p.HWq) * 4 >= 0x7ffffff0ll) { set_error("wgrad: an image exceeds 2 GiB"); return S2K_EINVAL; }
-    auto kern = wgrad_q4s_kernel<R, XW, PROQ>;
-    static PerDeviceOnce attr_once;
-    attr_once.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    const int mc = p.n_mtiles * p.n_ctiles;
-    const int slots = 256;
-    int max_splits = std::max(1, std::min(65535, cdiv(p.ntiles, 4)));
-    int splits = 1;
-    double best = 1e30;
-    const int s_hi = std::min(max_splits, std::max(1, 4 * slots / mc));
-    for (int sp = 1; sp <= s_hi; ++sp) {
-        const double rounds = (double)cdiv(mc * sp, slots);
-        const double cost = rounds * ((double)cdiv(p.ntiles, sp) + 1.0);
-        if (cost < best * 0.999) { best = cost; splits = sp; }
-    }
-    p.tiles_per_split = cdiv(p.ntiles, splits);
-    splits = cdiv(p.ntiles, p.tiles_per_split);
-    hipLaunchKernelGGL(kern, dim3(mc * splits), dim3(512), lds, st, p);
-    g_s2k_variant = 4;
-    return S2K_OK;
-}
-
-static int launch_wgrad_q4_spatial(WgradP& p, hipStream_t st) {
-    if (p.KH != 3 || p.KW != 3 || p.PT != 1 || p.PL != 1 || p.prop != S2K_PRO_NONE) return 1;
-    if (p.proq != S2K_PRO_NONE && p.proq != S2K_PRO_RELU) return 1;
-    if (p.M <= 32 || (p.M <= 64 && p.C <= 32)) return 1;                 // thin layers: wgrad_pc.hip's 128-pixel kernels
-    if ((p.W & 3) || (p.WO & 3)) return 1;
-    const bool relu = p.proq == S2K_PRO_RELU;
-#define Q4S(RR, XX) return relu ? launch_q4s<RR, XX, S2K_PRO_RELU>(p, st) : launch_q4s<RR, XX, S2K_PRO_NONE>(p, st);
-    if (p.WO >= 64 && p.WO % 64 == 0 && p.HO >= 1) Q4S(1, 64)
-    if (p.WO == 32 && p.HO >= 2) Q4S(2, 32)
-    if (p.WO == 16 && p.HO >= 4) Q4S(4, 16)
-    if (p.WO == 8 && p.HO >= 8) Q4S(8, 8)
-#undef Q4S
-    return 1;
-}
+// (A 3x3 form of this kernel existed in round 4 - `wgrad_q4s_kernel`: channel-major halo tile [c][R + 2][XW + 8], an aligned 16-byte group
+// plus the two dwords beside it serving the three taps of a row, 10 LDS reads per 36 MFMAs instead of 10 per 9.  Alone it ran the decoder's
+// weight gradients at 118 - 124 TF/s against wgrad_pc_kernel's 112 - 118; in the step it changed nothing (alternating runs, tools/
+// exp_wq4_unet.sh: 32.57 vs 32.58 ms) - those stages sit on the side stream under the encoder's backward, off the critical path - and was
+// removed.  git: "wgrad_q4s_kernel".)
 
 // S2K_OK = launched, 1 = not one of this kernel's shapes (the caller goes on to wgrad_pc.hip / the generic kernels), < 0 = error
 int launch_wgrad_q4(WgradP& p, int mode, hipStream_t st) {
-    static const int enabled = tune_int("S2K_WG_Q4", 7);      // bit 0: 1x1, bit 1: 3x3, bit 2: 1x1 with the SiLU + SE-gate operand
+    static const int enabled = tune_int("S2K_WG_Q4", 5);      // bit 0: 1x1, bit 2: 1x1 with the SiLU + SE-gate operand
     if (!enabled || p.gatep || p.p_bf16) return 1;
     if (p.gateq && (p.proq != S2K_PRO_SILU || p.T != 1 || !(enabled & 4))) return 1;      // the SE-gated operand of the project convs: 1x1, SiLU
     if (mode != S2K_MODE_CONV || p.S != 1 || p.H != p.HO || p.W != p.WO) return 1;
     if ((reinterpret_cast<uintptr_t>(p.p) | reinterpret_cast<uintptr_t>(p.q)) & 15) return 1;
-    if (p.T == 9) return (enabled & 2) ? launch_wgrad_q4_spatial(p, st) : 1;
     if (p.T != 1 || !(enabled & 1)) return 1;
     if (p.M <= 32 || p.C <= 32 || (p.HWp & 3) || p.HWq != p.HWp) return 1;
     if ((int64_t)p.B * p.HWp < 1024 || (int64_t)p.B * p.HWp > 0x7fffffffll) return 1;

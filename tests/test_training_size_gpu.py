@@ -202,7 +202,7 @@ def test_unet_bs32_plan_uses_the_benchmark_kernels_and_equals_the_bs8_step(unet_
     print("bs-32 plan kernel selection (stage kind, producer/consumer variant) -> launches:", variants)
     # weight gradients: the producer / consumer families - wgrad_pc_kernel (1) and, since round 4, the quad-read wgrad_q4 kernels (4)
     assert variants.get(("CONV", 1), 0) >= 50 and variants.get(("WGRAD", 1), 0) + variants.get(("WGRAD", 4), 0) >= 45, variants
-    assert variants.get(("WGRAD", 4), 0) >= 40, variants
+    assert variants.get(("WGRAD", 4), 0) >= 40, variants      # the 1x1 weight gradients, incl. the SE-gated project convs
     # ---- (ii) the replicated-batch property ---------------------------------------------------------------------------
     lg = logits.detach().cpu()
     for r in range(rep):
