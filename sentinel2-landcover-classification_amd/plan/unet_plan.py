@@ -784,14 +784,24 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
 
     q4 = {"base": 0, "packs_end": 0}
 
-    def pack_op(prog: Program, rows):
+    def pack_op(prog: Program, rows, flags: int = 0):
         if not rows:
             return
         total = rows[-1][11] + rows[-1][10] * rows[-1][4] * rows[-1][9]
         extra = {"Q4_BASE": q4["base"]} if q4["base"] and any(r[8] & 2 for r in rows) else {}
+        if flags:
+            extra["_flags"] = flags
         prog.ops.insert(0, ("WEIGHT_PACK", dict(TABLE=table(rows, 12), SRC=TRef(D.BASE["PARAMS"], 0, (layout.n_params,)),
                                                 DST=TRef(D.BASE["WPACK"], 0, (q4["packs_end"] // 4,)), TOTAL=total,
                                                 N_ENTRIES=len(rows), **extra)))
+
+    # f32 training plans: the BACKWARD's weight copies (transposed for the data gradients) are written during the FORWARD, on the
+    # executor's side stream, which has nothing else to do there - 0.17 ms (U-Net b5) off the main queue, which IS the step
+    # (profiles/r03_unet_streams.txt: busy 31.0 of 32.5 ms): +0.4 % in alternating runs (tools/exp_pack_side.sh; the ViT plans switch it off).  Legal because nothing changes the parameters between a forward and
+    # its backward (the optimiser runs after it), the two programs' copies live in different parts of WPACK, and no forward stage
+    # touches the backward's part; the side stream is forked from the caller's stream at the start of the run (so it sees the previous
+    # step's Adam) and joined at its end.  bf16-mixed plans keep the pack in front of the backward (mark_bf16 looks for it there).
+    bwd_pack_in_fwd = p.want_bwd and not getattr(p, "bf16", False) and getattr(p, "pack_side", True) and tune("S2K_PACK_SIDE", "1") != "0"
 
     def attach_q4():       # (once every CONV stage exists and before the pack tables are built)
         q4["packs_end"] = p.wpack.mark()
@@ -863,13 +873,16 @@ def finish_plan(p: "_P", layout: ParamLayout, training: bool, bucket_floats: int
         side_stream_hazards(p.bwd)
         n_before = len(p.bwd.ops)
         attach_q4()
-        pack_op(p.bwd, p.pack_rows["bwd"])
+        if not bwd_pack_in_fwd:
+            pack_op(p.bwd, p.pack_rows["bwd"])
         if len(p.bwd.ops) > n_before:   # WEIGHT_PACK went in front
             segments = [(a + 1 if a else 0, b + 1, lo, hi) for (a, b, lo, hi) in segments]
         bwd = p.bwd
     else:
         attach_q4()
     pack_op(p.fwd, p.pack_rows["fwd"])
+    if bwd_pack_in_fwd:
+        pack_op(p.fwd, p.pack_rows["bwd"], D.FLAG_SIDE)       # (in front of everything: forked before the forward's own pack is enqueued)
     attach_splitk_scratch()
     if getattr(p, "bf16", False):
         mark_bf16(p, bwd)

@@ -215,6 +215,9 @@ class _V:
 
     def __init__(self, p: _P, trainable):
         self.p = p
+        p.pack_side = False            # the backward's weight copies stay in front of the backward: written during the forward on the side
+                                       # stream they cost the MAE 0.15 % (2 x 344 MB of HBM traffic beside MFMA-bound Linears that have no
+                                       # slack; the U-Net gains 0.4 %: tools/exp_pack_side.sh)
         self.trainable = trainable     # name -> bool (frozen backbone: no parameter gradients, no wgrad stages)
         self._ident: dict[int, TRef] = {}
 
