@@ -387,6 +387,42 @@ def test_rccl_world_size_one_reducer(tmp_path):
     _close(res["grads"].to(DEV), _flat_grads(model), 2e-6)
 
 
+def test_rccl_world_size_one_sharded_adam(tmp_path):
+    """The sharded collective on RCCL itself (world size 1: one rank owns every slice): reduce_scatter_tensor into the shard buffer,
+    Adam over the owned slices, all_gather_into_tensor of the parameters, consolidate_state - the native path that the gloo
+    rehearsals may have to emulate - must leave the weights and moments of three plain FlatAdam steps without any reducer."""
+    import os
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "ddp_worker.py"), "0", "1", env["MASTER_PORT"], str(tmp_path), "unet_eval_sharded", "nccl"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = torch.load(tmp_path / "unet_eval_sharded.r0.pt")
+    assert res["backend"] == "nccl" and res["native"] is True and res["refused"]
+    # the same three steps (two plain, the third as two accumulated micro-batches) in this process, no reducer
+    from s2lc_amd.optim import FlatAdam
+
+    model, x, y, noise, loss_fn = build_case("unet_eval", seed=5)
+    model.to(DEV)
+    model._defer_wgrads = False
+    opt = FlatAdam(model, lr=1e-2, weight_decay=0.01)
+    n = x.shape[0]
+    for step in range(3):
+        opt.zero_grad()
+        if step == 2:
+            run_shard(model, "unet_eval", x, y, noise, loss_fn, 0, n // 2, DEV)
+            run_shard(model, "unet_eval", x, y, noise, loss_fn, n // 2, n, DEV)
+        else:
+            run_shard(model, "unet_eval", x, y, noise, loss_fn, 0, n, DEV)
+        opt.step()
+    torch.cuda.synchronize()
+    sd = opt.state_dict()["state"]
+    for k, ref in (("params", model._flat_params.detach().cpu()), ("m", sd["exp_avg"].cpu()), ("v", sd["exp_avg_sq"].cpu())):
+        scale = ref.abs().max().item()
+        err = (res[k] - ref).abs().max().item()
+        assert err <= 2e-4 * scale, f"{k}: {err:.3e} of {scale:.3e}"
+
+
 @pytest.mark.parametrize("case", ["unet_eval", "unet_train", "mae"])
 def test_two_rank_rehearsal_matches_ddp_semantics(case, tmp_path):
     world = 2
